@@ -1,0 +1,75 @@
+"""CPU: the C++ oracle against the committed torch-autograd golden vectors (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import rd_oracle as O
+from tests import helpers as H
+
+TOL = 1e-10   # fp64 parity tolerance of BASELINE.json's north_star
+
+
+@pytest.mark.parametrize("name", H.dyn_cases())
+def test_dynamics_and_steps(name):
+    d = H.load("dyn_" + name)
+    M = H.oracle_model(name, d)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    np.testing.assert_allclose(M.dynamics(Z, t, dt), d["xdot"], rtol=0, atol=TOL)
+    for rn, rule in H.RULES.items():
+        for sig in (O.STATIC_RETURN, O.INPLACE):
+            np.testing.assert_allclose(M.discrete_dynamics(rule, Z, t, dt, sig), d["xn_" + rn], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("name", H.dyn_cases())
+def test_forward_ad_jacobians(name):
+    d = H.load("dyn_" + name)
+    M = H.oracle_model(name, d)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    J, Y = M.jacobian(O.CONTINUOUS, O.FORWARD_AD, Z, t, dt)
+    np.testing.assert_allclose(J, d["Jc"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(Y, d["xdot"], rtol=0, atol=TOL)
+    for rn, rule in H.RULES.items():
+        J, Y = M.jacobian(rule, O.FORWARD_AD, Z, t, dt)
+        np.testing.assert_allclose(J, d["Jd_" + rn], rtol=0, atol=TOL)
+        np.testing.assert_allclose(Y, d["xn_" + rn], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("name", H.dyn_cases())
+def test_finite_difference_within_1e6(name):
+    # reference tolerance for FiniteDifference: atol = 1e-6  (test/integration_tests.jl:14)
+    d = H.load("dyn_" + name)
+    M = H.oracle_model(name, d)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    J, _ = M.jacobian(O.CONTINUOUS, O.FINITE_DIFF, Z, t, dt)
+    scale = max(1.0, np.abs(d["Jc"]).max())
+    np.testing.assert_allclose(J, d["Jc"], rtol=0, atol=1e-6 * scale)
+    J, _ = M.jacobian(O.RK4, O.FINITE_DIFF, Z, t, dt)
+    np.testing.assert_allclose(J, d["Jd_rk4"], rtol=0, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("name", [n for n in H.dyn_cases() if not n.startswith(("satpair", "liesat"))])
+def test_user_defined_chain_rule(name):
+    # chain rule == AD through the step to 1e-10 (test/integration_tests.jl:7-18,64-71,102-109)
+    d = H.load("dyn_" + name)
+    M = H.oracle_model(name, d)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    J, _ = M.jacobian(O.CONTINUOUS, O.USER, Z, t, dt)
+    np.testing.assert_allclose(J, d["Jc"], rtol=0, atol=TOL * max(1.0, np.abs(d["Jc"]).max()))
+    for rn, rule in H.RULES.items():
+        J, Y = M.jacobian(rule, O.USER, Z, t, dt)
+        np.testing.assert_allclose(J, d["Jd_" + rn], rtol=0, atol=TOL * max(1.0, np.abs(d["Jd_" + rn]).max()))
+        np.testing.assert_allclose(Y, d["xn_" + rn], rtol=0, atol=TOL)
+
+
+def test_user_defined_missing_raises():
+    M = O.satellite_pair()
+    with pytest.raises(NotImplementedError):
+        M.jacobian(O.CONTINUOUS, O.USER, np.ones((1, 20)), 0.0, 0.1)
+
+
+@pytest.mark.parametrize("tag,mk", [("rigid", O.satellite), ("satpair", O.satellite_pair), ("liesat", O.lie_satellite)])
+def test_errstate(tag, mk):
+    d = H.load("err_" + tag)
+    M = mk()
+    np.testing.assert_allclose(M.errstate_jacobian(d["X"]), d["G"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(M.nabla_errstate_jacobian(d["X"], d["Xbar"]), d["dG"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(M.state_diff(d["X"], d["X0"]), d["dX"], rtol=0, atol=1e-9)
