@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- knot-point Jacobians/sec of the batched RK4 discrete Jacobian (n = 13) on MI355X.
+
+A "step" is ONE pass of the hot path over one batch: `jacobian!(StaticReturn(), ForwardAD(),
+DiscretizedDynamics{RK4}(Satellite), J[k], y[k], Z[k])` for all k = 1..65536 (BASELINE.json configs[2]:
+Satellite RigidBody{QuatRotation}, n=13, m=6, RK4 dynamics + Jacobian, 65 536 knot points), ONE kernel launch that
+writes the 13x19 Jacobian and x_{k+1} of every knot point.  Inputs are resident in HBM before the timed region.
+Outputs rotate over 4 buffers (4 x 136 MB > the 256 MiB Infinity Cache) so steps do not rewrite cache-resident lines.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), every rank owns 65 536 knot points
+(weak scaling), no data-path collective in the timed region; the optional gather of the stacked Jacobians over xGMI
+is timed separately (`--gather all|root`) and reported beside the kernel-only figure.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 bench.py --gpus 8
+"""
+import argparse
+import json
+import os
+import sys
+import time as _time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "robotdynamics.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import rdhip as RD  # noqa: E402
+from rdhip import parallel as P  # noqa: E402
+
+N_PER_GPU = 65536
+NX, NU = 13, 6
+NZ = NX + NU
+# algorithmic bytes per knot point (SURVEY 8d / BASELINE.md section 2): read z (19 fp64) + t + dt, write J (13x19 fp64) + x_next (13 fp64)
+BYTES_PER_KNOT = NZ * 8 + 16 + NX * NZ * 8 + NX * 8       # 2248
+HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+NBUF = 4
+
+
+def synthetic_inputs(N, seed):
+    """rand(model) for a RigidBody{QuatRotation}: r, v, w, u ~ U[0,1), q uniform on S^3 (src/rigidbody.jl:50-59);
+    dt = 0.1, t_k = k dt (examples/single_satellite.jl:39)."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((N, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    Z = np.concatenate([rng.random((N, 3)), q, rng.random((N, 6)), rng.random((N, NU))], axis=1)
+    return Z, np.arange(N) * 0.1, np.full(N, 0.1)
+
+
+def cpu_baseline(Zn, t, dt, budget_s=12.0):
+    """The CPU oracle (a C++ port of the reference math, OpenMP over all host cores) on a bounded sample of the same
+    workload.  Reported beside the GPU figure; it is the checker being timed, never part of the product path."""
+    from oracle import rd_oracle as O
+    om = O.satellite()
+    n_s = 16384
+    om.jacobian(O.RK4, O.FORWARD_AD, Zn[:n_s], t[:n_s], dt[:n_s])   # warm
+    done, t0 = 0, _time.perf_counter()
+    while _time.perf_counter() - t0 < budget_s:
+        om.jacobian(O.RK4, O.FORWARD_AD, Zn[:n_s], t[:n_s], dt[:n_s])
+        done += n_s
+    el = _time.perf_counter() - t0
+    return {"value": done / el, "unit": "knot-point Jacobians/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"{done} knot points ({done // n_s} x {n_s}) of the same Satellite RK4 ForwardAD workload in {el:.1f} s, OpenMP over {O.num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gather", choices=["none", "all", "root"], default="all", help="also time the RCCL exchange of the stacked Jacobians (N>1 only; reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
+    args = ap.parse_args()
+
+    rank, local_rank, world = P.env_rank_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N = args.knots
+    Zn, t, dt = synthetic_inputs(N, seed=3 + rank)
+    model = RD.Satellite()                       # mass 1, J = I3 (examples/single_satellite.jl:33-35)
+    dmodel = RD.DiscretizedDynamics(model, RD.RK4)
+    Z = RD.PackedTrajectory(NX, NU, Zn, t, dt).to(dev)
+    Js = [RD.alloc_jacobians(dmodel, N, Z.data) for _ in range(NBUF)]
+    Ys = [torch.empty((N, NX), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    sig, diff = RD.StaticReturn(), RD.ForwardAD()
+
+    def step(i):
+        RD.jacobian_(sig, diff, dmodel, Js[i % NBUF], Ys[i % NBUF], Z)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    # kernel time: HIP events on the stream the kernel is launched on (rdhip borrows torch's current stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = _time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        step(i)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = _time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    value = world * N * args.steps / elapsed
+
+    gather = None
+    if world > 1 and args.gather != "none":
+        reps = 5
+        P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)     # warm (dense (N, n+m, n) slabs)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        g0 = _time.perf_counter()
+        for i in range(reps):
+            step(i)
+            P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=dev)
+        dist.all_reduce(gl, op=dist.ReduceOp.MAX)
+        gather = {"mode": args.gather, "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps,
+                  "bytes_per_rank": N * NX * NZ * 8}
+
+    if rank == 0:
+        achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived HBM bytes per launch, if measured
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "knot-point Jacobians/sec (RK4 discrete_jacobian!, n=13)",
+            "value": value, "unit": "knot-point Jacobians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Satellite RigidBody{QuatRotation} (n=13,m=6) RK4 discrete dynamics + ForwardAD Jacobian (BASELINE configs[2])",
+                       "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
+                       "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "rd::jac_ad_unrolled_kernel<Fun<RigidBody<double,SATELLITE,world>,RK4>>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
+        }
+        if gather:
+            out["gather"] = gather
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(Zn, t, dt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/* rdhip.h -- C ABI of librdhip: batched RobotDynamics.jl dynamics / Jacobian evaluation on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of RobotDynamics.jl v0.4.8.  The reference has no FFI for
+ * this path (it is Julia multiple dispatch, one knot point per call); each entry point below replaces a
+ * per-knot Julia loop `for k in 1:N; f(model, ..., Z[k]); end` by ONE call over a packed trajectory.
+ * All file:line citations are into the reference checkout (RobotDynamics.jl/).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, `int` status return (0 = OK, negative = rdhip_status), no exceptions,
+ *     no callbacks, no ownership transfer.  Pointers are not retained after the call returns.
+ *   - packed trajectory ("PackedTrajectory"): Z is (n+m) x N column-major, knot point k occupies
+ *     Z[k*(n+m) .. k*(n+m)+n+m), z = [x;u] exactly as KnotPoint.z (src/knotpoint.jl:146-153);
+ *     t[N], dt[N] are ALWAYS fp64 (KnotPoint.t/.dt are Float64, src/knotpoint.jl:150-151).
+ *   - terminal knot point: dt[k] == 0  =>  control reads as zeros (src/knotpoint.jl:67,123), and the
+ *     control columns of any Jacobian are zero.
+ *   - Jacobians: J is n x (n+m) x N, each n x (n+m) slab column-major = the storage of
+ *     DynamicsJacobian (src/jacobian.jl:26-37): A = J[:, 0:n], B = J[:, n:n+m].
+ *   - dtype selects the arithmetic and storage type of Z / outputs (RDHIP_F64 or RDHIP_F32).
+ *   - memspace: RDHIP_DEVICE = all data pointers are device pointers and the call is asynchronous on the
+ *     context's HIP stream; RDHIP_HOST = all data pointers are host pointers, the library stages them
+ *     through a per-context device workspace and the call returns after the results are back on the host.
+ *   - a context owns one HIP stream (or borrows the caller's) and is re-entrant per context: use one context
+ *     per host thread (the reference's model objects carry mutable caches and are likewise not thread-safe,
+ *     src/integration.jl:258-276).
+ *   - there is NO CPU fallback: every compute entry point fails with RDHIP_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef RDHIP_H
+#define RDHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDHIP_VERSION 10000 /* 1.0.0 */
+
+typedef enum {
+    RDHIP_OK = 0,
+    RDHIP_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad enum            (Julia: ArgumentError / AssertionError) */
+    RDHIP_ERR_UNSUPPORTED = -2,   /* model/rotation/rule combination not compiled in  (Julia: NotImplementedError, src/utils.jl:1-8) */
+    RDHIP_ERR_NOT_IMPLEMENTED = -3, /* UserDefined Jacobian missing for this model    (src/functionbase.jl:257) */
+    RDHIP_ERR_HIP = -4,           /* a HIP runtime call failed; see rdhip_last_error   */
+    RDHIP_ERR_NO_DEVICE = -5,     /* no usable GPU                                     */
+    RDHIP_ERR_DIM_MISMATCH = -6   /* leading dimension smaller than the state size etc. */
+} rdhip_status;
+
+/* model registry: user-defined Julia `dynamics` cannot run on the GPU, so the models of the reference's
+ * examples/ and test/ fixtures are compiled in.  params layout is given per kind. */
+typedef enum {
+    RDHIP_MODEL_CARTPOLE = 0,          /* examples/cartpole.jl:5-38      params = {mc, mp, l, g}                              */
+    RDHIP_MODEL_DOUBLE_INTEGRATOR = 1, /* test/double_integrator.jl:97   params = {D}, D in 1..3  (n = 2D, m = D)             */
+    RDHIP_MODEL_LINEAR = 2,            /* xdot = A x + B u (KAT model)   params = {n, m, A[n*n] col-major, B[n*m] col-major};
+                                          (n,m) in {(2,1),(4,2),(6,3)}                                                         */
+    RDHIP_MODEL_SATELLITE = 3,         /* RigidBody{R}: examples/single_satellite.jl:7-27, test/rigidbody_test.jl:23-54
+                                          F = q*u[1:3] (world), tau = u[4:6]   params = {mass, J[9] col-major}                */
+    RDHIP_MODEL_QUADROTOR = 4,         /* RigidBody{R}: test/quadrotor.jl:21-137
+                                          params = {mass, J[9], gravity[3], motor_dist, kf, km}                               */
+    RDHIP_MODEL_SATELLITE_PAIR = 5,    /* LieGroupModel, LieState(R,(0,3,3)): examples/satellite_pair.jl:8-40  params = {J1[9], J2[9]} */
+    RDHIP_MODEL_LIE_SATELLITE = 6      /* LieGroupModel, LieState(R,(3,0)), x = [w; q]: test/liemodel.jl:1-22  params = {Jdiag[3]}     */
+} rdhip_model_kind;
+
+typedef enum { RDHIP_ROT_QUAT = 0, RDHIP_ROT_MRP = 1, RDHIP_ROT_RP = 2 } rdhip_rotation;   /* src/liestate.jl:42-46 */
+typedef enum { RDHIP_FRAME_WORLD = 0, RDHIP_FRAME_BODY = 1 } rdhip_velocity_frame;          /* src/rigidbody.jl:258 */
+/* QuadratureRule (src/integration.jl:69,109,258; RK2 = v0.3 explicit midpoint); RDHIP_CONTINUOUS = no discretisation */
+typedef enum { RDHIP_CONTINUOUS = -1, RDHIP_EULER = 0, RDHIP_RK2 = 1, RDHIP_RK3 = 2, RDHIP_RK4 = 3 } rdhip_rule;
+typedef enum { RDHIP_FORWARD_AD = 0, RDHIP_FINITE_DIFF = 1, RDHIP_USER_DEFINED = 2 } rdhip_diffmethod; /* src/functionbase.jl:109-120 */
+typedef enum { RDHIP_F64 = 0, RDHIP_F32 = 1 } rdhip_dtype;
+typedef enum { RDHIP_DEVICE = 0, RDHIP_HOST = 1 } rdhip_memspace;
+typedef enum { RDHIP_STREAM_OWN = 0, RDHIP_STREAM_BORROW = 1 } rdhip_stream_mode;
+
+typedef struct rdhip_ctx rdhip_ctx;
+typedef struct rdhip_model rdhip_model;
+
+/* ---------------------------------------------------------------- library / context ------------------ */
+int rdhip_version(void);
+int rdhip_device_count(int* count);
+/* stream_mode RDHIP_STREAM_OWN: the context creates (and owns) a non-blocking HIP stream, `stream` is ignored;
+ * RDHIP_STREAM_BORROW: `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream;
+ * NULL = the device's default stream) and all launches go to it. */
+int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** out);
+int rdhip_ctx_destroy(rdhip_ctx* ctx);
+int rdhip_ctx_synchronize(rdhip_ctx* ctx);
+void* rdhip_ctx_stream(rdhip_ctx* ctx);
+/* message of the last failure on this context (ctx == NULL: last failure of a context-less call on this thread) */
+const char* rdhip_last_error(rdhip_ctx* ctx);
+/* HIP-event stopwatch on the context's stream (for hosts without their own event API) */
+int rdhip_timer_start(rdhip_ctx* ctx);
+int rdhip_timer_stop(rdhip_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+/* device memory helpers for hosts that do not own a device allocator (the Julia wrapper) */
+int rdhip_malloc(rdhip_ctx* ctx, void** ptr, unsigned long long bytes);
+int rdhip_free(rdhip_ctx* ctx, void* ptr);
+int rdhip_memcpy_h2d(rdhip_ctx* ctx, void* dst, const void* src, unsigned long long bytes); /* async on ctx stream */
+int rdhip_memcpy_d2h(rdhip_ctx* ctx, void* dst, const void* src, unsigned long long bytes); /* synchronous */
+
+/* ---------------------------------------------------------------- models and integer queries --------- */
+/* host-only object (no GPU needed) */
+int rdhip_model_create(int kind, int rotation, int velocity_frame, const double* params, int nparams, rdhip_model** out);
+int rdhip_model_destroy(rdhip_model* model);
+/* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
+int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);
+/* statevectortype: 0 = EuclideanState, 1 = RotationState (src/statevectortype.jl:63,73; src/liestate.jl:22) */
+int rdhip_model_statevectortype(const rdhip_model* model, int* is_rotation_state);
+/* LieState(model) = LieState{R,P}: rotation kind and partition P (src/liestate.jl:75-83); nP = 0 for Euclidean models */
+int rdhip_model_liestate(const rdhip_model* model, int* rotation, int* nP, int* P /* capacity >= 8 */);
+/* gen_inds(model::RigidBody): 1-based first index and length of r, q, v, w, u (src/rigidbody.jl:80-94) */
+int rdhip_model_gen_inds(const rdhip_model* model, int first[5], int len[5]);
+/* LieState index algebra for an arbitrary (R, P) (src/liestate.jl:42-46,121-131): length(s), errstate_dim(s),
+ * first(rot_inds(R,P,i)) for i = 1..nP-1 and first(vec_inds(R,P,i)) for i = 1..nP, all 1-based as in Julia */
+int rdhip_liestate_query(int rotation, const int* P, int nP, int* length, int* errstate_dim, int* rot_first, int* vec_first);
+
+/* ---------------------------------------------------------------- batched hot path ------------------- */
+/* dynamics(model, z) for every knot point: src/dynamics.jl:81-83 (RigidBody: src/rigidbody.jl:213-236).
+ * Xdot: n x N. */
+int rdhip_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
+                   const void* Z, const double* t, const double* dt, void* Xdot, int memspace);
+
+/* discrete_dynamics(DiscretizedDynamics{rule}(model), z): src/discrete_dynamics.jl:80-81,
+ * src/discretized_dynamics.jl:203-204, src/integration.jl:73-83 (Euler), :130-135 (RK3), :280-286 (RK4).
+ * v0.3 spelling: discrete_dynamics(rule, model, z).  Xn: n x N. */
+int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
+                            const void* Z, const double* t, const double* dt, void* Xn, int memspace);
+
+/* jacobian!(sig, diff, fun, J, y, z) for every knot point (src/functionbase.jl:242-257), where fun is the
+ * continuous model (rule = RDHIP_CONTINUOUS; generated methods src/jacobian_gen.jl:485-529, :643-685) or
+ * DiscretizedDynamics{rule}(model) (src/discretized_dynamics.jl:169,208-219; chain rule src/integration.jl:85-93,
+ * :149-177,:302-337).  v0.3 spellings: jacobian!(D, model, z) / discrete_jacobian!(rule, D, model, z).
+ * J: n x (n+m) x N, fully overwritten.  Y: n x N or NULL; receives f(z) (what InPlace leaves in `y`). */
+int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
+                   const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);
+
+/* errstate_jacobian!(model, G, x) (v0.3: state_diff_jacobian!(G, model, z)): src/statevectortype.jl:119-122,149-155,
+ * src/liestate.jl:262-298.  X: states, column k at X + k*ldx (ldx >= n; pass Z with ldx = n+m to read states out of
+ * a packed trajectory).  G: n x e x N column-major.  clear != 0: G is fully overwritten (zeros elsewhere);
+ * clear == 0 reproduces the reference exactly for RotationState models: only the identity diagonals and the
+ * rotation blocks are written, every other entry of G is left untouched (src/liestate.jl:293-297).
+ * EuclideanState models always write G = I (the reference clears in that branch). */
+int rdhip_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
+                            const void* X, int ldx, int clear, void* G, int memspace);
+
+/* state_diff(model, x, x0) with the default CayleyMap: src/statevectortype.jl:102-104,145-146, src/liestate.jl:210-260.
+ * dX: e x N. */
+int rdhip_state_diff(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
+                     const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace);
+
+/* nabla-errstate_jacobian!(model, nablaG, x, xbar) (v0.3: nabla^2 differential!): src/statevectortype.jl:137-147,
+ * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian. */
+int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
+                                  const void* X, int ldx, const void* Xbar, int ldxbar, int clear, void* nablaG, int memspace);
+
+/* rollout!(sig, DiscretizedDynamics{rule}(model), Z, x0) for M independent trajectories of K knot points:
+ * src/trajectories.jl:436-441, src/discrete_dynamics.jl:217-235.  Z: (n+m) x K x M (trajectory j at
+ * Z + j*K*(n+m)), states of knots 2..K are overwritten in place, controls are read; t, dt: K x M.
+ * X0: n x M initial states or NULL (keep state(Z[1])).  Sequential in k, parallel over trajectories. */
+int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M,
+                  void* Z, const double* t, const double* dt, const void* X0, int memspace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDHIP_H */

@@ -1,0 +1,404 @@
+// api.hip -- the C ABI (include/rdhip.h): contexts, the model registry, integer queries, argument checking,
+// host<->device staging for RDHIP_HOST calls, and dispatch into the per-family kernel launchers.
+// No compute happens on the CPU here; without a GPU every compute entry point returns RDHIP_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace rd;
+
+struct rdhip_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t ev0, ev1;
+    std::string err;
+    // grow-only device workspace slots for RDHIP_HOST staging
+    void* ws[8];
+    size_t ws_bytes[8];
+};
+struct rdhip_model {
+    ModelDesc d;
+    LieDesc lie;
+};
+
+static thread_local std::string g_err;
+
+static int fail(rdhip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_err = buf;
+    return code;
+}
+#define HIP_TRY(ctx, call)                                                                             \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RDHIP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+static int rot_params(int rot) { return rot == RDHIP_ROT_QUAT ? 4 : 3; }   // src/liestate.jl:42-46
+
+static void build_lie(rdhip_model* M) {
+    LieDesc& L = M->lie; const ModelDesc& d = M->d;
+    std::memset(&L, 0, sizeof L);
+    L.n = d.n; L.e = d.e; L.nrot = d.lie_nP > 0 ? d.lie_nP - 1 : 0;
+    if (d.lie_nP == 0) {
+        for (int i = 0; i < d.n && i < 16; ++i) { L.row_kind[i] = 0; L.row_col[i] = (signed char)i; L.err_src[i] = (signed char)i; }
+        return;
+    }
+    if (d.rot != RDHIP_ROT_QUAT) return;   // kernels refuse non-quaternion rotations; the table is unused
+    int r = 0, c = 0;
+    for (int v = 0; v < d.lie_nP; ++v) {
+        for (int j = 0; j < d.lie_P[v]; ++j) { L.row_kind[r] = 0; L.row_col[r] = (signed char)c; L.err_src[c] = (signed char)r; ++r; ++c; }
+        if (v < d.lie_nP - 1) {
+            L.rot_row0[v] = (signed char)r; L.rot_col0[v] = (signed char)c;
+            for (int i = 0; i < 4; ++i) { L.row_kind[r + i] = 1; L.row_col[r + i] = (signed char)c; L.row_sub[r + i] = (signed char)i; L.row_q0[r + i] = (signed char)r; }
+            for (int j = 0; j < 3; ++j) L.err_src[c + j] = (signed char)(-1 - v);
+            r += 4; c += 3;
+        }
+    }
+}
+
+extern "C" {
+
+int rdhip_version(void) { return RDHIP_VERSION; }
+
+int rdhip_device_count(int* count) {
+    if (!count) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "count is NULL");
+    int n = 0; hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return fail(nullptr, RDHIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n; return RDHIP_OK;
+}
+
+int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** out) {
+    if (!out) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (stream_mode != RDHIP_STREAM_OWN && stream_mode != RDHIP_STREAM_BORROW) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad stream_mode %d", stream_mode);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return fail(nullptr, RDHIP_ERR_NO_DEVICE, "no HIP device available (librdhip has no CPU fallback)"); }
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    rdhip_ctx* c = new (std::nothrow) rdhip_ctx();
+    if (!c) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
+    c->device = device_id; c->own_stream = (stream_mode == RDHIP_STREAM_OWN);
+    for (int i = 0; i < 8; ++i) { c->ws[i] = nullptr; c->ws_bytes[i] = 0; }
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) { if (c->own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); else c->stream = (hipStream_t)stream; }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
+    *out = c; return RDHIP_OK;
+}
+int rdhip_ctx_destroy(rdhip_ctx* c) {
+    if (!c) return RDHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c; return RDHIP_OK;
+}
+int rdhip_ctx_synchronize(rdhip_ctx* c) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
+}
+void* rdhip_ctx_stream(rdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+const char* rdhip_last_error(rdhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int rdhip_timer_start(rdhip_ctx* c) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream)); return RDHIP_OK;
+}
+int rdhip_timer_stop(rdhip_ctx* c, float* ms) {
+    if (!c || !ms) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1)); return RDHIP_OK;
+}
+int rdhip_malloc(rdhip_ctx* c, void** p, unsigned long long bytes) {
+    if (!c || !p) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return RDHIP_OK;
+}
+int rdhip_free(rdhip_ctx* c, void* p) {
+    if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipFree(p)); return RDHIP_OK;
+}
+int rdhip_memcpy_h2d(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
+    if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
+}
+int rdhip_memcpy_d2h(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
+    if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// models
+// ---------------------------------------------------------------------------------------------------------
+int rdhip_model_create(int kind, int rot, int frame, const double* params, int nparams, rdhip_model** out) {
+    if (!out) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (nparams < 0 || nparams > 64 || (nparams > 0 && !params)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad params (nparams=%d)", nparams);
+    if (rot < RDHIP_ROT_QUAT || rot > RDHIP_ROT_RP) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad rotation %d", rot);
+    if (frame != RDHIP_FRAME_WORLD && frame != RDHIP_FRAME_BODY) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad velocity frame %d", frame);
+    rdhip_model* M = new (std::nothrow) rdhip_model();
+    if (!M) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
+    ModelDesc& d = M->d; std::memset(&d, 0, sizeof d);
+    d.kind = kind; d.rot = rot; d.frame = frame; d.nparams = nparams;
+    for (int i = 0; i < nparams; ++i) d.params[i] = params[i];
+    const int rp = rot_params(rot);
+    int need = 0;
+    switch (kind) {
+        case RDHIP_MODEL_CARTPOLE: d.n = 4; d.m = 1; need = 4; break;
+        case RDHIP_MODEL_DOUBLE_INTEGRATOR: need = 1; if (nparams >= 1) { d.m = (int)params[0]; d.n = 2 * d.m; } break;
+        case RDHIP_MODEL_LINEAR: need = 2; if (nparams >= 2) { d.n = (int)params[0]; d.m = (int)params[1]; need = 2 + d.n * d.n + d.n * d.m; } break;
+        case RDHIP_MODEL_SATELLITE: d.n = 9 + rp; d.m = 6; need = 10; d.lie_nP = 2; d.lie_P[0] = 3; d.lie_P[1] = 6; break;       // src/rigidbody.jl:48
+        case RDHIP_MODEL_QUADROTOR: d.n = 9 + rp; d.m = 4; need = 16; d.lie_nP = 2; d.lie_P[0] = 3; d.lie_P[1] = 6; break;
+        case RDHIP_MODEL_SATELLITE_PAIR: d.n = 2 * rp + 6; d.m = 6; need = 18; d.lie_nP = 3; d.lie_P[0] = 0; d.lie_P[1] = 3; d.lie_P[2] = 3; break;
+        case RDHIP_MODEL_LIE_SATELLITE: d.n = 3 + rp; d.m = 3; need = 3; d.lie_nP = 2; d.lie_P[0] = 3; d.lie_P[1] = 0; break;
+        default: delete M; return fail(nullptr, RDHIP_ERR_INVALID_ARG, "unknown model kind %d", kind);
+    }
+    if (nparams != need) { delete M; return fail(nullptr, RDHIP_ERR_INVALID_ARG, "model kind %d expects %d params, got %d", kind, need, nparams); }
+    if (d.n <= 0 || d.m <= 0 || d.n > 16 || d.m > 8) { delete M; return fail(nullptr, RDHIP_ERR_INVALID_ARG, "unsupported dimensions n=%d m=%d", d.n, d.m); }
+    // errstate_dim: 3 per rotation + vector parts (src/liestate.jl:124) ; Euclidean: n (src/statevectortype.jl:144)
+    if (d.lie_nP) { int sp = 0; for (int i = 0; i < d.lie_nP; ++i) sp += d.lie_P[i]; d.e = 3 * (d.lie_nP - 1) + sp; } else d.e = d.n;
+    build_lie(M);
+    *out = M; return RDHIP_OK;
+}
+int rdhip_model_destroy(rdhip_model* M) { delete M; return RDHIP_OK; }
+int rdhip_model_dims(const rdhip_model* M, int* n, int* m, int* p, int* e) {
+    if (!M) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "model is NULL");
+    if (n) *n = M->d.n; if (m) *m = M->d.m; if (p) *p = M->d.n; if (e) *e = M->d.e; return RDHIP_OK;
+}
+int rdhip_model_statevectortype(const rdhip_model* M, int* is_rot) {
+    if (!M || !is_rot) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *is_rot = M->d.lie_nP > 0; return RDHIP_OK;
+}
+int rdhip_model_liestate(const rdhip_model* M, int* rot, int* nP, int* P) {
+    if (!M || !rot || !nP || !P) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *rot = M->d.rot; *nP = M->d.lie_nP; for (int i = 0; i < M->d.lie_nP; ++i) P[i] = M->d.lie_P[i]; return RDHIP_OK;
+}
+int rdhip_model_gen_inds(const rdhip_model* M, int first[5], int len[5]) {
+    if (!M || !first || !len) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    if (M->d.kind != RDHIP_MODEL_SATELLITE && M->d.kind != RDHIP_MODEL_QUADROTOR) return fail(nullptr, RDHIP_ERR_UNSUPPORTED, "gen_inds is defined for RigidBody models only");
+    const int rp = rot_params(M->d.rot);
+    first[0] = 1; len[0] = 3; first[1] = 4; len[1] = rp; first[2] = 4 + rp; len[2] = 3; first[3] = 7 + rp; len[3] = 3; first[4] = 10 + rp; len[4] = M->d.m;
+    return RDHIP_OK;
+}
+int rdhip_liestate_query(int rot, const int* P, int nP, int* length, int* edim, int* rot_first, int* vec_first) {
+    if (!P || nP < 1 || nP > 8 || !length || !edim || !rot_first || !vec_first) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad LieState query");
+    if (rot < RDHIP_ROT_QUAT || rot > RDHIP_ROT_RP) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad rotation %d", rot);
+    const int rp = rot_params(rot); int sp = 0;
+    for (int i = 0; i < nP; ++i) { if (P[i] < 0) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "negative partition"); sp += P[i]; }
+    *length = rp * (nP - 1) + sp; *edim = 3 * (nP - 1) + sp;
+    int acc = 0;
+    for (int i = 1; i <= nP; ++i) {   // 1-based like Julia
+        vec_first[i - 1] = acc + (i - 1) * rp + 1;            // vec_inds(R,P,i)
+        acc += P[i - 1];
+        if (i <= nP - 1) rot_first[i - 1] = acc + (i - 1) * rp + 1;   // rot_inds(R,P,i)
+    }
+    return RDHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// staging helper for RDHIP_HOST calls
+// ---------------------------------------------------------------------------------------------------------
+struct Stage {
+    rdhip_ctx* c; int slot = 0; int rc = RDHIP_OK;
+    struct Out { void* host; void* dev; size_t bytes; };
+    std::vector<Out> outs;
+    explicit Stage(rdhip_ctx* ctx) : c(ctx) {}
+    void* reserve(size_t bytes) {
+        if (rc) return nullptr;
+        if (slot >= 8) { rc = fail(c, RDHIP_ERR_HIP, "staging slots exhausted"); return nullptr; }
+        if (c->ws_bytes[slot] < bytes) {
+            if (c->ws[slot]) (void)hipFree(c->ws[slot]);
+            c->ws[slot] = nullptr; c->ws_bytes[slot] = 0;
+            hipError_t e = hipMalloc(&c->ws[slot], bytes ? bytes : 1);
+            if (e != hipSuccess) { rc = fail(c, RDHIP_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+            c->ws_bytes[slot] = bytes;
+        }
+        return c->ws[slot++];
+    }
+    const void* in(const void* host, size_t bytes) {
+        if (!host) return nullptr;
+        void* d = reserve(bytes); if (!d) return nullptr;
+        hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(c, RDHIP_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e));
+        return d;
+    }
+    void* out(void* host, size_t bytes, bool preload = false) {
+        if (!host) return nullptr;
+        void* d = reserve(bytes); if (!d) return nullptr;
+        if (preload) { hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream); if (e != hipSuccess) rc = fail(c, RDHIP_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
+        outs.push_back({host, d, bytes}); return d;
+    }
+    int finish(int krc) {
+        if (rc) return rc;
+        if (krc) return krc;
+        for (auto& o : outs) { hipError_t e = hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream); if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "D2H copy failed: %s", hipGetErrorString(e)); }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "stream sync failed: %s", hipGetErrorString(e));
+        return RDHIP_OK;
+    }
+};
+
+static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, int memspace) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (!M) return fail(c, RDHIP_ERR_INVALID_ARG, "model is NULL");
+    if (dtype != RDHIP_F64 && dtype != RDHIP_F32) return fail(c, RDHIP_ERR_INVALID_ARG, "bad dtype %d", dtype);
+    if (N < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "negative N");
+    if (memspace != RDHIP_DEVICE && memspace != RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "bad memspace %d", memspace);
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    return RDHIP_OK;
+}
+static int check_rotation(rdhip_ctx* c, const rdhip_model* M) {
+    if (M->d.lie_nP > 0 && M->d.rot != RDHIP_ROT_QUAT)
+        return fail(c, RDHIP_ERR_UNSUPPORTED, "only QuatRotation models have kernels (MRP / RodriguesParam: index queries only)");
+    return RDHIP_OK;
+}
+static int kernel_status(rdhip_ctx* c, int rc, const char* what) {
+    if (rc == RDHIP_OK) return rc;
+    if (rc == RDHIP_ERR_HIP) return fail(c, rc, "%s: kernel launch failed: %s", what, hipGetErrorString(hipGetLastError()));
+    if (rc == RDHIP_ERR_NOT_IMPLEMENTED) return fail(c, rc, "%s: User-defined Jacobian not implemented for this model", what);
+    if (rc == RDHIP_ERR_UNSUPPORTED) return fail(c, rc, "%s: model dimensions / kind not compiled in", what);
+    return fail(c, rc, "%s: invalid rule / diff / dtype", what);
+}
+
+static int family_eval(const ModelDesc& d, int rule, int dtype, const LaunchArgs& a) {
+    switch (d.kind) {
+        case RDHIP_MODEL_CARTPOLE: return fam_cartpole_eval(d, rule, dtype, a);
+        case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_eval(d, rule, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return fam_satellite_eval(d, rule, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_eval(d, rule, dtype, a);
+        default: return fam_lie_eval(d, rule, dtype, a);
+    }
+}
+static int family_jacobian(const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& a) {
+    switch (d.kind) {
+        case RDHIP_MODEL_CARTPOLE: return fam_cartpole_jacobian(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_jacobian(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return fam_satellite_jacobian(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_jacobian(d, rule, diff, dtype, a);
+        default: return fam_lie_jacobian(d, rule, diff, dtype, a);
+    }
+}
+static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchArgs& a) {
+    switch (d.kind) {
+        case RDHIP_MODEL_CARTPOLE: return fam_cartpole_rollout(d, rule, dtype, a);
+        case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_rollout(d, rule, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return fam_satellite_rollout(d, rule, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_rollout(d, rule, dtype, a);
+        default: return fam_lie_rollout(d, rule, dtype, a);
+    }
+}
+
+static int eval_common(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt,
+                       void* Y, int memspace, const char* what) {
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (N > 0 && (!Z || !t || !dt || !Y)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    LaunchArgs a{}; a.stream = c->stream; a.N = N;
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.Y = Y; return kernel_status(c, family_eval(d, rule, dtype, a), what); }
+    Stage s(c);
+    a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
+    a.Y = s.out(Y, (size_t)N * d.n * ts);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, family_eval(d, rule, dtype, a), what));
+}
+
+int rdhip_dynamics(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, const double* t, const double* dt, void* Xdot, int memspace) {
+    return eval_common(c, M, RDHIP_CONTINUOUS, dtype, N, Z, t, dt, Xdot, memspace, "rdhip_dynamics");
+}
+int rdhip_discrete_dynamics(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt, void* Xn, int memspace) {
+    if (rule == RDHIP_CONTINUOUS) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_discrete_dynamics: a quadrature rule is required");
+    return eval_common(c, M, rule, dtype, N, Z, t, dt, Xn, memspace, "rdhip_discrete_dynamics");
+}
+
+int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
+                   void* J, void* Y, int memspace) {
+    const char* what = "rdhip_jacobian";
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
+    if (N > 0 && (!Z || !t || !dt || !J)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    LaunchArgs a{}; a.stream = c->stream; a.N = N;
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.J = J; a.Y = Y; return kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what); }
+    Stage s(c);
+    a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
+    a.J = s.out(J, (size_t)N * d.n * (d.n + d.m) * ts); a.Y = s.out(Y, (size_t)N * d.n * ts);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what));
+}
+
+int rdhip_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, int clear, void* G, int memspace) {
+    const char* what = "rdhip_errstate_jacobian";
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (N > 0 && (!X || !G)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    if (ldx < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: ldx=%d < state_dim=%d", what, ldx, M->d.n);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_errstate_jacobian(M->lie, dtype, c->stream, N, X, ldx, clear, G), what);
+    Stage s(c);
+    const void* dX = s.in(X, (size_t)N * ldx * ts);
+    void* dG = s.out(G, (size_t)N * d.n * d.e * ts, /*preload=*/!clear);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, launch_errstate_jacobian(M->lie, dtype, c->stream, N, dX, ldx, clear, dG), what));
+}
+
+int rdhip_state_diff(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace) {
+    const char* what = "rdhip_state_diff";
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (N > 0 && (!X || !X0 || !dX)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    if (ldx < M->d.n || ldx0 < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, X, ldx, X0, ldx0, dX), what);
+    Stage s(c);
+    const void* a = s.in(X, (size_t)N * ldx * ts); const void* b = s.in(X0, (size_t)N * ldx0 * ts);
+    void* o = s.out(dX, (size_t)N * d.e * ts);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, a, ldx, b, ldx0, o), what));
+}
+
+int rdhip_nabla_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* Xb, int ldxb,
+                                  int clear, void* H, int memspace) {
+    const char* what = "rdhip_nabla_errstate_jacobian";
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (N > 0 && (!X || !Xb || !H)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    if (ldx < M->d.n || ldxb < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_nabla_errstate(M->lie, dtype, c->stream, N, X, ldx, Xb, ldxb, clear, H), what);
+    Stage s(c);
+    const void* a = s.in(X, (size_t)N * ldx * ts); const void* b = s.in(Xb, (size_t)N * ldxb * ts);
+    void* o = s.out(H, (size_t)N * d.e * d.e * ts, /*preload=*/!clear);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, launch_nabla_errstate(M->lie, dtype, c->stream, N, a, ldx, b, ldxb, clear, o), what));
+}
+
+int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, void* Z, const double* t, const double* dt,
+                  const void* X0, int memspace) {
+    const char* what = "rdhip_rollout";
+    int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
+    if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
+    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (K * Mt > 0 && (!Z || !t || !dt)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K;
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, family_rollout(d, rule, dtype, a), what); }
+    Stage s(c);
+    a.Z = s.out(Z, (size_t)K * Mt * (d.n + d.m) * ts, /*preload=*/true);
+    a.t = (const double*)s.in(t, (size_t)K * Mt * 8); a.dt = (const double*)s.in(dt, (size_t)K * Mt * 8);
+    a.X0 = s.in(X0, (size_t)Mt * d.n * ts);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, family_rollout(d, rule, dtype, a), what));
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// common.hpp -- host-side descriptors shared by the C-ABI layer (api.hip) and the per-family kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/rdhip.h"
+
+namespace rd {
+
+struct ModelDesc {
+    int kind, rot, frame;
+    int n, m, e;
+    int nparams;
+    double params[64];
+    int lie_nP;        // 0 => EuclideanState
+    int lie_P[8];
+};
+
+struct LaunchArgs {
+    hipStream_t stream;
+    long long N;        // knot points (rollout: trajectories M)
+    long long K;        // rollout: knots per trajectory
+    const void* Z;
+    const double* t;
+    const double* dt;
+    void* J;
+    void* Y;            // eval: output; jacobian: optional f(z)
+    const void* X0;     // rollout
+};
+
+// per-family entry points (one translation unit each so they compile in parallel)
+#define RD_DECLARE_FAMILY(name)                                                                      \
+    int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                  \
+    int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);    \
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+RD_DECLARE_FAMILY(fam_cartpole)
+RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
+RD_DECLARE_FAMILY(fam_satellite)
+RD_DECLARE_FAMILY(fam_quadrotor)
+RD_DECLARE_FAMILY(fam_lie)         // satellite pair, lie satellite
+
+// error-state kernels (errstate.hip)
+struct LieDesc {
+    int n, e, nrot;
+    signed char row_kind[16];   // 0: vector row, 1: quaternion row
+    signed char row_col[16];    // vector row: its column in G ; quaternion row: first column of the 3-wide block
+    signed char row_sub[16];    // quaternion row: component index 0..3
+    signed char row_q0[16];     // quaternion row: state index of the quaternion's scalar part
+    signed char rot_row0[4];    // state index of rotation k's scalar part
+    signed char rot_col0[4];    // error-state index of rotation k's first component
+    signed char err_src[16];    // state_diff: error index -> state index for vector parts, -1-k for rotation k parts
+};
+int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G);
+int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX);
+int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H);
+
+}  // namespace rd

@@ -1,0 +1,278 @@
+// models.hpp -- the compiled-in model registry: continuous dynamics xdot = f(x,u) written ONCE as templates
+// on the scalar type S (T or Dual<T,K>), plus the explicit Runge-Kutta rules.
+// Reference formulas (file:line in RobotDynamics.jl):
+//   Cartpole            examples/cartpole.jl:15-34 (== test/cartpole_model.jl:11-30)
+//   DoubleIntegrator    test/double_integrator.jl:97-107
+//   RigidBody           src/rigidbody.jl:213-236 ; quaternion is NEVER renormalised (src/rigidbody.jl:101-105)
+//   Satellite wrench    examples/single_satellite.jl:18-27 ; Quadrotor wrench test/quadrotor.jl:56-96
+//   SatellitePair       examples/satellite_pair.jl:14-38 ; LieSatellite test/liemodel.jl:14-22
+//   Euler/RK3/RK4       src/integration.jl:73-83, :130-135, :280-286 ; RK2 = v0.3 explicit midpoint
+// Rotations.jl arithmetic is restated in closed (formula) form, SURVEY.md App. A.
+// Deviations from the reference's literal operation order (all << the 1e-10 parity tolerance, stated in DESIGN.md):
+//   F ./ m  and  J \ v  are evaluated as multiplications by host-precomputed reciprocals / inverses;
+//   hipcc contracts a*b+c into FMA.
+#pragma once
+#include "scalar.hpp"
+
+namespace rd {
+
+enum { RULE_CONTINUOUS = -1, RULE_EULER = 0, RULE_RK2 = 1, RULE_RK3 = 2, RULE_RK4 = 3 };
+
+// ---- small vector helpers -------------------------------------------------------------------------------
+template <class S> RD_DEV void cross3(const S* a, const S* b, S* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+// y = A x, A 3x3 column-major plain-T matrix
+template <class T, class S> RD_DEV void mat3vec(const T* A, const S* x, S* y) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[i] = x[0] * A[i] + x[1] * A[i + 3] + x[2] * A[i + 6];
+}
+// q * r for a possibly non-unit quaternion q = [w, v]: (w^2 - v.v) r + 2 v (v.r) + 2 w (v x r)
+template <class S> RD_DEV void quat_rotate(const S* q, const S* r, S* o) {
+    using T = typename scalar_of<S>::type;
+    const S vv = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const S vr = q[1] * r[0] + q[2] * r[1] + q[3] * r[2];
+    const S a = q[0] * q[0] - vv;
+    S c[3]; cross3(q + 1, r, c);
+    const S vr2 = vr * T(2), w2 = q[0] * T(2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a * r[i] + q[1 + i] * vr2 + w2 * c[i];
+}
+// q \ r = conj(q) * r
+template <class S> RD_DEV void quat_rotate_inv(const S* q, const S* r, S* o) {
+    const S qc[4] = {q[0], -q[1], -q[2], -q[3]};
+    quat_rotate(qc, r, o);
+}
+// Rotations.kinematics(q, w) = 1/2 q (x) [0; w]
+template <class S> RD_DEV void quat_kinematics(const S* q, const S* w, S* qd) {
+    using T = typename scalar_of<S>::type;
+    const T half = T(0.5);
+    qd[0] = (-(q[1] * w[0]) - q[2] * w[1] - q[3] * w[2]) * half;
+    qd[1] = (q[0] * w[0] + q[2] * w[2] - q[3] * w[1]) * half;
+    qd[2] = (q[0] * w[1] + q[3] * w[0] - q[1] * w[2]) * half;
+    qd[3] = (q[0] * w[2] + q[1] * w[1] - q[2] * w[0]) * half;
+}
+
+inline void host_inv3(const double* A, double* Ai) {
+    const bool diag = A[1] == 0 && A[2] == 0 && A[3] == 0 && A[5] == 0 && A[6] == 0 && A[7] == 0;
+    if (diag) {   // inv(Diagonal) = Diagonal(1 ./ d)
+        for (int i = 0; i < 9; ++i) Ai[i] = 0;
+        Ai[0] = 1.0 / A[0]; Ai[4] = 1.0 / A[4]; Ai[8] = 1.0 / A[8];
+        return;
+    }
+    const double a = A[0], b = A[3], c = A[6], d = A[1], e = A[4], f = A[7], g = A[2], h = A[5], i = A[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    Ai[0] = (e * i - f * h) / det; Ai[3] = (c * h - b * i) / det; Ai[6] = (b * f - c * e) / det;
+    Ai[1] = (f * g - d * i) / det; Ai[4] = (a * i - c * g) / det; Ai[7] = (c * d - a * f) / det;
+    Ai[2] = (d * h - e * g) / det; Ai[5] = (b * g - a * h) / det; Ai[8] = (a * e - b * d) / det;
+}
+
+// ---- models ---------------------------------------------------------------------------------------------
+template <class T_> struct Cartpole {
+    using T = T_;
+    static constexpr int NX = 4, NU = 1;
+    T mc, mp, l, g;
+    static Cartpole make(const double* p) { return Cartpole{T(p[0]), T(p[1]), T(p[2]), T(p[3])}; }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+        const S s = sin_(x[1]), c = cos_(x[1]);
+        const T H11 = mc + mp, H22 = mp * l * l;
+        const S H12 = c * (mp * l);
+        const S r0 = (x[3] * x[3]) * s * (-(mp * l)) - u[0];   // C*qd + G - B*u, row 1
+        const S r1 = s * (mp * g * l);                           // row 2
+        const S det = H12 * H12 * T(-1) + H11 * H22;
+        const S y0 = (r0 * H22 - H12 * r1) / det;
+        const S y1 = (r1 * H11 - H12 * r0) / det;
+        xd[0] = x[2]; xd[1] = x[3]; xd[2] = -y0; xd[3] = -y1;
+    }
+};
+
+template <class T_, int D> struct DoubleIntegrator {
+    using T = T_;
+    static constexpr int NX = 2 * D, NU = D;
+    static DoubleIntegrator make(const double*) { return DoubleIntegrator{}; }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+#pragma unroll
+        for (int i = 0; i < D; ++i) { xd[i] = x[D + i]; xd[D + i] = u[i]; }
+    }
+};
+
+template <class T_, int N_, int M_> struct Linear {
+    using T = T_;
+    static constexpr int NX = N_, NU = M_;
+    T A[N_ * N_], B[N_ * M_];
+    static Linear make(const double* p) {
+        Linear L;
+        for (int i = 0; i < N_ * N_; ++i) L.A[i] = T(p[2 + i]);
+        for (int i = 0; i < N_ * M_; ++i) L.B[i] = T(p[2 + N_ * N_ + i]);
+        return L;
+    }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+#pragma unroll
+        for (int i = 0; i < N_; ++i) {
+            S acc = x[0] * A[i];
+#pragma unroll
+            for (int j = 1; j < N_; ++j) acc = acc + x[j] * A[i + j * N_];
+#pragma unroll
+            for (int j = 0; j < M_; ++j) acc = acc + u[j] * B[i + j * N_];
+            xd[i] = acc;
+        }
+    }
+};
+
+enum { WRENCH_SATELLITE = 0, WRENCH_QUADROTOR = 1 };
+
+// RigidBody{QuatRotation}: x = [r(3) q(4) v(3) w(3)], forces in the world frame, moments in the body frame
+template <class T_, int WRENCH, bool BODY> struct RigidBody {
+    using T = T_;
+    static constexpr int NX = 13, NU = (WRENCH == WRENCH_SATELLITE) ? 6 : 4;
+    T mass, inv_mass;
+    T J[9], Jinv[9];
+    T grav[3];          // mass * gravity (quadrotor)
+    T L, kf, km;        // quadrotor
+    static RigidBody make(const double* p) {
+        RigidBody M; M.mass = T(p[0]); M.inv_mass = T(1.0 / p[0]);
+        double Ji[9]; host_inv3(p + 1, Ji);
+        for (int i = 0; i < 9; ++i) { M.J[i] = T(p[1 + i]); M.Jinv[i] = T(Ji[i]); }
+        if (WRENCH == WRENCH_QUADROTOR) {
+            for (int i = 0; i < 3; ++i) M.grav[i] = T(p[0] * p[10 + i]);
+            M.L = T(p[13]); M.kf = T(p[14]); M.km = T(p[15]);
+        } else { M.grav[0] = M.grav[1] = M.grav[2] = T(0); M.L = M.kf = M.km = T(0); }
+        return M;
+    }
+    template <class S> RD_DEV void wrench(const S* q, const S* u, S* F, S* tau) const {
+        if constexpr (WRENCH == WRENCH_SATELLITE) {
+            quat_rotate(q, u, F);
+            tau[0] = u[3]; tau[1] = u[4]; tau[2] = u[5];
+        } else {
+            const S F1 = max0_(u[0] * kf), F2 = max0_(u[1] * kf), F3 = max0_(u[2] * kf), F4 = max0_(u[3] * kf);
+            const S fb[3] = {S(T(0)), S(T(0)), F1 + F2 + F3 + F4};
+            S qF[3]; quat_rotate(q, fb, qF);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) F[i] = qF[i] + grav[i];
+            tau[0] = (F2 - F4) * L; tau[1] = (F3 - F1) * L;
+            tau[2] = (u[0] - u[1] + u[2] - u[3]) * km;
+        }
+    }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+        const S* q = x + 3; const S* v = x + 7; const S* w = x + 10;
+        S F[3], tau[3]; wrench(q, u, F, tau);
+        quat_kinematics(q, w, xd + 3);
+        if constexpr (!BODY) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xd[i] = v[i]; xd[7 + i] = F[i] * inv_mass; }
+        } else {
+            quat_rotate(q, v, xd);
+            S Fm[3] = {F[0] * inv_mass, F[1] * inv_mass, F[2] * inv_mass};
+            S a[3]; quat_rotate_inv(q, Fm, a);
+            S c[3]; cross3(w, v, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xd[7 + i] = a[i] - c[i];
+        }
+        S Jw[3]; mat3vec(J, w, Jw);
+        S c[3]; cross3(w, Jw, c);
+        S tt[3] = {tau[0] - c[0], tau[1] - c[1], tau[2] - c[2]};
+        mat3vec(Jinv, tt, xd + 10);
+    }
+};
+
+// SatellitePair: x = [q1(4) w1(3) q2(4) w2(3)], u = [u1(3) u2(3)]
+template <class T_> struct SatellitePair {
+    using T = T_;
+    static constexpr int NX = 14, NU = 6;
+    T J[2][9], Jinv[2][9];
+    static SatellitePair make(const double* p) {
+        SatellitePair M;
+        for (int b = 0; b < 2; ++b) {
+            double Ji[9]; host_inv3(p + 9 * b, Ji);
+            for (int i = 0; i < 9; ++i) { M.J[b][i] = T(p[9 * b + i]); M.Jinv[b][i] = T(Ji[i]); }
+        }
+        return M;
+    }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const S* q = x + 7 * b; const S* w = x + 7 * b + 4; const S* ub = u + 3 * b;
+            S Jw[3]; mat3vec(J[b], w, Jw);
+            S c[3]; cross3(w, Jw, c);
+            S tt[3] = {ub[0] - c[0], ub[1] - c[1], ub[2] - c[2]};
+            mat3vec(Jinv[b], tt, xd + 7 * b + 4);
+            quat_kinematics(q, w, xd + 7 * b);
+        }
+    }
+};
+
+// LieSatellite (test/liemodel.jl): x = [w(3) q(4)], q normalised inside the dynamics, J diagonal
+template <class T_> struct LieSatellite {
+    using T = T_;
+    static constexpr int NX = 7, NU = 3;
+    T Jd[3], Jdinv[3];
+    static LieSatellite make(const double* p) {
+        LieSatellite M;
+        for (int i = 0; i < 3; ++i) { M.Jd[i] = T(p[i]); M.Jdinv[i] = T(1.0 / p[i]); }
+        return M;
+    }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+        const S* w = x;
+        const S nn = sqrt_(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+        const S q[4] = {x[3] / nn, x[4] / nn, x[5] / nn, x[6] / nn};
+        const S Jw[3] = {w[0] * Jd[0], w[1] * Jd[1], w[2] * Jd[2]};
+        S c[3]; cross3(w, Jw, c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xd[i] = (u[i] - c[i]) * Jdinv[i];
+        quat_kinematics(q, w, xd + 3);
+    }
+};
+
+// ---- DiscretizedDynamics{RULE}(model): `evaluate(fun, z)` -------------------------------------------------
+// RULE_CONTINUOUS evaluates the continuous model.  The explicit rules follow the StaticReturn `integrate`
+// methods (k_i = f(.) * h ; x + k1/2 ...), src/integration.jl:130-135 and :280-286.
+template <class Mdl, int RULE> struct Fun {
+    using T = typename Mdl::T;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX;
+    Mdl m;
+    template <class S> RD_DEV void eval(const S* x, const S* u, T /*t*/, T h, S* y) const {
+        if constexpr (RULE == RULE_CONTINUOUS) {
+            m.f(x, u, y);
+        } else if constexpr (RULE == RULE_EULER) {
+            S k1[NX]; m.f(x, u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + k1[i] * h;
+        } else if constexpr (RULE == RULE_RK2) {
+            S k[NX], xs[NX]; m.f(x, u, k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = x[i] + k[i] * (h * T(0.5));
+            m.f(xs, u, k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + k[i] * h;
+        } else if constexpr (RULE == RULE_RK3) {
+            S k1[NX], k2[NX], k3[NX], xs[NX];
+            m.f(x, u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x[i] + k1[i] * T(0.5); }
+            m.f(xs, u, k2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; xs[i] = x[i] - k1[i] + k2[i] * T(2); }
+            m.f(xs, u, k3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + (k1[i] + k2[i] * T(4) + k3[i] * h) * T(1.0 / 6.0);
+        } else {
+            S k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
+            m.f(x, u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x[i] + k1[i] * T(0.5); }
+            m.f(xs, u, k2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; xs[i] = x[i] + k2[i] * T(0.5); }
+            m.f(xs, u, k3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k3[i] = k3[i] * h; xs[i] = x[i] + k3[i]; }
+            m.f(xs, u, k4);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + (k1[i] + (k2[i] + k3[i]) * T(2) + k4[i] * h) * T(1.0 / 6.0);
+        }
+    }
+};
+
+}  // namespace rd

@@ -1,0 +1,161 @@
+"""ctypes binding of librdhip.so (include/rdhip.h).  No torch types cross this boundary: only raw pointers and sizes.
+
+The library is built in-tree (robotdynamics.jl_amd/lib/librdhip.so) by `make -C robotdynamics.jl_amd/csrc` or
+`__graft_entry__.build()`.  There is no CPU fallback anywhere in this package: if the library is missing, or no GPU
+is present, the compute entry points raise.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "librdhip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "rdhip.h")
+
+# rdhip_status
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_NO_DEVICE, ERR_DIM_MISMATCH = 0, -1, -2, -3, -4, -5, -6
+# rdhip_model_kind
+MODEL_CARTPOLE, MODEL_DOUBLE_INTEGRATOR, MODEL_LINEAR, MODEL_SATELLITE, MODEL_QUADROTOR, MODEL_SATELLITE_PAIR, MODEL_LIE_SATELLITE = range(7)
+ROT_QUAT, ROT_MRP, ROT_RP = range(3)
+FRAME_WORLD, FRAME_BODY = range(2)
+CONTINUOUS, EULER, RK2, RK3, RK4 = -1, 0, 1, 2, 3
+FORWARD_AD, FINITE_DIFF, USER_DEFINED = range(3)
+F64, F32 = range(2)
+DEVICE, HOST = range(2)
+STREAM_OWN, STREAM_BORROW = range(2)
+
+
+class RdhipError(RuntimeError):
+    """A librdhip call failed (HIP error, missing library, no GPU)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"librdhip status {code}: {msg}")
+        self.code = code
+
+
+class NoDeviceError(RdhipError):
+    pass
+
+
+_lib = None
+
+_P = C.c_void_p
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+_LL = C.c_longlong
+_SIGS = {
+    "rdhip_version": (C.c_int, []),
+    "rdhip_device_count": (C.c_int, [_IP]),
+    "rdhip_ctx_create": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "rdhip_ctx_destroy": (C.c_int, [_P]),
+    "rdhip_ctx_synchronize": (C.c_int, [_P]),
+    "rdhip_ctx_stream": (_P, [_P]),
+    "rdhip_last_error": (C.c_char_p, [_P]),
+    "rdhip_timer_start": (C.c_int, [_P]),
+    "rdhip_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "rdhip_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_ulonglong]),
+    "rdhip_free": (C.c_int, [_P, _P]),
+    "rdhip_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_ulonglong]),
+    "rdhip_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_ulonglong]),
+    "rdhip_model_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _DP, C.c_int, C.POINTER(_P)]),
+    "rdhip_model_destroy": (C.c_int, [_P]),
+    "rdhip_model_dims": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
+    "rdhip_model_statevectortype": (C.c_int, [_P, _IP]),
+    "rdhip_model_liestate": (C.c_int, [_P, _IP, _IP, _IP]),
+    "rdhip_model_gen_inds": (C.c_int, [_P, _IP, _IP]),
+    "rdhip_liestate_query": (C.c_int, [C.c_int, _IP, C.c_int, _IP, _IP, _IP, _IP]),
+    "rdhip_dynamics": (C.c_int, [_P, _P, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
+    "rdhip_discrete_dynamics": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
+    "rdhip_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
+    "rdhip_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "rdhip_state_diff": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
+    "rdhip_nabla_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load librdhip.so; raises RdhipError if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RdhipError(ERR_HIP, f"{LIB_PATH} not found: build it with `make -C robotdynamics.jl_amd/csrc` "
+                                      "(or __graft_entry__.build()); this package has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, ctx_handle=None):
+    if rc == OK:
+        return
+    msg = lib().rdhip_last_error(ctx_handle)
+    msg = msg.decode() if msg else ""
+    if rc == ERR_NOT_IMPLEMENTED:
+        raise NotImplementedError(msg)            # Julia: NotImplementedError (src/utils.jl:1-8)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc in (ERR_INVALID_ARG, ERR_DIM_MISMATCH):
+        raise ValueError(msg)                      # Julia: ArgumentError / DimensionMismatch
+    if rc == ERR_NO_DEVICE:
+        raise NoDeviceError(rc, msg)
+    raise RdhipError(rc, msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().rdhip_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+class Context:
+    """One HIP stream on one device (rdhip_ctx).  Not thread-safe; use one per host thread."""
+
+    def __init__(self, device=0, stream=None):
+        """stream=None: the context owns a fresh non-blocking stream; otherwise an integer hipStream_t
+        (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream) that is borrowed."""
+        h = _P()
+        mode = STREAM_OWN if stream is None else STREAM_BORROW
+        check(lib().rdhip_ctx_create(int(device), _P(stream or 0), mode, C.byref(h)))
+        self.handle, self.device = h, int(device)
+
+    def synchronize(self):
+        check(lib().rdhip_ctx_synchronize(self.handle), self.handle)
+
+    @property
+    def stream(self):
+        return lib().rdhip_ctx_stream(self.handle) or 0
+
+    def timer_start(self):
+        check(lib().rdhip_timer_start(self.handle), self.handle)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().rdhip_timer_stop(self.handle, C.byref(ms)), self.handle)
+        return ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rdhip_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context_for(device, stream):
+    """Cached context per (device, borrowed stream); stream=None -> a context with its own stream."""
+    key = (int(device), stream)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(device, stream)
+    return ctx

@@ -1,0 +1,1188 @@
+"""Host-side mirror of RobotDynamics.jl's operator interface for the batched hot path.
+
+Julia is not available in the build image, so the host layer above the C ABI is written in Python; it keeps the
+reference's names, argument order and error behaviour so that callers (and the parity tests) read like the
+reference's own code.  Julia's trailing `!` becomes a trailing underscore (`jacobian!` -> `jacobian_`).
+Every function here ends in ONE call into librdhip (include/rdhip.h) -- there is no Python or CPU compute path.
+
+Array conventions (row k = knot point k, i.e. the C-order view of Julia's column-major arrays):
+    Z.data  (N, n+m)        == Julia (n+m) x N         t, dt  (N,) float64
+    Y / Xn  (N, n)          == Julia n x N
+    J       (N, n, n+m) view whose memory is (N, n+m, n) C-order == Julia n x (n+m) x N   (see `alloc_jacobians`)
+    G       (N, n, e)   view whose memory is (N, e, n)   C-order == Julia n x e x N
+numpy arrays are host memory (the library stages them, call is synchronous); torch CUDA tensors are device
+memory (call is asynchronous on torch's current stream).
+
+Reference citations are file:line in RobotDynamics.jl v0.4.8.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing (device memory + streams), never the compute path
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+# =============================================================================================================
+# traits: FunctionSignature / DiffMethod / QuadratureRule / StateVectorType / FunctionInputs
+# (src/functionbase.jl:78-80, :109-120, :172-206 ; src/statevectortype.jl:63,73 ; src/discretized_dynamics.jl:16-99)
+# =============================================================================================================
+class _Trait:
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self))
+
+    def __repr__(self):
+        return type(self).__name__ + "()"
+
+
+class FunctionSignature(_Trait):
+    pass
+
+
+class InPlace(FunctionSignature):
+    pass
+
+
+class StaticReturn(FunctionSignature):
+    pass
+
+
+class DiffMethod(_Trait):
+    pass
+
+
+class ForwardAD(DiffMethod):
+    code = L.FORWARD_AD
+
+
+class FiniteDifference(DiffMethod):
+    code = L.FINITE_DIFF
+
+
+class UserDefined(DiffMethod):
+    code = L.USER_DEFINED
+
+
+class ImplicitFunctionTheorem(DiffMethod):
+    """Exists for API completeness; implicit integrators are outside the accelerated path."""
+
+    def __init__(self, diff):
+        if isinstance(diff, ImplicitFunctionTheorem):   # src/functionbase.jl:113-116
+            raise ValueError("DiffMethod for ImplicitFunctionTheorem cannot also be ImplicitFunctionTheorem.")
+        self.diff = diff
+
+
+class StateVectorType(_Trait):
+    pass
+
+
+class EuclideanState(StateVectorType):
+    pass
+
+
+class RotationState(StateVectorType):
+    pass
+
+
+class FunctionInputs(_Trait):
+    pass
+
+
+class StateControl(FunctionInputs):
+    pass
+
+
+class StateOnly(FunctionInputs):
+    pass
+
+
+class ControlOnly(FunctionInputs):
+    pass
+
+
+class QuadratureRule:
+    code = None
+
+    def __init__(self, n=None, m=None):   # RK4(n, m) in the reference allocates caches; nothing to allocate here
+        pass
+
+
+class Explicit(QuadratureRule):
+    pass
+
+
+class Euler(Explicit):
+    code = L.EULER
+
+
+class RK2(Explicit):       # v0.3 explicit midpoint
+    code = L.RK2
+
+
+class RK3(Explicit):
+    code = L.RK3
+
+
+class RK4(Explicit):
+    code = L.RK4
+
+
+def _rule_code(Q):
+    if isinstance(Q, type) and issubclass(Q, QuadratureRule) or isinstance(Q, QuadratureRule):
+        if Q.code is None:
+            raise NotImplementedError(f"{Q} has no batched kernel (implicit integrators are out of scope)")
+        return Q.code
+    raise ValueError(f"not a QuadratureRule: {Q!r}")
+
+
+# rotation parameterisations (Rotations.jl types, only as tags)
+class QuatRotation:
+    code, nparams = L.ROT_QUAT, 4
+
+
+UnitQuaternion = QuatRotation   # pre-1.0 Rotations.jl name
+
+
+class MRP:
+    code, nparams = L.ROT_MRP, 3
+
+
+class RodriguesParam:
+    code, nparams = L.ROT_RP, 3
+
+
+def params(R):   # Rotations.params(::Type) as extended at src/liestate.jl:42-46
+    return R.nparams
+
+
+# =============================================================================================================
+# array plumbing
+# =============================================================================================================
+def _is_torch(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+class _Arg:
+    """A caller array resolved to (pointer, memspace, dtype code)."""
+    __slots__ = ("ptr", "space", "dtype", "device", "keep")
+
+    def __init__(self, a, name, want_dtype=None):
+        if a is None:
+            self.ptr, self.space, self.dtype, self.device, self.keep = None, None, None, None, None
+            return
+        if _is_torch(a):
+            # logical views (transposes) are fine as long as the underlying memory is the dense slab
+            if a.dtype not in (torch.float64, torch.float32):
+                raise ValueError(f"{name}: dtype must be float64 or float32")
+            self.ptr = a.data_ptr()
+            self.space = L.DEVICE if a.is_cuda else L.HOST
+            self.dtype = L.F64 if a.dtype == torch.float64 else L.F32
+            self.device = a.device.index if a.is_cuda else None
+        elif isinstance(a, np.ndarray):
+            if a.dtype not in (np.float64, np.float32):
+                raise ValueError(f"{name}: dtype must be float64 or float32")
+            self.ptr = a.ctypes.data
+            self.space, self.device = L.HOST, None
+            self.dtype = L.F64 if a.dtype == np.float64 else L.F32
+        else:
+            raise ValueError(f"{name}: expected a numpy array or torch tensor, got {type(a)}")
+        self.keep = a
+        if want_dtype is not None and self.dtype != want_dtype:
+            raise ValueError(f"{name}: dtype does not match the trajectory data")
+
+
+def _dense(a, shape, name, transposed_last2=False):
+    """Check that `a` has logical `shape` and that its memory is the dense slab the C ABI expects.
+    transposed_last2: logical (N, r, c) must be stored as C-order (N, c, r) (Julia column-major r x c x N)."""
+    if tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")   # DimensionMismatch
+    if _is_torch(a):
+        st = tuple(a.stride())
+        item = 1
+    else:
+        st = tuple(s // a.itemsize for s in a.strides)
+        item = 1
+    nd = len(shape)
+    if transposed_last2:
+        N, r, c = shape
+        want = (r * c, 1, r)
+    else:
+        want = []
+        acc = item
+        for s in reversed(shape):
+            want.append(acc)
+            acc *= s
+        want = tuple(reversed(want))
+    for i in range(nd):
+        if shape[i] > 1 and st[i] != want[i]:
+            hint = " (allocate it with rdhip.alloc_jacobians / alloc_errstate_jacobians)" if transposed_last2 else " (must be C-contiguous)"
+            raise ValueError(f"{name}: memory layout {st} does not match the packed layout {want}{hint}")
+    return a
+
+
+def _resolve_ctx(args):
+    """Pick memspace/device/stream from the data arguments; all must live in the same space."""
+    spaces = {a.space for a in args if a.ptr is not None}
+    if len(spaces) != 1:
+        raise ValueError("all arrays of one call must be either host (numpy) or device (torch.cuda) arrays")
+    space = spaces.pop()
+    if space == L.DEVICE:
+        devs = {a.device for a in args if a.ptr is not None}
+        if len(devs) != 1:
+            raise ValueError("arrays live on different devices")
+        dev = devs.pop()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        return L.context_for(dev, stream), space
+    dev = torch.cuda.current_device() if (torch is not None and torch.cuda.is_available()) else 0
+    return L.context_for(dev, None), space
+
+
+def _empty_like_data(data, shape):
+    if _is_torch(data):
+        return torch.empty(shape, dtype=data.dtype, device=data.device)
+    return np.empty(shape, dtype=data.dtype)
+
+
+def alloc_jacobians(model, N, like=None, dtype=None):
+    """(N, n, n+m) Jacobian stack with the reference's column-major-per-knot memory (src/jacobian.jl:26-37)."""
+    n, m = state_dim(model), control_dim(model)
+    base = _alloc((N, n + m, n), like, dtype)
+    return base.transpose(1, 2) if _is_torch(base) else base.transpose(0, 2, 1)
+
+
+def alloc_errstate_jacobians(model, N, like=None, dtype=None):
+    n, e = state_dim(model), errstate_dim(model)
+    base = _alloc((N, e, n), like, dtype, zero=True)
+    return base.transpose(1, 2) if _is_torch(base) else base.transpose(0, 2, 1)
+
+
+def _alloc(shape, like, dtype, zero=False):
+    if like is not None and _is_torch(like):
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=dtype or like.dtype, device=like.device)
+    f = np.zeros if zero else np.empty
+    return f(shape, dtype=dtype or (like.dtype if like is not None else np.float64))
+
+
+# =============================================================================================================
+# knot points and packed trajectories  (src/knotpoint.jl, src/trajectories.jl)
+# =============================================================================================================
+class AbstractKnotPoint:
+    """z = [x; u], t, dt.  dt == 0 marks a terminal knot point whose control reads as zeros
+    (src/knotpoint.jl:67,123)."""
+
+    def __init__(self, *args):
+        # KnotPoint(x, u, t, dt) | KnotPoint(n, m, z, t, dt)     (src/knotpoint.jl:154-183)
+        if len(args) == 4:
+            x, u, t, dt = args
+            x, u = np.asarray(x), np.asarray(u)
+            both32 = x.dtype == np.float32 and u.dtype == np.float32
+            z = np.concatenate([x, u]).astype(np.float32 if both32 else np.float64)
+            n, m = x.shape[0], u.shape[0]
+        elif len(args) == 5:
+            n, m, z, t, dt = args
+            z = z if isinstance(z, np.ndarray) else np.asarray(z, dtype=np.float64)
+        elif len(args) == 3:
+            raise TypeError("KnotPoint(x, u, dt) is the v0.3 constructor; v0.4 needs KnotPoint(x, u, t, dt) (src/knotpoint.jl:178-183)")
+        else:
+            raise TypeError("KnotPoint(x, u, t, dt) or KnotPoint(n, m, z, t, dt)")
+        assert n > 0 and m > 0, "state and control dimensions must be positive"
+        assert n + m == len(z), "n + m must equal length(z)"
+        self.z, self.t, self.dt, self.n, self.m = z, float(t), float(dt), int(n), int(m)
+
+    # AbstractVector interface
+    def __len__(self):
+        return self.n + self.m
+
+    def __getitem__(self, i):
+        return self.z[i]
+
+    def __setitem__(self, i, v):
+        self.z[i] = v
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.z, dtype=dtype)
+
+
+class KnotPoint(AbstractKnotPoint):
+    pass
+
+
+class StaticKnotPoint(AbstractKnotPoint):
+    """StaticKnotPoint(z, v): same t, dt, new data (src/knotpoint.jl:225-227)."""
+
+    def __init__(self, *args):
+        if len(args) == 2 and isinstance(args[0], AbstractKnotPoint):
+            z, v = args
+            super().__init__(z.n, z.m, np.asarray(v), z.t, z.dt)
+        elif len(args) == 1 and isinstance(args[0], AbstractKnotPoint):
+            z = args[0]
+            super().__init__(z.n, z.m, z.z, z.t, z.dt)
+        else:
+            super().__init__(*args)
+
+
+def is_terminal(z):
+    return z.dt == 0.0
+
+
+def state(z):
+    return z.z[: z.n]
+
+
+def control(z):
+    return np.zeros(z.m, dtype=z.z.dtype) if is_terminal(z) else z.z[z.n:]
+
+
+def getdata(z):
+    return z.data if isinstance(z, PackedTrajectory) else z.z
+
+
+def getparams(z):
+    return {"t": z.t, "dt": z.dt}
+
+
+def time(z):
+    return z.t
+
+
+def timestep(z):
+    return z.dt
+
+
+def setdata_(z, v):
+    z.z[:] = v
+
+
+def setstate_(z, x):
+    z.z[: z.n] = x
+
+
+def setcontrol_(z, u):
+    z.z[z.n:] = u
+
+
+def settime_(z, t):
+    z.t = float(t)
+
+
+def settimestep_(z, dt):
+    z.dt = float(dt)
+
+
+class PackedTrajectory:
+    """Dense replacement for SampledTrajectory = Vector{KnotPoint} (src/trajectories.jl:40-50): one (N, n+m)
+    array + t, dt vectors.  `Z[k]` is a KnotPoint VIEW into row k (host trajectories)."""
+
+    def __init__(self, n, m, data, t, dt):
+        self.n, self.m = int(n), int(m)
+        N = data.shape[0]
+        _dense(data, (N, n + m), "data")
+        self.data = data
+        if _is_torch(data):
+            self.t = torch.as_tensor(t, dtype=torch.float64, device=data.device).expand(N).contiguous()
+            self.dt = torch.as_tensor(dt, dtype=torch.float64, device=data.device).expand(N).contiguous()
+        else:
+            self.t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (N,)))
+            self.dt = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, dtype=np.float64), (N,)))
+
+    # ---- constructors mirroring SampledTrajectory{n,m}(X, U; dt=, tf=) (src/trajectories.jl:92-109) --------------
+    @classmethod
+    def from_states_controls(cls, X, U, dt=None, tf=None, t0=0.0, dtype=np.float64):
+        X, U = np.asarray(X, dtype=dtype), np.asarray(U, dtype=dtype)
+        N, n = X.shape
+        m = U.shape[1]
+        times = _gettimeinfo(t0=t0, tf=tf, dt=dt, N=N)
+        dts = np.empty(N)
+        dts[:-1] = np.diff(times)
+        data = np.zeros((N, n + m), dtype=dtype)
+        data[:, :n] = X
+        if U.shape[0] == N:          # terminal control present: dt = Inf (first-order hold convention)
+            data[:, n:] = U
+            dts[-1] = np.inf
+        elif U.shape[0] == N - 1:
+            data[:-1, n:] = U
+            dts[-1] = 0.0
+        else:
+            raise ValueError("U must have N or N-1 rows")
+        return cls(n, m, data, times, dts)
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, k):
+        if _is_torch(self.data):
+            raise TypeError("indexing knot points needs a host trajectory; use .cpu() first")
+        if k < 0:
+            k += len(self)
+        return KnotPoint(self.n, self.m, self.data[k], self.t[k], self.dt[k])
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def to(self, device):
+        if torch is None:
+            raise RuntimeError("torch is required for device trajectories")
+        d = torch.as_tensor(np.array(self.data) if not _is_torch(self.data) else self.data).to(device)
+        return PackedTrajectory(self.n, self.m, d, torch.as_tensor(np.array(self.t) if not _is_torch(self.t) else self.t).to(device),
+                                torch.as_tensor(np.array(self.dt) if not _is_torch(self.dt) else self.dt).to(device))
+
+    def cpu(self):
+        if not _is_torch(self.data):
+            return self
+        return PackedTrajectory(self.n, self.m, self.data.cpu().numpy(), self.t.cpu().numpy(), self.dt.cpu().numpy())
+
+
+SampledTrajectory = PackedTrajectory
+Traj = PackedTrajectory   # v0.3 name (src/deprecate.jl:6)
+
+
+def _gettimeinfo(t0=0.0, tf=None, dt=None, N=0):   # src/trajectories.jl:355-400
+    if dt is not None and np.ndim(dt) > 0:
+        dt = np.asarray(dt, dtype=np.float64)
+        assert np.all(dt > 0), "All time steps must be positive"
+        if N == 0:
+            N = len(dt) + 1
+        assert len(dt) == N - 1, f"Time step vector must have length of N-1, got {len(dt)} with N={N}."
+        return np.concatenate([[t0], t0 + np.cumsum(dt)])
+    missing = (tf is None) + (dt is None) + (N == 0)
+    if missing > 1:
+        raise ValueError("Must specify at least two of the following: dt, tf, N")
+    if N == 0:
+        N = int(round(tf / dt + 1))
+        dt = (tf - t0) / (N - 1)
+    if tf is not None and dt is None:
+        dt = tf / (N - 1)
+    if dt is not None and tf is None:
+        tf = dt * (N - 1)
+    assert np.isclose(tf, dt * (N - 1)), "Inconsistent time step and final time."
+    return np.linspace(t0, tf, N)
+
+
+def states(Z):
+    return Z.data[:, : Z.n]
+
+
+def controls(Z):
+    return Z.data[:, Z.n:]
+
+
+def gettimes(Z):
+    return Z.t
+
+
+def has_terminal_control(Z):
+    return float(Z.dt[-1]) != 0.0
+
+
+# =============================================================================================================
+# models  (AbstractFunction > AbstractModel > ContinuousDynamics / DiscreteDynamics)
+# =============================================================================================================
+class AbstractFunction:
+    pass
+
+
+class AbstractModel(AbstractFunction):
+    pass
+
+
+class ContinuousDynamics(AbstractModel):
+    """A registered continuous model.  Subclasses define `_kind`, `_params()`; user-defined Python dynamics cannot
+    run on the GPU (no kernel DSL by design), so only the registry models are evaluable."""
+    _kind = None
+    rotation = QuatRotation
+    velocity_frame = "world"
+
+    def _params(self):
+        raise NotImplementedError
+
+    @property
+    def _handle(self):
+        h = getattr(self, "_h", None)
+        if h is None:
+            if self._kind is None:
+                raise NotImplementedError(f"User-defined static return function not implemented for {type(self).__name__}")   # src/functionbase.jl:231-232
+            p = np.ascontiguousarray(np.asarray(self._params(), dtype=np.float64))
+            h = C.c_void_p()
+            frame = L.FRAME_BODY if self.velocity_frame == "body" else L.FRAME_WORLD
+            L.check(L.lib().rdhip_model_create(self._kind, self.rotation.code, frame, p.ctypes.data_as(C.POINTER(C.c_double)), p.size, C.byref(h)))
+            self._h = h
+        return h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None:
+            try:
+                L.lib().rdhip_model_destroy(h)
+            except Exception:
+                pass
+
+    def _dims4(self):
+        n, m, p, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().rdhip_model_dims(self._handle, C.byref(n), C.byref(m), C.byref(p), C.byref(e)))
+        return n.value, m.value, p.value, e.value
+
+
+class DiscreteDynamics(AbstractModel):
+    pass
+
+
+class _DiscretizedMeta(type):
+    def __getitem__(cls, Q):          # DiscretizedDynamics[RK4](model)  ==  DiscretizedDynamics{RK4}(model)
+        return lambda model: cls(model, Q)
+
+
+class DiscretizedDynamics(DiscreteDynamics, metaclass=_DiscretizedMeta):
+    """DiscretizedDynamics(continuous_dynamics, integrator) (src/discretized_dynamics.jl:169-184)."""
+
+    def __init__(self, continuous_dynamics, integrator):
+        if not isinstance(continuous_dynamics, ContinuousDynamics):
+            raise TypeError("continuous_dynamics must be a ContinuousDynamics model")
+        self.continuous_dynamics = continuous_dynamics
+        self.integrator = integrator() if isinstance(integrator, type) else integrator
+        _rule_code(self.integrator)
+
+    def __copy__(self):               # Base.copy(model) is shallow (src/discretized_dynamics.jl:194-196)
+        return DiscretizedDynamics(self.continuous_dynamics, self.integrator)
+
+
+def integration(model):
+    return model.integrator
+
+
+class LieGroupModel(ContinuousDynamics):
+    pass
+
+
+class Cartpole(ContinuousDynamics):          # examples/cartpole.jl:5-12 ; test/cartpole_model.jl:2-9
+    _kind = L.MODEL_CARTPOLE
+
+    def __init__(self, mc=1.0, mp=0.2, l=0.5, g=9.81):
+        self.mc, self.mp, self.l, self.g = mc, mp, l, g
+
+    def _params(self):
+        return [self.mc, self.mp, self.l, self.g]
+
+
+class DoubleIntegrator(ContinuousDynamics):  # test/double_integrator.jl:97-99  (DI{D})
+    _kind = L.MODEL_DOUBLE_INTEGRATOR
+
+    def __init__(self, D):
+        self.D = int(D)
+
+    def _params(self):
+        return [self.D]
+
+
+class LinearModel(ContinuousDynamics):       # xdot = A x + B u
+    _kind = L.MODEL_LINEAR
+
+    def __init__(self, A, B):
+        self.A, self.B = np.asarray(A, dtype=np.float64), np.asarray(B, dtype=np.float64)
+
+    def _params(self):
+        n, m = self.B.shape
+        return np.concatenate([[n, m], self.A.flatten(order="F"), self.B.flatten(order="F")])
+
+
+class RigidBody(LieGroupModel):
+    """abstract type RigidBody{R} <: LieGroupModel (src/rigidbody.jl:46); LieState = (R, (3, 6)) (:48)."""
+
+    def __init__(self, R=QuatRotation, bodyframe=False):
+        self.rotation = R
+        self.velocity_frame = "body" if bodyframe else "world"
+
+
+class Satellite(RigidBody):                  # examples/single_satellite.jl:7-35 ; `Body` of test/rigidbody_test.jl:23-54
+    _kind = L.MODEL_SATELLITE
+
+    def __init__(self, mass=1.0, J=None, R=QuatRotation, bodyframe=False):
+        super().__init__(R, bodyframe)
+        self.mass = float(mass)
+        self.J = np.eye(3) if J is None else np.asarray(J, dtype=np.float64)
+
+    def _params(self):
+        return np.concatenate([[self.mass], self.J.flatten(order="F")])
+
+
+def Body(R=QuatRotation, bodyframe=False):   # test/rigidbody_test.jl:53-54: mass 2, J = Diagonal(2, 3, 1)
+    return Satellite(2.0, np.diag([2.0, 3.0, 1.0]), R, bodyframe)
+
+
+class Quadrotor(RigidBody):                  # test/quadrotor.jl:21-46
+    _kind = L.MODEL_QUADROTOR
+
+    def __init__(self, R=QuatRotation, mass=0.5, J=None, gravity=(0.0, 0.0, -9.81), motor_dist=0.1750, kf=1.0, km=0.0245, bodyframe=False):
+        super().__init__(R, bodyframe)
+        self.mass = float(mass)
+        self.J = np.diag([0.0023, 0.0023, 0.004]) if J is None else np.asarray(J, dtype=np.float64)
+        self.gravity = np.asarray(gravity, dtype=np.float64)
+        self.motor_dist, self.kf, self.km = float(motor_dist), float(kf), float(km)
+
+    def _params(self):
+        return np.concatenate([[self.mass], self.J.flatten(order="F"), self.gravity, [self.motor_dist, self.kf, self.km]])
+
+
+class SatellitePair(LieGroupModel):          # examples/satellite_pair.jl:8-44
+    _kind = L.MODEL_SATELLITE_PAIR
+
+    def __init__(self, J1=None, J2=None, R=QuatRotation):
+        self.rotation = R
+        self.J1 = np.eye(3) if J1 is None else np.asarray(J1, dtype=np.float64)
+        self.J2 = 2 * np.eye(3) if J2 is None else np.asarray(J2, dtype=np.float64)
+
+    def _params(self):
+        return np.concatenate([self.J1.flatten(order="F"), self.J2.flatten(order="F")])
+
+
+class LieSatellite(LieGroupModel):           # `Satellite` of test/liemodel.jl:1-22 (x = [w; q])
+    _kind = L.MODEL_LIE_SATELLITE
+
+    def __init__(self, Jd=(1.0, 1.0, 1.0), R=QuatRotation):
+        self.rotation = R
+        self.Jd = np.asarray(Jd, dtype=np.float64)
+
+    def _params(self):
+        return self.Jd
+
+
+# ---- trait queries ------------------------------------------------------------------------------------------------
+def _cm(fun):
+    return fun.continuous_dynamics if isinstance(fun, DiscretizedDynamics) else fun
+
+
+def state_dim(fun):
+    if isinstance(fun, (AbstractKnotPoint, PackedTrajectory)):
+        return fun.n
+    if isinstance(fun, LieState):
+        return len(fun)
+    if not isinstance(fun, AbstractFunction):
+        raise TypeError(f"state_dim needs to be implemented for {type(fun)}")
+    return _cm(fun)._dims4()[0]
+
+
+def control_dim(fun):
+    if isinstance(fun, (AbstractKnotPoint, PackedTrajectory)):
+        return fun.m
+    return _cm(fun)._dims4()[1]
+
+
+def output_dim(fun):
+    return _cm(fun)._dims4()[2]
+
+
+def errstate_dim(fun):
+    if isinstance(fun, LieState):
+        return fun.errstate_dim()
+    if isinstance(fun, AbstractKnotPoint):     # src/functionbase.jl:134
+        return fun.n
+    return _cm(fun)._dims4()[3]
+
+
+def dims(fun):
+    if isinstance(fun, AbstractKnotPoint):
+        return (fun.n, fun.m)
+    if isinstance(fun, PackedTrajectory):      # dims(Z) = (n per knot, m per knot, N)  src/trajectories.jl:131
+        N = len(fun)
+        return ([fun.n] * N, [fun.m] * N, N)
+    return _cm(fun)._dims4()[:3]
+
+
+def jacobian_width(fun):                       # src/functionbase.jl:135
+    return errstate_dim(fun) + control_dim(fun)
+
+
+def functioninputs(fun):
+    return StateControl()
+
+
+def input_dim(fun):
+    return state_dim(fun) + control_dim(fun)
+
+
+def default_diffmethod(fun):                   # src/functionbase.jl:121 ; src/discretized_dynamics.jl:190
+    return ForwardAD() if isinstance(fun, DiscretizedDynamics) else UserDefined()
+
+
+def default_signature(fun):
+    return StaticReturn()
+
+
+def statevectortype(fun):
+    flag = C.c_int()
+    L.check(L.lib().rdhip_model_statevectortype(_cm(fun)._handle, C.byref(flag)))
+    return RotationState() if flag.value else EuclideanState()
+
+
+def rotation_type(model):
+    return _cm(model).rotation
+
+
+def velocity_frame(model):
+    return _cm(model).velocity_frame
+
+
+def gen_inds(model):
+    """1-based index ranges (r, q, v, w, u) of a RigidBody state (src/rigidbody.jl:80-94)."""
+    first = (C.c_int * 5)()
+    ln = (C.c_int * 5)()
+    L.check(L.lib().rdhip_model_gen_inds(_cm(model)._handle, first, ln))
+    return {k: range(first[i], first[i] + ln[i]) for i, k in enumerate(("r", "q", "v", "w", "u"))}
+
+
+class LieState:
+    """LieState{R,P}: partition of a state vector into vector parts P and rotations R (src/liestate.jl:75-131)."""
+
+    def __init__(self, *args):
+        if len(args) == 1 and isinstance(args[0], AbstractFunction):
+            rot, nP, P = C.c_int(), C.c_int(), (C.c_int * 8)()
+            L.check(L.lib().rdhip_model_liestate(_cm(args[0])._handle, C.byref(rot), C.byref(nP), P))
+            if nP.value == 0:
+                raise TypeError(f"LieState is not defined for the Euclidean model {type(args[0]).__name__}")
+            self.R = {L.ROT_QUAT: QuatRotation, L.ROT_MRP: MRP, L.ROT_RP: RodriguesParam}[rot.value]
+            self.P = tuple(P[i] for i in range(nP.value))
+        else:
+            self.R = args[0]
+            self.P = tuple(args[1]) if len(args) == 2 and not isinstance(args[1], int) else tuple(int(p) for p in args[1:])
+        self._q = None
+
+    def _query(self):
+        if self._q is None:
+            P = (C.c_int * len(self.P))(*self.P)
+            ln, ed = C.c_int(), C.c_int()
+            rf, vf = (C.c_int * 8)(), (C.c_int * 8)()
+            L.check(L.lib().rdhip_liestate_query(self.R.code, P, len(self.P), C.byref(ln), C.byref(ed), rf, vf))
+            self._q = (ln.value, ed.value, list(rf)[: len(self.P) - 1], list(vf)[: len(self.P)])
+        return self._q
+
+    def __len__(self):
+        return self._query()[0]
+
+    def errstate_dim(self):
+        return self._query()[1]
+
+    def __eq__(self, other):
+        return isinstance(other, LieState) and self.R is other.R and self.P == other.P
+
+    def __hash__(self):
+        return hash((self.R, self.P))
+
+    def __repr__(self):
+        return f"LieState{{{self.R.__name__},{self.P}}}()"
+
+
+def QuatState(n, Q):
+    """QuatState(n, Q): LieState with quaternions starting at the 1-based indices Q (src/liestate.jl:99-113)."""
+    Q = list(Q)
+    P = [Q[0] - 1] + [Q[i] - Q[i - 1] - 4 for i in range(1, len(Q))] + [n - (Q[-1] + 4) + 1]
+    return LieState(QuatRotation, tuple(P))
+
+
+def num_rotations(s):
+    return len(s.P) - 1
+
+
+def rot_inds(s, i):      # 1-based ranges like Julia (src/liestate.jl:127)
+    f = s._query()[2][i - 1]
+    return range(f, f + s.R.nparams)
+
+
+def vec_inds(s, i):      # src/liestate.jl:128-129
+    f = s._query()[3][i - 1]
+    return range(f, f + s.P[i - 1])
+
+
+def inds(s, i):          # src/liestate.jl:130
+    return vec_inds(s, 1 + i // 2) if i % 2 == 1 else rot_inds(s, i // 2)
+
+
+# ---- rand / zeros / fill generators (src/functionbase.jl:271-278, src/rigidbody.jl:50-70, src/liestate.jl:175-205) ------
+def rand(model, rng=None, dtype=np.float64):
+    rng = np.random.default_rng() if rng is None else rng
+    n, m = state_dim(model), control_dim(model)
+    x = rng.random(n)
+    if isinstance(statevectortype(model), RotationState):
+        s = LieState(model)
+        for i in range(1, num_rotations(s) + 1):
+            ri = rot_inds(s, i)
+            if s.R is QuatRotation:   # rand(QuatRotation): normalised 4-D Gaussian
+                q = rng.standard_normal(4)
+                x[ri.start - 1: ri.stop - 1] = q / np.linalg.norm(q)
+    return x.astype(dtype), rng.random(m).astype(dtype)
+
+
+def zeros(model, dtype=np.float64):
+    n, m = state_dim(model), control_dim(model)
+    x = np.zeros(n, dtype=dtype)
+    if isinstance(statevectortype(model), RotationState):
+        s = LieState(model)
+        if s.R is QuatRotation:
+            for i in range(1, num_rotations(s) + 1):
+                x[rot_inds(s, i).start - 1] = 1.0   # one(QuatRotation) = [1,0,0,0]
+    u = np.zeros(m, dtype=dtype)
+    cm = _cm(model)
+    if isinstance(cm, Quadrotor):       # hover controls, test/quadrotor.jl:133-137
+        u[:] = -cm.mass * cm.gravity[2] / 4
+    return x, u
+
+
+def fill(model, v):
+    return np.full(state_dim(model), v), np.full(control_dim(model), v)
+
+
+def trim_controls(model):               # test/quadrotor.jl:52-54
+    return np.full(4, -model.gravity[2] * model.mass / 4.0)
+
+
+# =============================================================================================================
+# DynamicsJacobian (src/jacobian.jl)
+# =============================================================================================================
+class DynamicsJacobian:
+    """n x (n+m) Jacobian stored column-major, with A / B views (src/jacobian.jl:26-48,74-75)."""
+
+    def __init__(self, *args):
+        if len(args) == 1 and isinstance(args[0], AbstractFunction):
+            n, m = state_dim(args[0]), control_dim(args[0])
+        elif len(args) == 1:
+            F = np.asarray(args[0], dtype=np.float64)
+            n, m = F.shape[0], F.shape[1] - F.shape[0]
+        else:
+            n, m = args
+        self.data = np.zeros((n, n + m), order="F")
+        if len(args) == 1 and not isinstance(args[0], AbstractFunction):
+            self.data[:] = args[0]
+        self.A = self.data[:, :n]
+        self.B = self.data[:, n:]
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def __getitem__(self, i):
+        return self.data[i]
+
+    def __setitem__(self, i, v):
+        self.data[i] = v
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.data, dtype=dtype)
+
+
+def get_A(D):
+    return D.A
+
+
+def get_B(D):
+    return D.B
+
+
+def get_data(A):
+    return A.data if isinstance(A, DynamicsJacobian) else A
+
+
+# =============================================================================================================
+# the batched operators
+# =============================================================================================================
+def _model_rule(fun):
+    if isinstance(fun, DiscretizedDynamics):
+        return fun.continuous_dynamics, _rule_code(fun.integrator)
+    if isinstance(fun, ContinuousDynamics):
+        return fun, L.CONTINUOUS
+    raise NotImplementedError(f"no batched kernels for {type(fun).__name__}")
+
+
+def _as_traj(fun, z):
+    """Accept a PackedTrajectory, a single knot point, or (x, u, t, dt)."""
+    if isinstance(z, PackedTrajectory):
+        return z, False
+    if isinstance(z, AbstractKnotPoint):
+        data = np.ascontiguousarray(np.asarray(z.z)[None, :])
+        if data.dtype not in (np.float64, np.float32):
+            data = data.astype(np.float64)
+        return PackedTrajectory(z.n, z.m, data, [z.t], [z.dt]), True
+    raise TypeError(f"expected a KnotPoint or PackedTrajectory, got {type(z)}")
+
+
+def _check_traj(fun, Z):
+    n, m = state_dim(fun), control_dim(fun)
+    if (Z.n, Z.m) != (n, m):
+        raise ValueError(f"trajectory has (n,m)=({Z.n},{Z.m}) but the model has ({n},{m})")
+    return n, m
+
+
+def _eval_into(fun, Y, Z):
+    model, rule = _model_rule(fun)
+    n, m = _check_traj(fun, Z)
+    N = len(Z)
+    _dense(Y, (N, n), "output")
+    az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+    ay = _Arg(Y, "output", az.dtype)
+    ctx, space = _resolve_ctx([az, at, adt, ay])
+    lib = L.lib()
+    if rule == L.CONTINUOUS:
+        rc = lib.rdhip_dynamics(ctx.handle, model._handle, az.dtype, N, az.ptr, at.ptr, adt.ptr, ay.ptr, space)
+    else:
+        rc = lib.rdhip_discrete_dynamics(ctx.handle, model._handle, rule, az.dtype, N, az.ptr, at.ptr, adt.ptr, ay.ptr, space)
+    L.check(rc, ctx.handle)
+    return Y
+
+
+def _split_args(args):
+    """(z,) | (x, u) | (x, u, t) | (x, u, t, dt) -> a one-knot PackedTrajectory."""
+    if len(args) == 1:
+        return args[0]
+    x, u = np.asarray(args[0], dtype=np.float64), np.asarray(args[1], dtype=np.float64)
+    t = args[2] if len(args) > 2 else 0.0
+    dt = args[3] if len(args) > 3 else np.nan    # continuous dynamics never reads dt; NaN is "not terminal"
+    return KnotPoint(len(x), len(u), np.concatenate([x, u]), t, dt)
+
+
+def evaluate(fun, *args):
+    """evaluate(fun, z): src/functionbase.jl:214-218 -> dynamics (src/dynamics.jl:110) or discrete_dynamics
+    (src/discrete_dynamics.jl:65).  z may be one knot point or a whole PackedTrajectory."""
+    Z, single = _as_traj(fun, _split_args(args))
+    Y = _empty_like_data(Z.data, (len(Z), state_dim(fun)))
+    _eval_into(fun, Y, Z)
+    return Y[0] if single else Y
+
+
+def evaluate_(fun, y, *args):
+    """evaluate!(fun, y, z): src/functionbase.jl:215."""
+    Z, single = _as_traj(fun, _split_args(args))
+    if single:
+        y[...] = evaluate(fun, Z)[0]
+        return None
+    _eval_into(fun, y, Z)
+    return None
+
+
+def dynamics(model, *args):
+    """dynamics(model, z) / (model, x, u[, t]): src/dynamics.jl:81-83."""
+    if not isinstance(model, ContinuousDynamics):
+        raise TypeError("dynamics needs a ContinuousDynamics model")
+    return evaluate(model, *args)
+
+
+def dynamics_(*args):
+    """dynamics!(model, xdot, z) / dynamics!(sig, model, xdot, z): src/dynamics.jl:95-107."""
+    if isinstance(args[0], FunctionSignature):
+        args = args[1:]
+    model, xdot = args[0], args[1]
+    return evaluate_(model, xdot, *args[2:])
+
+
+def discrete_dynamics(*args):
+    """discrete_dynamics(dmodel, z) / (dmodel, x, u, t, dt): src/discrete_dynamics.jl:80-83.
+    v0.3 spelling discrete_dynamics(RK3, model, z) is accepted."""
+    if isinstance(args[0], type) and issubclass(args[0], QuadratureRule) or isinstance(args[0], QuadratureRule):
+        fun, rest = DiscretizedDynamics(args[1], args[0]), args[2:]
+    else:
+        fun, rest = args[0], args[1:]
+    if not isinstance(fun, DiscreteDynamics):
+        raise TypeError("discrete_dynamics needs a DiscreteDynamics model (wrap it: DiscretizedDynamics(model, RK4))")
+    return evaluate(fun, *rest)
+
+
+def discrete_dynamics_(*args):
+    """discrete_dynamics!(dmodel, xn, z) / (sig, dmodel, xn, z): src/discrete_dynamics.jl:94-108."""
+    if isinstance(args[0], FunctionSignature):
+        args = args[1:]
+    if isinstance(args[0], type) and issubclass(args[0], QuadratureRule):   # v0.3: discrete_dynamics!(Q, xn, model, Z)
+        Q, xn, model = args[0], args[1], args[2]
+        return evaluate_(DiscretizedDynamics(model, Q), xn, *args[3:])
+    return evaluate_(args[0], args[1], *args[2:])
+
+
+def jacobian_(*args):
+    """jacobian!(sig, diff, fun, J, y, z): src/functionbase.jl:242 (generated methods src/jacobian_gen.jl:485-529,
+    :643-685; chain rule src/discretized_dynamics.jl:208-219).  Also the v0.3 form jacobian!(J, model, z).
+    Batched: J (N,n,n+m) from alloc_jacobians, y (N,n) or None, z a PackedTrajectory.  Per-knot: J (n,n+m), y (n)."""
+    if len(args) == 3:    # v0.3: jacobian!(D, model, z)
+        J, fun, z = args
+        sig, diff, y = default_signature(fun), default_diffmethod(fun), None
+    elif len(args) == 6:
+        sig, diff, fun, J, y, z = args
+    else:
+        raise TypeError("jacobian_(sig, diff, fun, J, y, z)  or  jacobian_(J, model, z)")
+    if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+        raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+    if isinstance(diff, ImplicitFunctionTheorem):
+        raise ValueError("ImplicitFunctionTheorem needs an implicit integrator (not part of the batched path)")
+    model, rule = _model_rule(fun)
+    Z, single = _as_traj(fun, z)
+    n, m = _check_traj(fun, Z)
+    N = len(Z)
+    if single:
+        Jb = alloc_jacobians(fun, 1, Z.data)
+        yb = np.empty((1, n), dtype=Z.data.dtype)
+        jacobian_(sig, diff, fun, Jb, yb, Z)
+        get_data(J)[...] = Jb[0]
+        if y is not None:
+            y[...] = yb[0]
+        return None
+    _dense(J, (N, n, n + m), "J", transposed_last2=True)
+    az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+    aj = _Arg(J, "J", az.dtype)
+    ay = _Arg(y, "y", az.dtype)
+    if y is not None:
+        _dense(y, (N, n), "y")
+    ctx, space = _resolve_ctx([az, at, adt, aj, ay])
+    L.check(L.lib().rdhip_jacobian(ctx.handle, model._handle, rule, diff.code, az.dtype, N, az.ptr, at.ptr, adt.ptr, aj.ptr, ay.ptr, space), ctx.handle)
+    return None
+
+
+def discrete_jacobian_(Q, J, model, z):
+    """v0.3 discrete_jacobian!(Q, D, model, z) == jacobian!(sig, ForwardAD(), DiscretizedDynamics{Q}(model), D, y, z)."""
+    fun = DiscretizedDynamics(model, Q)
+    return jacobian_(default_signature(fun), ForwardAD(), fun, J, None, z)
+
+
+def _states_of(model, x):
+    """(array, ld, N, single): states from a PackedTrajectory / KnotPoint / (N, >=n) array / single vector."""
+    n = state_dim(model)
+    if isinstance(x, PackedTrajectory):
+        return x.data, x.n + x.m, len(x), False
+    if isinstance(x, AbstractKnotPoint):
+        a = np.ascontiguousarray(np.asarray(x.z, dtype=np.float64)[None, :n])
+        return a, n, 1, True
+    if (isinstance(x, np.ndarray) or _is_torch(x)) and x.ndim == 2:
+        # rows = states; a row stride larger than the row length is a leading dimension (e.g. Z.data[:, :n])
+        st = tuple(x.stride()) if _is_torch(x) else tuple(v // x.itemsize for v in x.strides)
+        if x.shape[1] < n:
+            raise ValueError(f"states have length {x.shape[1]}, model needs {n}")
+        if x.shape[1] > 1 and st[1] != 1 or (x.shape[0] > 1 and st[0] < x.shape[1]):
+            raise ValueError(f"x: memory layout {st} is not a row-major state stack")
+        return x, (st[0] if x.shape[0] > 1 else x.shape[1]), x.shape[0], False
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64)[None, :])
+    if a.shape[1] < n:
+        raise ValueError(f"state has length {a.shape[1]}, model needs {n}")
+    return a, a.shape[1], 1, True
+
+
+def errstate_jacobian_(model, G, x, clear=None):
+    """errstate_jacobian!(model, G, z|x): src/statevectortype.jl:119-122.  Like the reference, G is NOT cleared for
+    RotationState models unless clear=True (src/liestate.jl:293-297); Euclidean models write G = I."""
+    X, ldx, N, single = _states_of(model, x)
+    cm = _cm(model)
+    n, e = state_dim(model), errstate_dim(model)
+    clear = False if clear is None else bool(clear)
+    if single:
+        Gb = np.ascontiguousarray(np.asarray(get_data(G), dtype=X.dtype).T[None])      # (1, e, n)
+        errstate_jacobian_(model, Gb.transpose(0, 2, 1), X, clear)
+        get_data(G)[...] = Gb[0].T
+        return None
+    _dense(G, (N, n, e), "G", transposed_last2=True)
+    ax = _Arg(X, "x")
+    ag = _Arg(G, "G", ax.dtype)
+    ctx, space = _resolve_ctx([ax, ag])
+    L.check(L.lib().rdhip_errstate_jacobian(ctx.handle, cm._handle, ax.dtype, N, ax.ptr, ldx, int(clear), ag.ptr, space), ctx.handle)
+    return None
+
+
+def state_diff_jacobian_(G, model, z):
+    """v0.3 state_diff_jacobian!(G, model, z) (deprecated alias, src/deprecate.jl:1) -- note the argument order."""
+    return errstate_jacobian_(model, G, z)
+
+
+def state_diff(model, x, x0):
+    """state_diff(model, x, x0) with the default CayleyMap: src/statevectortype.jl:104, src/liestate.jl:26-28."""
+    X, ldx, N, single = _states_of(model, x)
+    X0, ldx0, N0, _ = _states_of(model, x0)
+    if N != N0:
+        raise ValueError("x and x0 hold different numbers of states")
+    dx = _empty_like_data(X, (N, errstate_dim(model)))
+    state_diff_(model, dx, X, X0)
+    return dx[0] if single else dx
+
+
+def state_diff_(model, dx, x, x0):
+    """state_diff!(model, dx, x, x0): src/statevectortype.jl:102."""
+    X, ldx, N, single = _states_of(model, x)
+    X0, ldx0, _, _ = _states_of(model, x0)
+    e = errstate_dim(model)
+    if single and not (hasattr(dx, "ndim") and dx.ndim == 2):
+        tmp = np.empty((1, e), dtype=X.dtype)
+        state_diff_(model, tmp, X, X0)
+        dx[...] = tmp[0]
+        return None
+    _dense(dx, (N, e), "dx")
+    ax, a0 = _Arg(X, "x"), _Arg(X0, "x0")
+    ad = _Arg(dx, "dx", ax.dtype)
+    if a0.dtype != ax.dtype:
+        raise ValueError("x and x0 have different dtypes")
+    ctx, space = _resolve_ctx([ax, a0, ad])
+    L.check(L.lib().rdhip_state_diff(ctx.handle, _cm(model)._handle, ax.dtype, N, ax.ptr, ldx, a0.ptr, ldx0, ad.ptr, space), ctx.handle)
+    return None
+
+
+def nabla_errstate_jacobian_(model, dG, x, xbar, clear=None):
+    """nabla-errstate_jacobian!(model, nablaG, x, xbar): src/statevectortype.jl:137-141, src/liestate.jl:300-320.
+    Only the 3x3 rotation blocks are written unless clear=True (Euclidean models: nablaG .= 0)."""
+    X, ldx, N, single = _states_of(model, x)
+    Xb, ldxb, _, _ = _states_of(model, xbar)
+    e = errstate_dim(model)
+    clear = False if clear is None else bool(clear)
+    if single:
+        Hb = np.ascontiguousarray(np.asarray(get_data(dG), dtype=X.dtype).T[None])
+        nabla_errstate_jacobian_(model, Hb.transpose(0, 2, 1), X, Xb, clear)
+        get_data(dG)[...] = Hb[0].T
+        return None
+    _dense(dG, (N, e, e), "nablaG", transposed_last2=True)
+    ax, ab = _Arg(X, "x"), _Arg(Xb, "xbar")
+    ah = _Arg(dG, "nablaG", ax.dtype)
+    ctx, space = _resolve_ctx([ax, ab, ah])
+    L.check(L.lib().rdhip_nabla_errstate_jacobian(ctx.handle, _cm(model)._handle, ax.dtype, N, ax.ptr, ldx, ab.ptr, ldxb, int(clear), ah.ptr, space), ctx.handle)
+    return None
+
+
+grad_errstate_jacobian_ = nabla_errstate_jacobian_
+
+
+def nabla2_differential_(dG, model, x, dx):
+    """v0.3 nabla^2 differential!(nablaG, model, x, dx) (src/deprecate.jl:2)."""
+    return nabla_errstate_jacobian_(model, dG, x, dx)
+
+
+def propagate_dynamics_(sig, model, z2, z1):
+    """propagate_dynamics!(sig, model, z2, z1): src/discrete_dynamics.jl:217-235."""
+    setstate_(z2, discrete_dynamics(model, z1))
+    return None
+
+
+def rollout_(sig, model, Z, x0=None):
+    """rollout!(sig, model, Z, x0): src/trajectories.jl:436-441.  Z is ONE PackedTrajectory (K knots) or a list /
+    (M, K, n+m) stack of trajectories that share the kernel launch (sequential in k, parallel over trajectories)."""
+    cm, rule = _model_rule(model)
+    if rule == L.CONTINUOUS:
+        raise TypeError("rollout! needs a DiscreteDynamics model")
+    if isinstance(Z, PackedTrajectory):
+        _check_traj(model, Z)
+        K, M = len(Z), 1
+        data3, t2, dt2 = Z.data, Z.t, Z.dt
+    else:                       # {"data": (M, K, n+m), "t": (M, K), "dt": (M, K)}
+        data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
+        M, K = data3.shape[0], data3.shape[1]
+        if data3.shape[2] != state_dim(model) + control_dim(model):
+            raise ValueError("trajectory stack has the wrong knot-point length")
+    x0a = x0
+    if x0a is not None and not _is_torch(x0a):
+        x0a = np.ascontiguousarray(np.asarray(x0a, dtype=data3.dtype if isinstance(data3, np.ndarray) else np.float64).reshape(M, -1))
+    if x0a is not None and tuple(x0a.shape) != (M, state_dim(model)) and tuple(x0a.shape) != (state_dim(model),):
+        raise ValueError("x0 has the wrong shape")
+    az, at, adt, a0 = _Arg(data3, "Z.data"), _Arg(t2, "Z.t"), _Arg(dt2, "Z.dt"), _Arg(x0a, "x0")
+    if a0.ptr is not None and a0.dtype != az.dtype:
+        raise ValueError("x0 dtype does not match the trajectory")
+    ctx, space = _resolve_ctx([az, at, adt, a0])
+    L.check(L.lib().rdhip_rollout(ctx.handle, cm._handle, rule, az.dtype, K, M, az.ptr, at.ptr, adt.ptr, a0.ptr, space), ctx.handle)
+    return None
+
+
+def maxdiff(a, b):   # src/utils.jl:16-22
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))

@@ -1,0 +1,259 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the rdhip host mirror) against the CPU oracle and the
+committed golden vectors.  Tolerances: fp64 max |GPU - oracle| < 1e-10 (BASELINE.json north_star); fp32 is compared
+with the fp64 oracle at rel 1e-4; integer queries are bit-exact (tests/test_host_abi.py)."""
+import numpy as np
+import pytest
+
+import rdhip as RD
+from oracle import rd_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+torch = pytest.importorskip("torch")
+
+RULES = {"euler": RD.Euler, "rk2": RD.RK2, "rk3": RD.RK3, "rk4": RD.RK4}
+ORULE = {"euler": O.EULER, "rk2": O.RK2, "rk3": O.RK3, "rk4": O.RK4}
+
+
+def rd_model(name, d):
+    """Build the rdhip model that corresponds to a dyn_* fixture."""
+    if name.startswith("cartpole"):
+        return RD.Cartpole(*d["params"])
+    if name.startswith("di"):
+        return RD.DoubleIntegrator(int(d["params"][0]))
+    if name.startswith("linear"):
+        return RD.LinearModel(d["A"], d["B"])
+    if name.startswith(("satellite_", "body_", "satfull_")):
+        return RD.Satellite(float(d["mass"]), d["J"], bodyframe=bool(d["frame"]))
+    if name.startswith("quadrotor"):
+        return RD.Quadrotor(mass=float(d["mass"]), J=d["J"], gravity=d["gravity"], motor_dist=float(d["L"]), kf=float(d["kf"]), km=float(d["km"]),
+                            bodyframe=bool(d["frame"]))
+    if name.startswith("satpair"):
+        return RD.SatellitePair(d["J1"], d["J2"])
+    if name.startswith("liesat"):
+        return RD.LieSatellite(d["Jd"])
+    raise KeyError(name)
+
+
+def traj(model, Z, t, dt, device=None, dtype=np.float64):
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = RD.PackedTrajectory(n, m, np.ascontiguousarray(Z, dtype=dtype), t, dt)
+    return T.to(device) if device else T
+
+
+def host(a):
+    return a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+
+
+# ------------------------------------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", H.dyn_cases())
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_golden_dynamics_and_jacobians(name, where):
+    d = H.load("dyn_" + name)
+    model = rd_model(name, d)
+    Z = traj(model, d["Z"], d["t"], d["dt"], "cuda" if where == "cuda" else None)
+    N = len(Z)
+    np.testing.assert_allclose(host(RD.dynamics(model, Z)), d["xdot"], rtol=0, atol=TOL)
+    J = RD.alloc_jacobians(model, N, Z.data)
+    Y = RD.evaluate(model, Z) * 0
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), model, J, Y, Z)
+    np.testing.assert_allclose(host(J), d["Jc"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y), d["xdot"], rtol=0, atol=TOL)
+    for rn, Q in RULES.items():
+        dm = RD.DiscretizedDynamics(model, Q)
+        np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), d["xn_" + rn], rtol=0, atol=TOL)
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+        np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(Y), d["xn_" + rn], rtol=0, atol=TOL)
+        # FiniteDifference: reference tolerance atol = 1e-6 (test/integration_tests.jl:14)
+        RD.jacobian_(RD.InPlace(), RD.FiniteDifference(), dm, J, None, Z)
+        scale = max(1.0, np.abs(d["Jd_" + rn]).max())
+        np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("tag,mk", [("rigid", RD.Satellite), ("satpair", RD.SatellitePair), ("liesat", RD.LieSatellite)])
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_golden_errstate(tag, mk, where):
+    d = H.load("err_" + tag)
+    model = mk()
+    X, Xb, X0 = d["X"], d["Xbar"], d["X0"]
+    if where == "cuda":
+        X, Xb, X0 = (torch.as_tensor(a).cuda() for a in (X, Xb, X0))
+    N = X.shape[0]
+    G = RD.alloc_errstate_jacobians(model, N, X)
+    RD.errstate_jacobian_(model, G, X)                      # G pre-zeroed, like the reference's callers do
+    np.testing.assert_allclose(host(G), d["G"], rtol=0, atol=TOL)
+    G2 = RD.alloc_errstate_jacobians(model, N, X)
+    G2 += 7.0
+    RD.errstate_jacobian_(model, G2, X, clear=True)
+    np.testing.assert_allclose(host(G2), d["G"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(RD.state_diff(model, X, X0)), d["dX"], rtol=0, atol=1e-9)
+    e = RD.errstate_dim(model)
+    base = torch.zeros((N, e, e), dtype=torch.float64, device="cuda") if where == "cuda" else np.zeros((N, e, e))
+    dG = base.transpose(1, 2) if where == "cuda" else base.transpose(0, 2, 1)
+    RD.nabla_errstate_jacobian_(model, dG, X, Xb)
+    np.testing.assert_allclose(host(dG), d["dG"], rtol=0, atol=TOL)
+
+
+def test_errstate_does_not_clear_by_default():
+    # src/liestate.jl:293-297: only ones and rotation blocks are written
+    model = RD.Body()
+    rng = np.random.default_rng(0)
+    X = H.rand_rigid(rng, 70, 6)[:, :13]
+    G = RD.alloc_errstate_jacobians(model, 70, X)
+    G += 7.0
+    RD.errstate_jacobian_(model, G, X)
+    ref = O.body().errstate_jacobian(X, clear=False, G0=np.full((70, 13, 12), 7.0))
+    np.testing.assert_allclose(G, ref, rtol=0, atol=TOL)
+    assert G[3, 0, 5] == 7.0 and G[3, 0, 0] == 1.0
+    # Euclidean model: always G = I
+    C = RD.Cartpole()
+    Gc = RD.alloc_errstate_jacobians(C, 5, X)
+    Gc += 3.0
+    RD.errstate_jacobian_(C, Gc, rng.random((5, 4)))
+    np.testing.assert_array_equal(Gc, np.broadcast_to(np.eye(4), (5, 4, 4)))
+
+
+# ------------------------------------------------------------------------------------------------ seeded random vs oracle
+CASES = [
+    ("cartpole", lambda: RD.Cartpole(), lambda: O.cartpole(), lambda rng, N: rng.random((N, 5))),
+    ("satellite", lambda: RD.Satellite(), lambda: O.satellite(), lambda rng, N: H.rand_rigid(rng, N, 6)),
+    ("body_bodyframe", lambda: RD.Body(bodyframe=True), lambda: O.body(O.FRAME_BODY), lambda rng, N: H.rand_rigid(rng, N, 6)),
+    ("quadrotor", lambda: RD.Quadrotor(), lambda: O.quadrotor(), lambda rng, N: H.rand_rigid(rng, N, 4, 0.6, 1.9)),
+    ("quadrotor_body", lambda: RD.Quadrotor(bodyframe=True), lambda: O.quadrotor(O.FRAME_BODY), lambda rng, N: H.rand_rigid(rng, N, 4, 0.6, 1.9)),
+]
+
+
+@pytest.mark.parametrize("name,mk,omk,gen", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000])
+def test_random_vs_oracle_ragged_sizes(name, mk, omk, gen, N):
+    rng = np.random.default_rng(N)
+    model, om = mk(), omk()
+    Zn = gen(rng, N)
+    t = np.arange(N) * 0.1
+    dt = np.full(N, 0.1)
+    if N > 2:
+        dt[-1] = 0.0          # terminal knot point: control reads as zeros (src/knotpoint.jl:67)
+    Z = traj(model, Zn, t, dt, "cuda")
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y = torch.empty((N, RD.state_dim(model)), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(RD.discrete_dynamics(RD.DiscretizedDynamics(model, RD.RK3), Z)), om.discrete_dynamics(O.RK3, Zn, t, dt), rtol=0, atol=TOL)
+    if N > 2:
+        n = RD.state_dim(model)
+        assert np.all(host(J)[-1, :, n:] == 0.0)
+        np.testing.assert_array_equal(host(J)[-1, :, :n], np.eye(n))
+
+
+def test_empty_batch_is_a_noop():
+    model = RD.Satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Z = traj(model, np.zeros((0, 19)), np.zeros(0), np.zeros(0), "cuda")
+    J = RD.alloc_jacobians(dm, 0, Z.data)
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, None, Z)
+    assert RD.discrete_dynamics(dm, Z).shape == (0, 13)
+
+
+def test_fp32_against_fp64_oracle():
+    # no Julia fp32 twin exists (KnotPoint.t/dt are Float64): compare with the fp64 oracle, rel 1e-4
+    rng = np.random.default_rng(5)
+    for model, om, Zn in ((RD.Cartpole(), O.cartpole(), rng.random((500, 5))), (RD.Satellite(), O.satellite(), H.rand_rigid(rng, 500, 6))):
+        N = 500
+        t, dt = np.zeros(N), np.full(N, 0.1)
+        Z = traj(model, Zn, t, dt, "cuda", dtype=np.float32)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        assert J.dtype == torch.float32
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, None, Z)
+        Jo, _ = om.jacobian(O.RK4, O.FORWARD_AD, Zn.astype(np.float32).astype(np.float64), t, dt)
+        np.testing.assert_allclose(host(J), Jo, rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_satellite_properties_and_sampled_oracle():
+    """BASELINE config: Satellite RK4, N = 65536.  Size-independent properties + oracle on the whole batch."""
+    N = 65536
+    rng = np.random.default_rng(3)
+    Zn = H.rand_rigid(rng, N, 6)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    model = RD.Satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Z = traj(model, Zn, t, dt, "cuda")
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    Jh, Yh = host(J), host(Y)
+    # structural facts of the world-frame satellite: d r'/d r = I, d r'/d v = h I, d v'/d v = I, rows q / w independent of r, v, f
+    np.testing.assert_array_equal(Jh[:, 0:3, 0:3], np.broadcast_to(np.eye(3), (N, 3, 3)))
+    np.testing.assert_allclose(Jh[:, 0:3, 7:10], np.broadcast_to(0.1 * np.eye(3), (N, 3, 3)), atol=1e-15)
+    np.testing.assert_array_equal(Jh[:, 7:10, 7:10], np.broadcast_to(np.eye(3), (N, 3, 3)))
+    assert not Jh[:, 3:7, 0:3].any() and not Jh[:, 3:7, 7:10].any() and not Jh[:, 3:7, 13:16].any()
+    assert not Jh[:, 10:13, 0:10].any() and not Jh[:, 10:13, 13:16].any()
+    # linearity in the control: x'(u) is affine in f and tau for fixed x (F = q*f, tau enters w linearly only through RK products)
+    # -> check the directional derivative identity J*dz ~ (f(z+eps dz) - f(z-eps dz)) / 2eps on a slice
+    sl = slice(0, 4096)
+    dz = rng.standard_normal((4096, 19))
+    eps = 1e-6
+    om = O.satellite()
+    fp = om.discrete_dynamics(O.RK4, Zn[sl] + eps * dz, t[sl], dt[sl])
+    fm = om.discrete_dynamics(O.RK4, Zn[sl] - eps * dz, t[sl], dt[sl])
+    np.testing.assert_allclose(np.einsum("kij,kj->ki", Jh[sl], dz), (fp - fm) / (2 * eps), atol=1e-7)
+    # whole batch against the oracle
+    Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    assert np.abs(Jh - Jo).max() < TOL and np.abs(Yh - Yo).max() < TOL
+
+
+def test_rollout_matches_oracle_and_is_idempotent():
+    rng = np.random.default_rng(9)
+    M, K = 37, 21
+    model, om = RD.Cartpole(), O.cartpole()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    data = rng.random((M, K, 5))
+    t = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy()
+    dt = np.full((M, K), 0.05); dt[:, -1] = 0.0
+    ref = om.rollout(O.RK4, data, t, dt)
+    stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(t).cuda(), "dt": torch.as_tensor(dt).cuda()}
+    RD.rollout_(RD.StaticReturn(), dm, stack)
+    np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
+    RD.rollout_(RD.InPlace(), dm, stack)      # rolling out an already rolled-out trajectory changes nothing
+    np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
+    # single trajectory through the SampledTrajectory-style constructor, with x0
+    X, U = rng.random((K, 4)), rng.random((K - 1, 1))
+    Zt = RD.PackedTrajectory.from_states_controls(X, U, dt=0.05)
+    x0 = rng.random(4)
+    RD.rollout_(RD.StaticReturn(), dm, Zt, x0)
+    ref1 = om.rollout(O.RK4, np.concatenate([X, np.vstack([U, np.zeros((1, 1))])], axis=1)[None], Zt.t[None], Zt.dt[None], X0=x0[None])
+    np.testing.assert_allclose(Zt.data, ref1[0], rtol=0, atol=TOL)
+
+
+def test_single_knot_point_api_reads_like_the_reference():
+    # examples/cartpole.jl:41-57 restated with v0.4 calls
+    model = RD.Cartpole()
+    n, m = RD.dims(model)[:2]
+    rng = np.random.default_rng(1)
+    x, u = RD.rand(model, rng)
+    z = RD.KnotPoint(x, u, 0.0, 0.1)
+    om = O.cartpole()
+    xdot = RD.dynamics(model, x, u)
+    np.testing.assert_allclose(xdot, om.dynamics(z.z[None], 0.0, 0.1)[0], atol=TOL)
+    D = RD.DynamicsJacobian(model)
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), model, D, np.zeros(n), z)
+    np.testing.assert_allclose(D.data, om.jacobian(O.CONTINUOUS, O.FORWARD_AD, z.z[None], 0.0, 0.1)[0][0], atol=TOL)
+    dmodel = RD.DiscretizedDynamics[RD.RK3](model)
+    xn = RD.discrete_dynamics(dmodel, z)
+    np.testing.assert_allclose(xn, om.discrete_dynamics(O.RK3, z.z[None], 0.0, 0.1)[0], atol=TOL)
+    np.testing.assert_allclose(RD.discrete_dynamics(RD.RK3, model, z), xn, atol=0)            # v0.3 spelling
+    np.testing.assert_allclose(RD.discrete_dynamics(dmodel, x, u, 0.0, 0.1), xn, atol=0)
+    RD.discrete_jacobian_(RD.RK3, D, model, z)                                                  # v0.3 spelling
+    np.testing.assert_allclose(D.data, om.jacobian(O.RK3, O.FORWARD_AD, z.z[None], 0.0, 0.1)[0][0], atol=TOL)
+    assert D.A.shape == (4, 4) and D.B.shape == (4, 1)
+    # errors mirror the reference
+    with pytest.raises(NotImplementedError):
+        RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), RD.SatellitePair(), np.zeros((14, 20)), np.zeros(14), RD.KnotPoint(np.ones(14), np.ones(6), 0.0, 0.1))
+    with pytest.raises(ValueError):
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dmodel, RD.alloc_jacobians(dmodel, 3), None, RD.PackedTrajectory(4, 1, np.zeros((2, 5)), 0.0, 0.1))

@@ -1,0 +1,225 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rdhip.h declares; integer queries are bit-exact
+against the oracle and the reference's index tables; host-side knot-point / trajectory logic; no CPU fallback."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rdhip as RD
+from oracle import rd_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(RD.HEADER_PATH).read()
+    declared = sorted(set(re.findall(r"\b(rdhip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(RD.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in rdhip.h but not exported"
+    assert sorted(RD.EXPORTS) == declared, "python binding table and header disagree"
+    assert lib.rdhip_version() == 10000
+
+
+def test_no_cpu_fallback_and_product_never_touches_oracle():
+    pkg = os.path.join(ROOT, "robotdynamics.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")) and "build" not in dp:
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "rd_oracle" not in txt and "oracle/" not in txt and "import oracle" not in txt, f"{f} references the oracle"
+    if RD.device_count() == 0:
+        with pytest.raises(RD.NoDeviceError):
+            RD.Context(0)
+        with pytest.raises(RD.NoDeviceError):
+            RD.dynamics(RD.Cartpole(), np.zeros(4), np.zeros(1))
+
+
+MODELS = [
+    (lambda R: RD.Cartpole(), lambda r: O.cartpole(), False),
+    (lambda R: RD.DoubleIntegrator(2), lambda r: O.double_integrator(2), False),
+    (lambda R: RD.Satellite(R=R), lambda r: O.Model(O.SATELLITE, O.satellite().params, rot=r), True),
+    (lambda R: RD.Quadrotor(R=R), lambda r: O.Model(O.QUADROTOR, O.quadrotor().params, rot=r), True),
+    (lambda R: RD.SatellitePair(R=R), lambda r: O.Model(O.SATELLITE_PAIR, O.satellite_pair().params, rot=r), True),
+    (lambda R: RD.LieSatellite(R=R), lambda r: O.Model(O.LIE_SATELLITE, [1.0, 1.0, 1.0], rot=r), True),
+]
+
+
+@pytest.mark.parametrize("mk,omk,lie", MODELS)
+def test_dimension_queries_match_oracle_bit_exact(mk, omk, lie):
+    for R, r in ((RD.QuatRotation, O.ROT_QUAT), (RD.MRP, O.ROT_MRP), (RD.RodriguesParam, O.ROT_RP)):
+        m, om = mk(R), omk(r)
+        assert RD.dims(m) == om.dims()
+        assert (RD.state_dim(m), RD.control_dim(m), RD.output_dim(m), RD.errstate_dim(m)) == (om.n, om.m, om.p, om.e)
+        assert RD.jacobian_width(m) == om.e + om.m and RD.input_dim(m) == om.n + om.m
+        if lie:
+            s = RD.LieState(m)
+            assert (s.R.code, s.P) == om.liestate()
+            assert isinstance(RD.statevectortype(m), RD.RotationState)
+            dm = RD.DiscretizedDynamics(m, RD.RK4)       # trait forwarding, src/discretized_dynamics.jl:186-189
+            assert RD.dims(dm) == om.dims() and RD.errstate_dim(dm) == om.e and isinstance(RD.statevectortype(dm), RD.RotationState)
+        else:
+            assert isinstance(RD.statevectortype(m), RD.EuclideanState)
+            with pytest.raises(TypeError):
+                RD.LieState(m)
+        if not lie:
+            break
+
+
+def test_reference_index_tables():
+    # test/liestate.jl:33-48
+    s = RD.LieState(RD.QuatRotation, (3, 2, 3))
+    assert len(s) == 16 and RD.errstate_dim(s) == 14
+    assert RD.vec_inds(s, 1) == range(1, 4) == RD.inds(s, 1)
+    assert RD.rot_inds(s, 1) == range(4, 8) == RD.inds(s, 2)
+    assert RD.vec_inds(s, 2) == range(8, 10) == RD.inds(s, 3)
+    assert RD.rot_inds(s, 2) == range(10, 14) == RD.inds(s, 4)
+    assert RD.vec_inds(s, 3) == range(14, 17) == RD.inds(s, 5)
+    assert RD.QuatState(16, (4, 10)) == s and RD.QuatState(16, [4, 10]) == s
+    assert RD.num_rotations(s) == 2
+    # test/liestate.jl:56-67 (RodriguesParam)
+    s = RD.LieState(RD.RodriguesParam, (3, 2, 3))
+    assert RD.LieState(RD.RodriguesParam, 3, 2, 3) == s
+    assert len(s) == 14 and RD.errstate_dim(s) == 14
+    assert RD.rot_inds(s, 1) == range(4, 7) and RD.vec_inds(s, 2) == range(7, 9)
+    assert RD.rot_inds(s, 2) == range(9, 12) and RD.vec_inds(s, 3) == range(12, 15)
+    # test/liemodel.jl:24-26
+    m = RD.LieSatellite()
+    assert RD.LieState(m) == RD.QuatState(7, (4,)) and RD.state_dim(m) == 7 and RD.errstate_dim(m) == 6
+    # test/rigidbody_test.jl:60,69,88-98 ; test/rigid_body_jacobians.jl:5
+    b = RD.Body()
+    assert RD.dims(b) == (13, 6, 13)
+    assert RD.LieState(b) == RD.LieState(RD.QuatRotation, (3, 6)) and RD.rotation_type(b) is RD.QuatRotation
+    g = RD.gen_inds(b)
+    assert g["q"] == range(4, 8) and g["u"] == range(14, 20) and g["r"] == range(1, 4) and g["v"] == range(8, 11) and g["w"] == range(11, 14)
+    g = RD.gen_inds(RD.Body(RD.MRP))
+    assert g["q"] == range(4, 7) and g["v"] == range(7, 10) and g["u"] == range(13, 19)
+    for R in (RD.QuatRotation, RD.MRP, RD.RodriguesParam):      # test/rigidbody_test.jl:79-85
+        assert RD.state_dim(RD.Body(R)) == 9 + RD.params(R)
+    assert RD.params(RD.QuatRotation) == 4 and RD.params(RD.MRP) == 3 and RD.params(RD.RodriguesParam) == 3
+    x0, u0 = RD.zeros(b)                                         # test/rigidbody_test.jl:72-76
+    assert list(x0[3:7]) == [1, 0, 0, 0] and not u0.any()
+    x, u = RD.rand(b, np.random.default_rng(0))
+    assert abs(np.linalg.norm(x[3:7]) - 1) < 1e-14 and len(x) == 13 and len(u) == 6
+    x, u = RD.rand(RD.SatellitePair(), np.random.default_rng(0))  # examples/satellite_pair.jl:46-48
+    assert abs(np.linalg.norm(x[0:4]) - 1) < 1e-14 and abs(np.linalg.norm(x[7:11]) - 1) < 1e-14
+
+
+def test_default_traits():
+    c = RD.Cartpole()
+    assert RD.default_diffmethod(c) == RD.UserDefined() and RD.default_signature(c) == RD.StaticReturn()
+    assert RD.default_diffmethod(RD.DiscretizedDynamics(c, RD.RK4)) == RD.ForwardAD()   # src/discretized_dynamics.jl:190
+    assert RD.velocity_frame(RD.Quadrotor(bodyframe=True)) == "body" and RD.velocity_frame(RD.Quadrotor()) == "world"
+    with pytest.raises(ValueError):
+        RD.ImplicitFunctionTheorem(RD.ImplicitFunctionTheorem(RD.ForwardAD()))
+    assert RD.functioninputs(c) == RD.StateControl()
+
+
+def test_knotpoint_semantics():
+    # test/knotpoints.jl: data views, terminal control = zeros
+    x, u = np.arange(1.0, 5.0), np.array([7.0])
+    z = RD.KnotPoint(x, u, 0.5, 0.1)
+    assert RD.dims(z) == (4, 1) and len(z) == 5 and RD.state_dim(z) == 4 and RD.control_dim(z) == 1
+    assert list(RD.state(z)) == [1, 2, 3, 4] and list(RD.control(z)) == [7]
+    assert RD.time(z) == 0.5 and RD.timestep(z) == 0.1 and not RD.is_terminal(z)
+    RD.state(z)[0] = 9.0                       # state(z) is a view (src/knotpoint.jl:48)
+    assert z[0] == 9.0
+    zt = RD.KnotPoint(4, 1, z.z.copy(), 1.0, 0.0)
+    assert RD.is_terminal(zt) and list(RD.control(zt)) == [0.0] and zt.z[4] == 7.0     # src/knotpoint.jl:67,123
+    z2 = RD.StaticKnotPoint(z, np.zeros(5))     # src/knotpoint.jl:225-227
+    assert z2.t == z.t and z2.dt == z.dt and not z2.z.any()
+    with pytest.raises(AssertionError):
+        RD.KnotPoint(3, 1, np.zeros(5), 0.0, 0.1)
+    with pytest.raises(TypeError):
+        RD.KnotPoint(x, u, 0.1)                 # v0.3 3-arg constructor does not exist in v0.4.8
+    RD.setstate_(z, np.zeros(4)); RD.setcontrol_(z, [2.0]); RD.settime_(z, 3.0); RD.settimestep_(z, 0.0)
+    assert not RD.state(z).any() and z.z[4] == 2.0 and z.t == 3.0 and RD.is_terminal(z)
+
+
+def test_packed_trajectory_time_grids():
+    # src/trajectories.jl:92-109, 355-400 ; test/trajectories.jl
+    N, n, m = 11, 4, 2
+    X, U = np.random.default_rng(0).random((N, n)), np.random.default_rng(1).random((N - 1, m))
+    Z = RD.PackedTrajectory.from_states_controls(X, U, dt=0.1)
+    assert len(Z) == N and RD.dims(Z) == ([n] * N, [m] * N, N)
+    np.testing.assert_allclose(RD.gettimes(Z), np.arange(N) * 0.1)
+    assert Z.dt[-1] == 0.0 and np.allclose(Z.dt[:-1], 0.1) and RD.is_terminal(Z[N - 1]) and not RD.has_terminal_control(Z)
+    assert not RD.controls(Z)[-1].any()
+    np.testing.assert_array_equal(RD.states(Z), X)
+    Z2 = RD.PackedTrajectory.from_states_controls(X, np.vstack([U, U[-1:]]), tf=2.0)
+    assert Z2.t[-1] == 2.0 and np.allclose(Z2.dt[:-1], 0.2) and np.isinf(Z2.dt[-1]) and RD.has_terminal_control(Z2)
+    z3 = Z[3]
+    z3.z[0] = 42.0                               # Z[k] is a view into the packed data
+    assert Z.data[3, 0] == 42.0 and z3.t == pytest.approx(0.3)
+    with pytest.raises(ValueError):
+        RD._gettimeinfo(N=5)
+    np.testing.assert_allclose(RD._gettimeinfo(dt=[0.1, 0.2, 0.3]), [0, 0.1, 0.3, 0.6])
+    with pytest.raises(ValueError):
+        RD.PackedTrajectory(4, 2, np.zeros((5, 7)), 0.0, 0.1)
+
+
+def test_layout_checks_and_dynamics_jacobian():
+    m = RD.Cartpole()
+    J = RD.alloc_jacobians(m, 3)
+    assert J.shape == (3, 4, 5) and J.base.shape == (3, 5, 4) and J.base.flags.c_contiguous
+    D = RD.DynamicsJacobian(m)                    # test/jacobian_test.jl
+    assert D.shape == (4, 5) and D.A.shape == (4, 4) and D.B.shape == (4, 1) and D.data.flags.f_contiguous
+    D.A[1, 2] = 5.0
+    assert D[1, 2] == 5.0 and RD.get_A(D) is D.A and RD.get_B(D) is D.B
+    D2 = RD.DynamicsJacobian(np.arange(20.0).reshape(4, 5))
+    assert D2.B[0, 0] == 4.0
+
+
+def _gloo_worker(rank, world, port, N, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "robotdynamics.jl_amd"))
+    sys.path.insert(0, ROOT)
+    from rdhip import parallel as P
+    from oracle import rd_oracle as O2
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    Z = rng.random((N, 5))
+    lo, hi = P.shard_range(N, rank, world)
+    # the per-rank kernel is stood in for by the oracle here (no GPU in this test); what is under test is the
+    # sharding + exchange logic of rdhip.parallel
+    Jl, _ = O2.cartpole().jacobian(O2.RK4, O2.FORWARD_AD, Z[lo:hi], 0.0, 0.1) if hi > lo else (np.zeros((0, 4, 5)), None)
+    local = torch.as_tensor(np.ascontiguousarray(Jl))
+    full = P.gather_stacked(local, N, "all")
+    root = P.gather_stacked(local, N, "root")
+    none = P.gather_stacked(local, N, "none")
+    ref, _ = O2.cartpole().jacobian(O2.RK4, O2.FORWARD_AD, Z, 0.0, 0.1)
+    ok = bool(np.array_equal(full.numpy(), ref)) and none is local
+    ok = ok and ((root is None) if rank != 0 else bool(np.array_equal(root.numpy(), ref)))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [10, 7])
+def test_world_size_2_sharding_and_gather_gloo(N):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + N) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, N, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_ranges_cover_everything():
+    from rdhip import parallel as P
+    for N in (0, 1, 7, 64, 65536, 262144 + 3):
+        for world in (1, 2, 4, 8):
+            spans = [P.shard_range(N, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == N
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert sum(P.shard_sizes(N, world)) == N
