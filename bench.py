@@ -51,20 +51,20 @@ def synthetic_inputs(N, seed):
     return Z, np.arange(N) * 0.1, np.full(N, 0.1)
 
 
-def cpu_baseline(Zn, t, dt, budget_s=12.0):
-    """The CPU oracle (a C++ port of the reference math, OpenMP over all host cores) on a bounded sample of the same
-    workload.  Reported beside the GPU figure; it is the checker being timed, never part of the product path."""
+def cpu_baseline(Zn, t, dt):
+    """The CPU oracle (a C++ port of the reference math: forward-mode duals through the RK4 step, like
+    ForwardDiff.jacobian) built -O3 -march=native on this host, on a bounded sample of the same workload: all host
+    cores (OpenMP) and one core (the reference's own per-knot loop is single-threaded).  It is the checker being timed,
+    never part of the product path."""
     from oracle import rd_oracle as O
     om = O.satellite()
-    n_s = 16384
-    om.jacobian(O.RK4, O.FORWARD_AD, Zn[:n_s], t[:n_s], dt[:n_s])   # warm
-    done, t0 = 0, _time.perf_counter()
-    while _time.perf_counter() - t0 < budget_s:
-        om.jacobian(O.RK4, O.FORWARD_AD, Zn[:n_s], t[:n_s], dt[:n_s])
-        done += n_s
-    el = _time.perf_counter() - t0
-    return {"value": done / el, "unit": "knot-point Jacobians/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{done} knot points ({done // n_s} x {n_s}) of the same Satellite RK4 ForwardAD workload in {el:.1f} s, OpenMP over {O.num_threads()} threads"}
+    cores = os.cpu_count() or 1
+    v_all, n_all = O.timed_jacobian_throughput(om, O.RK4, Zn, t, dt, cores, 8.0)
+    v_one, n_one = O.timed_jacobian_throughput(om, O.RK4, Zn[:8192], t[:8192], dt[:8192], 1, 4.0)
+    return {"value": v_all, "unit": "knot-point Jacobians/s", "cores": cores, "kind": "port",
+            "sample": f"{n_all} knot points of the same Satellite RK4 ForwardAD workload on {cores} OpenMP threads (8 s); "
+                      f"single thread: {v_one:.0f}/s over {n_one} knot points (4 s)",
+            "single_thread_value": v_one}
 
 
 def main():

@@ -31,6 +31,44 @@ def build(force=False):
     return _LIB_PATH
 
 
+_FAST_PATH = os.path.join(_HERE, "_build", "librd_oracle_fast.so")
+
+
+def timed_jacobian_throughput(model, rule, Z, t, dt, threads, budget_s):
+    """CPU-baseline helper for bench.py: knot-point Jacobians/s of the host-tuned build of this same oracle
+    (-O3 -march=native, built on the machine it runs on), C entry point called directly on preallocated buffers."""
+    import hashlib
+    import time
+    # -march=native: (re)build when the binary is missing, older than the source, or was built on a different CPU
+    src = os.path.join(_HERE, "rd_oracle.cpp")
+    try:
+        cpu = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        cpu = []
+    stamp = hashlib.sha1("".join(cpu).encode()).hexdigest()
+    stamp_file = os.path.join(_HERE, "_build", "fast.stamp")
+    fresh = (os.path.exists(_FAST_PATH) and os.path.getmtime(_FAST_PATH) >= os.path.getmtime(src)
+             and os.path.exists(stamp_file) and open(stamp_file).read() == stamp)
+    if not fresh:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/librd_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        open(stamp_file, "w").write(stamp)
+    L = C.CDLL(_FAST_PATH)
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    N = Z.shape[0]
+    t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (N,)))
+    dt = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, dtype=np.float64), (N,)))
+    J = np.empty((N, model.n + model.m, model.n))
+    Y = np.empty((N, model.n))
+    L.oracle_set_num_threads(int(threads))
+    call = lambda: L.oracle_jacobian(model._buf, int(rule), FORWARD_AD, STATIC_RETURN, N, _dp(Z), _dp(t), _dp(dt), _dp(J), _dp(Y))
+    call()
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        call()
+        done += N
+    return done / (time.perf_counter() - t0), done
+
+
 _lib = None
 
 

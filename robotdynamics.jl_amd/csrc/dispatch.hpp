@@ -1,6 +1,7 @@
 // dispatch.hpp -- run-time (rule, diff, dtype) -> kernel template instantiation.
 #pragma once
 #include "common.hpp"
+#include <cstdint>
 #include "kernels.hpp"
 
 namespace rd {
@@ -8,7 +9,7 @@ namespace rd {
 inline int hip_status(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_ERR_HIP; }
 
 // which (model, rule) pairs get the compile-time-column ForwardAD kernel (big code, structural sparsity folded)
-template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; static constexpr int KW = 1; };
+template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; };
 
 template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
@@ -24,26 +25,64 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }
+// persistent grid for the tile kernels: as many workgroups as fit on the chip at once (LDS-limited), never more than tiles
+inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
+    const int by_lds = (int)(160 * 1024 / lds_bytes);
+    const int by_waves = 2048 / threads;
+    int per_cu = by_lds < by_waves ? by_lds : by_waves;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const long long g = 256LL * per_cu;
+    return (unsigned)(ntiles < g ? ntiles : g);
+}
+
+template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = JacLds<Fn, T, Plan>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return RDHIP_ERR_HIP;
+    const long long ntiles = (a.N + TILE - 1) / TILE;
+    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    return hip_status(hipGetLastError());
+}
+
+template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return RDHIP_ERR_HIP;
+    const long long ntiles = (a.N + TILE - 1) / TILE;
+    constexpr int threads = (Plan::NG + NC) * TILE;
+    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    return hip_status(hipGetLastError());
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const LaunchArgs& a) {
     using Fn = Fun<Mdl, RULE>;
     using T = typename Fn::T;
     constexpr int NZ = Fn::NX + Fn::NU;
-    constexpr int NG = NZ >= 4 ? 4 : NZ;
+    using DefPlan = ContiguousPlan<NZ, (NZ >= 4 ? 4 : NZ)>;     // compact kernels: 4 waves per tile, one chunk
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
-    const unsigned grid = (unsigned)((a.N + TILE - 1) / TILE);
-    const dim3 block(NG * TILE);
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (UnrollPolicy<Mdl, RULE>::value)
-            hipLaunchKernelGGL((jac_ad_unrolled_kernel<Fn, T, NG, UnrollPolicy<Mdl, RULE>::KW>), dim3(grid), block, 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
-        else
-            hipLaunchKernelGGL((jac_ad_loop_kernel<Fn, T, NG>), dim3(grid), block, 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+        if constexpr (UnrollPolicy<Mdl, RULE>::value) {
+            using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+            constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+            if constexpr (NC > 0) {
+                // compute/copy split-role kernel: needs 16-byte aligned output slabs (a tile is copied as 16-byte units)
+                if (aligned16(a.J) && aligned16(a.Y))
+                    return launch_split_kernel<Fn, T, Plan, NC>(jac_ad_split_kernel<Fn, T, Plan, NC>, fn, a);
+            }
+            return launch_jac_kernel<Fn, T, Plan>(jac_ad_unrolled_kernel<Fn, T, Plan>, fn, a);
+        } else {
+            return launch_jac_kernel<Fn, T, DefPlan>(jac_ad_loop_kernel<Fn, T, DefPlan>, fn, a);
+        }
     } else if (diff == RDHIP_FINITE_DIFF) {
-        hipLaunchKernelGGL((jac_fd_kernel<Fn, T, NG>), dim3(grid), block, 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
-    } else {
-        return RDHIP_ERR_NOT_IMPLEMENTED;
+        return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
     }
-    return hip_status(hipGetLastError());
+    return RDHIP_ERR_NOT_IMPLEMENTED;
 }
 
 template <class Mdl> int dispatch_eval_rule(const Mdl& m, int rule, const LaunchArgs& a) {

@@ -1,11 +1,9 @@
 // kernels.hpp -- the batched kernels.  Data layout in HBM (all column-major, knot point k contiguous):
 //   Z  (n+m) x N      t, dt  N (fp64)      Y  n x N      J  n x (n+m) x N
 // Mapping (gfx950, wave64): one LANE owns one knot point, one WAVEFRONT owns 64 knot points x a group of
-// Jacobian columns, one WORKGROUP (NG waves) owns a tile of 64 knot points.  The z tile is read once, coalesced,
-// into LDS and shared by the NG waves; every finished Jacobian column (n values per lane) is transposed through
-// a per-wave LDS buffer so that the global stores are lane-contiguous.  Everything between load and store lives
-// in registers; there is no inter-workgroup data reuse, so no XCD-aware remap is needed (each 64-knot tile is
-// touched by exactly one workgroup).
+// Jacobian columns, one WORKGROUP (NG waves) owns a tile of 64 knot points.  Inputs and outputs of a tile are
+// contiguous slabs of global memory; they are staged through LDS so that every global access is lane-contiguous.
+// Everything between load and store lives in registers.
 #pragma once
 #include "models.hpp"
 
@@ -16,6 +14,11 @@ constexpr int TILE = 64;   // knot points per wave = wave width on gfx950
 template <class T> RD_DEV T sqrt_eps();
 template <> RD_DEV double sqrt_eps<double>() { return 1.4901161193847656e-08; }   // sqrt(eps(Float64))
 template <> RD_DEV float sqrt_eps<float>() { return 3.4526698300124393e-04f; }     // sqrt(eps(Float32))
+
+// dt === 0 (terminal knot point) tested on the BIT PATTERN: the build uses -ffinite-math-only, under which a
+// floating-point compare against a NaN/Inf time step (the reference stores dt = Inf on a last knot point that
+// carries a control, src/trajectories.jl:104) would be undefined.
+RD_DEV bool is_terminal_dt(double h) { return (__double_as_longlong(h) << 1) == 0; }
 
 RD_DEV void wave_sync() {
     // LDS hand-off inside ONE wave: DS ops of a wave execute in order, we only need the compiler to keep them so.
@@ -34,22 +37,6 @@ RD_DEV void read_knot(const T* zs, int lane, bool term, T (&x)[Fn::NX], T (&u)[F
     for (int i = 0; i < Fn::NU; ++i) u[i] = term ? T(0) : zs[lane * NZ + Fn::NX + i];
 }
 
-// transpose one per-lane column (NY values) through the wave's LDS buffer and store it lane-contiguously:
-// element e = kn*NY + i of the tile column goes to dst[kn*stride + i]
-template <int NY, class T>
-RD_DEV void store_column(T* buf, const T (&col)[NY], T* dst, long long stride, int lane, int nk) {
-#pragma unroll
-    for (int i = 0; i < NY; ++i) buf[lane * NY + i] = col[i];
-    wave_sync();
-#pragma unroll
-    for (int it = 0; it < NY; ++it) {
-        const int e = it * TILE + lane;
-        const int kn = e / NY, i = e - kn * NY;
-        if (kn < nk) dst[kn * stride + i] = buf[e];
-    }
-    wave_sync();
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // evaluate: Y[:,k] = fun(z_k)      (dynamics / discrete_dynamics)
 // ------------------------------------------------------------------------------------------------------------
@@ -65,7 +52,7 @@ __global__ void __launch_bounds__(256) eval_kernel(Fn fn, long long N, const T* 
     const int kl = threadIdx.x < nk ? threadIdx.x : nk - 1;
     const T t = (T)tt[k0 + kl], h = (T)dtt[k0 + kl];
     T x[NX], u[NU], y[NY];
-    read_knot<Fn, T>(lds, kl, dtt[k0 + kl] == 0.0, x, u);
+    read_knot<Fn, T>(lds, kl, is_terminal_dt(dtt[k0 + kl]), x, u);
     fn.eval(x, u, t, h, y);
     __syncthreads();
 #pragma unroll
@@ -95,7 +82,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
     for (long long k = 1; k < K; ++k) {
         const double h = dtt[j * K + k - 1];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = (h == 0.0) ? T(0) : Zj[(k - 1) * NZ + NX + i];
+        for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(h) ? T(0) : Zj[(k - 1) * NZ + NX + i];
         fn.eval(x, u, (T)tt[j * K + k - 1], (T)h, y);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x[i] = y[i]; Zj[k * NZ + i] = y[i]; }
@@ -103,151 +90,422 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Jacobians.  Common frame: workgroup = NG waves, wave g owns columns [g*NZ/NG, (g+1)*NZ/NG).
+// Jacobians.  One WORKGROUP (NG waves) owns a tile of 64 knot points at a time and walks tiles persistently;
+// one LANE owns one knot point; the NZ = n+m Jacobian columns are split into NCHUNK contiguous column chunks that
+// are processed one after the other, and inside a chunk every wave owns a compile-time list of columns (Plan).
+//
+// LDS per workgroup:  out[64][RS]  one row per knot point holding the chunk's columns (and, in one chunk, f(z)),
+//                                  RS odd so that the lane stride hits distinct banks;
+//                     z tile 64 x NZ, t[64], dt[64].
+// After a chunk is computed the whole workgroup copies it out: thread u handles element u of the chunk, so one store
+// instruction writes 64 consecutive elements of rows that are (ncol*NY*sizeof(T))-byte contiguous runs of global
+// memory.  Measured on MI355X (profiles/): storing single columns from single waves (104-B runs) ran 2x
+// slower than a streaming fill; whole-workgroup chunk copies run within 15 % of it.  With NCHUNK = 2 the LDS
+// footprint (77 KB for the 13x19 fp64 case) lets two workgroups share a CU, so one computes while the other's
+// stores drain.  The next tile's z/t/dt are prefetched into registers before the last copy-out.
+// No inter-workgroup data reuse exists, so no XCD-aware remap is needed: each tile is touched by exactly one workgroup.
 // ------------------------------------------------------------------------------------------------------------
-template <class Fn, class T, int NG> struct JacFrame {
+
+// Default plan: one chunk, contiguous column ranges per wave, f(z) emitted by wave 0.
+template <int NZ, int NG_> struct ContiguousPlan {
+    static constexpr int NG = NG_, NCHUNK = 1;
+    static constexpr int chunk_begin(int) { return 0; }
+    static constexpr int chunk_end(int) { return NZ; }
+    static constexpr int wave_of(int c) { int g = 0; while (!(c >= g * NZ / NG && c < (g + 1) * NZ / NG)) ++g; return g; }
+    static constexpr int value_chunk = 0, value_wave = 0;
+};
+
+template <class Fn, class T, class Plan> struct JacLds {
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
+    static constexpr int run(int ch) { return (Plan::chunk_end(ch) - Plan::chunk_begin(ch)) * NY + (ch == Plan::value_chunk ? NY : 0); }
+    static constexpr int max_run() { int m = 0; for (int ch = 0; ch < Plan::NCHUNK; ++ch) m = run(ch) > m ? run(ch) : m; return m; }
+    static constexpr int RS = max_run() | 1;     // odd row stride -> conflict-free lane-strided LDS writes
+    static constexpr size_t OUT_ELEMS = (size_t)TILE * RS, Z_ELEMS = (size_t)TILE * NZ;
+    static constexpr size_t BYTES = (OUT_ELEMS + Z_ELEMS) * sizeof(T) + 2 * TILE * sizeof(double);
+};
+
+template <class Fn, class T> struct JacFrame {
     static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY;
     T x[NX], u[NU];
     T t, h;
     bool term;
-    int lane, g, nk;
-    T* buf;          // this wave's LDS staging buffer (TILE*NY)
-    T* Jt;           // J + k0*NY*NZ
-    T* Yt;           // Y + k0*NY or nullptr
-    RD_DEV void put_column(int c, const T (&col)[NY]) { store_column<NY, T>(buf, col, Jt + (long long)c * NY, (long long)NY * NZ, lane, nk); }
-    RD_DEV void put_value(const T (&y)[NY]) { if (Yt) store_column<NY, T>(buf, y, Yt, (long long)NY, lane, nk); }
+    int g;
+    T* row;          // this lane's row of the LDS output tile
+    T* yrow;         // this lane's row of a separate LDS f(z) tile, or nullptr: f(z) goes behind the chunk's columns
+    bool want_y;
+    // position inside the row: columns of the current chunk first
+    RD_DEV void put_at(int pos, const T (&col)[NY]) {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) row[pos * NY + i] = col[i];
+    }
+    RD_DEV void put_value(int pos_after_columns, const T (&y)[NY]) {
+        if (yrow) {
+#pragma unroll
+            for (int i = 0; i < NY; ++i) yrow[i] = y[i];
+        } else put_at(pos_after_columns, y);
+    }
 };
 
-#define RD_JAC_PROLOGUE(NGv)                                                                                  \
-    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY;                                        \
-    __shared__ T zs[TILE * NZ];                                                                               \
-    __shared__ T stage[NGv * TILE * NY];                                                                      \
-    JacFrame<Fn, T, NGv> fr;                                                                                  \
-    fr.lane = threadIdx.x & 63; fr.g = threadIdx.x >> 6;                                                      \
-    const long long k0 = (long long)blockIdx.x * TILE;                                                        \
-    fr.nk = (int)((N - k0) < TILE ? (N - k0) : TILE);                                                         \
-    for (int e = threadIdx.x; e < fr.nk * NZ; e += NGv * TILE) zs[e] = Z[k0 * NZ + e];                        \
-    __syncthreads();                                                                                          \
-    const int kl = fr.lane < fr.nk ? fr.lane : fr.nk - 1;                                                     \
-    const double hd = dtt[k0 + kl];                                                                           \
-    fr.t = (T)tt[k0 + kl]; fr.h = (T)hd; fr.term = (hd == 0.0);                                               \
-    read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);                                                            \
-    fr.buf = stage + fr.g * TILE * NY;                                                                        \
-    fr.Jt = J + k0 * NY * NZ; fr.Yt = Y ? Y + k0 * NY : nullptr;
+// 16-byte lane-contiguous copy of one row (LDS -> global) by one wave; rows are only sizeof(T)-aligned on both sides
+template <class T> struct Vec16;
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); static constexpr int V = 2; };
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); static constexpr int V = 4; };
+template <class T> RD_DEV void row_copy(const T* __restrict__ src, T* __restrict__ dst, int len, int lane) {
+    using V = typename Vec16<T>::type;
+    constexpr int NV = Vec16<T>::V;
+    const int nu = len / NV;
+    for (int u = lane; u < nu; u += TILE) reinterpret_cast<V*>(dst)[u] = reinterpret_cast<const V*>(src)[u];
+    const int e = nu * NV + lane;
+    if (e < len) dst[e] = src[e];
+}
 
-// ---- ForwardAD, compile-time columns: KW tangent directions per pass, seeds are constants --------------------
-template <class Fn, class T, int NG, int KW, int C, int C1, bool FIRST> struct AdCols {   // FIRST: this pass also emits f(z)
-    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T, NG>& fr) {
+// Body::template run<CH>(fn, fr) computes the columns of chunk CH that belong to wave fr.g and `put`s them.
+//
+// VMEM ordering rule that shapes the loop (gfx950 has ONE counter, vmcnt, for loads and stores, and they may retire
+// out of order relative to each other, so waiting for any load also waits for every older store): the only global
+// loads of an iteration -- the prefetch of the NEXT tile's z/t/dt -- are issued at the top of the iteration and
+// consumed right before the copy-out; the copy-out stores are the last VMEM operations of the iteration and nobody
+// waits for them until the next iteration's prefetch is consumed, i.e. they drain behind a whole compute phase.
+template <class Fn, class T, class Plan, class Body>
+RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                          T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, NT = NG * TILE;
+    using L = JacLds<Fn, T, Plan>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* out = reinterpret_cast<T*>(smem);
+    T* zs = out + L::OUT_ELEMS;                                          // z tile
+    double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);             // t[64], dt[64]
+    const int lane = threadIdx.x & 63;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    constexpr int ZPT = (TILE * NZ + NT - 1) / NT;   // z elements each thread stages per tile
+
+    JacFrame<Fn, T> fr;
+    fr.g = threadIdx.x >> 6;
+    fr.row = out + lane * L::RS;
+    fr.yrow = nullptr;
+    fr.want_y = (Y != nullptr);
+
+    long long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {   // first tile: stage z, t, dt
+        const long long k0 = tile * TILE;
+        const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+        for (int e = threadIdx.x; e < nk * NZ; e += NT) zs[e] = Z[k0 * NZ + e];
+        if (threadIdx.x < nk) ts[threadIdx.x] = tt[k0 + threadIdx.x];
+        else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long long k0 = tile * TILE;
+        const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+        // ---- issue the prefetch of the next tile's inputs (registers; consumed after the compute phase)
+        const long long nxt = tile + gridDim.x;
+        const long long k1 = nxt * TILE;
+        const int nk1 = (nxt < ntiles) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+        // The loads are UNCONDITIONAL (out-of-range lanes re-read element 0): a load inside an exec-masked branch leaves a
+        // "maybe pending" load at the loop back-edge, and the compiler then drains vmcnt(0) -- i.e. every store of the
+        // previous copy-out -- at the top of the loop.
+        T zpre[ZPT]; double tpre;
+#pragma unroll
+        for (int r = 0; r < ZPT; ++r) { const int e = r * NT + threadIdx.x; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
+        {
+            const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+            const int idx = threadIdx.x & (TILE - 1);
+            tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads up here
+        // ---- this tile
+        const int kl = lane < nk ? lane : nk - 1;        // lanes past a ragged end recompute the last knot point (never copied out)
+        const double hd = ts[TILE + kl];
+        fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
+        read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
+        T* Jt = J + k0 * (NY * NZ);
+        T* Yt = Y ? Y + k0 * NY : nullptr;
+#pragma unroll
+        for (int ch = 0; ch < Plan::NCHUNK; ++ch) {
+            switch (ch) {   // compile-time chunk index for the body
+                case 0: Body::template run<0>(fn, fr); break;
+                case 1: if constexpr (Plan::NCHUNK > 1) Body::template run<1>(fn, fr); break;
+                case 2: if constexpr (Plan::NCHUNK > 2) Body::template run<2>(fn, fr); break;
+                default: if constexpr (Plan::NCHUNK > 3) Body::template run<3>(fn, fr); break;
+            }
+            __syncthreads();                              // chunk complete in LDS
+            if (ch == 0) {                                // consume the prefetch BEFORE any store of this iteration is issued
+                __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the prefetch and the previous tile's stores (which had a whole compute phase)
+                // (every wave finished reading zs/ts before the barrier above, so the single buffer can be refilled)
+#pragma unroll
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NT + threadIdx.x; if (e < TILE * NZ) zs[e] = zpre[r]; }
+                if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // copy-out: wave g takes rows g, g+NG, ...; a row is one (two with f(z)) contiguous run of global memory
+            const int c0 = Plan::chunk_begin(ch), jr = (Plan::chunk_end(ch) - c0) * NY;
+            const bool has_y = (ch == Plan::value_chunk) && Yt;
+            for (int kn = fr.g; kn < nk; kn += NG) {
+                const T* src = out + kn * L::RS;
+                row_copy<T>(src, Jt + kn * (NY * NZ) + c0 * NY, jr, lane);
+                if (has_y) row_copy<T>(src + jr, Yt + kn * NY, NY, lane);
+            }
+            __syncthreads();                              // LDS output tile free again; next inputs visible
+        }
+    }
+}
+
+// ---- ForwardAD, compile-time columns: one tangent direction per pass, the seed is a constant -----------------------
+// emits f(z) together with the first column it handles when this (chunk, wave) is the plan's value slot
+template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDING> struct AdCols {
+    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
         constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY;
-        constexpr int W = (C1 - C) < KW ? (C1 - C) : KW;
-        if constexpr (W > 0) {
-            using D = Dual<T, W>;
-            D xd[NX], ud[NU], yd[NY];
+        constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
+        if constexpr (C < C1) {
+            if constexpr (Plan::wave_of(C) == G) {
+                using D = Dual<T, 1>;
+                D xd[NX], ud[NU], yd[NY];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                xd[i].v = fr.x[i];
+                for (int i = 0; i < NX; ++i) { xd[i].v = fr.x[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
 #pragma unroll
-                for (int c = 0; c < W; ++c) xd[i].d[c] = (i == C + c) ? T(1) : T(0);
-            }
+                for (int i = 0; i < NU; ++i) { ud[i].v = fr.u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
+#if defined(RD_ABLATE) && RD_ABLATE == 2   // tuning only: no arithmetic, same store pattern
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                ud[i].v = fr.u[i];
-#pragma unroll
-                for (int c = 0; c < W; ++c) ud[i].d[c] = (NX + i == C + c) ? T(1) : T(0);
-            }
-            fn.eval(xd, ud, fr.t, fr.h, yd);
-            if constexpr (FIRST) {
-                T yv[NY];
-#pragma unroll
-                for (int i = 0; i < NY; ++i) yv[i] = yd[i].v;
-                fr.put_value(yv);
-            }
-#pragma unroll
-            for (int c = 0; c < W; ++c) {
+                for (int i = 0; i < NY; ++i) { yd[i].v = fr.x[i]; yd[i].d[0] = fr.x[i] + T(C); }
+#else
+                fn.eval(xd, ud, fr.t, fr.h, yd);
+#endif
                 T col[NY];
-                // control columns of a terminal knot point are zero (`!is_terminal(z) * u`, src/knotpoint.jl:67)
-                const T sc = (C + c >= NX && fr.term) ? T(0) : T(1);
+                if constexpr (VALUE_PENDING) {
+                    if (fr.want_y) {
 #pragma unroll
-                for (int i = 0; i < NY; ++i) col[i] = yd[i].d[c] * sc;
-                fr.put_column(C + c, col);
+                        for (int i = 0; i < NY; ++i) col[i] = yd[i].v;
+                        fr.put_value(C1 - C0, col);
+                    }
+                }
+                // control columns of a terminal knot point are zero (`!is_terminal(z) * u`, src/knotpoint.jl:67)
+                const T sc = (C >= NX && fr.term) ? T(0) : T(1);
+#pragma unroll
+                for (int i = 0; i < NY; ++i) col[i] = yd[i].d[0] * sc;
+                fr.put_at(C - C0, col);
+                AdCols<Fn, T, Plan, CH, G, C + 1, false>::run(fn, fr);
+            } else {
+                AdCols<Fn, T, Plan, CH, G, C + 1, VALUE_PENDING>::run(fn, fr);
             }
-            AdCols<Fn, T, NG, KW, C + W, C1, false>::run(fn, fr);
         }
     }
 };
-template <class Fn, class T, int NG, int KW, int G> struct AdGroups {
-    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T, NG>& fr) {
-        constexpr int NZ = Fn::NX + Fn::NU;
-        if constexpr (G < NG) {
-            if (fr.g == G) AdCols<Fn, T, NG, KW, G * NZ / NG, (G + 1) * NZ / NG, G == 0>::run(fn, fr);
-            else AdGroups<Fn, T, NG, KW, G + 1>::run(fn, fr);
+template <class Fn, class T, class Plan> struct AdUnrolledBody {
+    template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr) {
+        if constexpr (G < Plan::NG) {
+            if (fr.g == G) AdCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr);
+            else waves<CH, G + 1>(fn, fr);
         }
     }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) { waves<CH, 0>(fn, fr); }
 };
-template <class Fn, class T, int NG, int KW>
-__global__ void __launch_bounds__(NG * TILE) jac_ad_unrolled_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                    const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    RD_JAC_PROLOGUE(NG)
-    AdGroups<Fn, T, NG, KW, 0>::run(fn, fr);
+template <class Fn, class T, class Plan>
+__global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_unrolled_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                         const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_tile_loop<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+}
+
+// ---- split-role variant of the tile loop --------------------------------------------------------------------------
+// A copy-out that is issued by the same waves that compute cannot overlap with compute: when HBM is the bottleneck the
+// store instructions block AT ISSUE, so a workgroup whose LDS tile fills a whole CU alternates "all compute" / "all
+// store" phases (measured: total = store time + compute time).  Here a workgroup has NG COMPUTE waves and NC COPY
+// waves.  Per tile:   compute waves fill the LDS tile            | copy waves issue the previous tile's stores from VGPRs
+//                     -------- barrier A (tile complete) --------
+//                     compute waves refill z/t/dt (prefetched)   | copy waves pull the whole tile LDS -> VGPRs (16 B/lane)
+//                     -------- barrier B (LDS free) -------------
+// so the HBM write stream of tile t runs under the arithmetic of tile t+1.  Requires 16-byte aligned J and Y (the
+// copy is a linear 16-byte sweep over the tile, which is one contiguous slab of global memory).
+template <class Fn, class T, class Plan, int NC> struct SplitLds {
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
+    static constexpr size_t J_ELEMS = (size_t)TILE * NY * NZ, Y_ELEMS = (size_t)TILE * NY, Z_ELEMS = (size_t)TILE * NZ;
+    static constexpr size_t J_BYTES = (J_ELEMS * sizeof(T) + 15) / 16 * 16, Y_BYTES = (Y_ELEMS * sizeof(T) + 15) / 16 * 16;
+    static constexpr size_t BYTES = J_BYTES + Y_BYTES + Z_ELEMS * sizeof(T) + 2 * TILE * sizeof(double);
+    static constexpr int JU = (int)(J_ELEMS * sizeof(T) / 16), YU = (int)(Y_ELEMS * sizeof(T) / 16);   // whole 16-B units per full tile
+    static constexpr int JPL = (JU + NC * TILE - 1) / (NC * TILE), YPL = (YU + NC * TILE - 1) / (NC * TILE);   // units per copy lane
+    static_assert(J_ELEMS * sizeof(T) % 16 == 0 && Y_ELEMS * sizeof(T) % 16 == 0, "tile slabs must be multiples of 16 bytes");
+};
+
+template <class Fn, class T, class Plan, int NC, class Body>
+RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                           T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, NTC = NG * TILE;
+    static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
+    using L = SplitLds<Fn, T, Plan, NC>;
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* jt = reinterpret_cast<T*>(smem);
+    T* yt = reinterpret_cast<T*>(smem + L::J_BYTES);
+    T* zs = reinterpret_cast<T*>(smem + L::J_BYTES + L::Y_BYTES);
+    double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    long long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    if (wave < NG) {
+        // =========================== compute waves ===========================
+        constexpr int ZPT = (TILE * NZ + NTC - 1) / NTC;
+        JacFrame<Fn, T> fr;
+        fr.g = wave;
+        fr.row = jt + lane * (NY * NZ);
+        fr.yrow = yt + lane * NY;
+        fr.want_y = (Y != nullptr);
+        {
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            for (int e = threadIdx.x; e < nk * NZ; e += NTC) zs[e] = Z[k0 * NZ + e];
+            if (threadIdx.x < nk) ts[threadIdx.x] = tt[k0 + threadIdx.x];
+            else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
+        }
+        __syncthreads();                                   // barrier 0
+        for (; tile < ntiles; tile += gridDim.x) {
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            const long long nxt = tile + gridDim.x;
+            const long long k1 = nxt * TILE;
+            const int nk1 = (nxt < ntiles) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+            T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
+            {
+                const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+                const int idx = threadIdx.x & (TILE - 1);
+                tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int kl = lane < nk ? lane : nk - 1;
+            const double hd = ts[TILE + kl];
+            fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
+            read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
+            Body::template run<0>(fn, fr);
+            __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TILE * NZ) zs[e] = zpre[r]; }
+            if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
+            __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
+        }
+    } else {
+        // =========================== copy waves ==============================
+        const int ct = threadIdx.x - NG * TILE;            // 0 .. NC*64-1
+        const V4* jsrc = reinterpret_cast<const V4*>(jt);
+        const V4* ysrc = reinterpret_cast<const V4*>(yt);
+        __syncthreads();                                   // barrier 0
+        for (; tile < ntiles; tile += gridDim.x) {
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            V4 jv[L::JPL], yv[L::YPL];
+            __syncthreads();                               // barrier A
+#pragma unroll
+            for (int r = 0; r < L::JPL; ++r) { const int u = r * (NC * TILE) + ct; jv[r] = jsrc[u < L::JU ? u : 0]; }
+#pragma unroll
+            for (int r = 0; r < L::YPL; ++r) { const int u = r * (NC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the tile is in registers
+            __syncthreads();                               // barrier B
+            // number of valid bytes of a ragged last tile is nk*NY*NZ*sizeof(T), a multiple of sizeof(T) only
+            const int jbytes = nk * NY * NZ * (int)sizeof(T), ybytes = nk * NY * (int)sizeof(T);
+            V4* jdst = reinterpret_cast<V4*>(J + k0 * (NY * NZ));
+#pragma unroll
+            for (int r = 0; r < L::JPL; ++r) {
+                const int u = r * (NC * TILE) + ct;
+                if (u * 16 + 16 <= jbytes) jdst[u] = jv[r];
+                else if (u * 16 < jbytes) {                // partial last unit of a ragged tile: element-wise
+                    const T* pv = reinterpret_cast<const T*>(&jv[r]);
+                    T* pd = reinterpret_cast<T*>(jdst + u);
+                    for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= jbytes) pd[q] = pv[q];
+                }
+            }
+            if (Y) {
+                V4* ydst = reinterpret_cast<V4*>(Y + k0 * NY);
+#pragma unroll
+                for (int r = 0; r < L::YPL; ++r) {
+                    const int u = r * (NC * TILE) + ct;
+                    if (u * 16 + 16 <= ybytes) ydst[u] = yv[r];
+                    else if (u * 16 < ybytes) {
+                        const T* pv = reinterpret_cast<const T*>(&yv[r]);
+                        T* pd = reinterpret_cast<T*>(ydst + u);
+                        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= ybytes) pd[q] = pv[q];
+                    }
+                }
+            }
+        }
+    }
+}
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                               const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
 // ---- ForwardAD, run-time column loop (compact code for the long tail of model x rule combinations) -----------
-template <class Fn, class T, int NG>
-__global__ void __launch_bounds__(NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    RD_JAC_PROLOGUE(NG)
-    using D = Dual<T, 1>;
-    const int c0 = fr.g * NZ / NG, c1 = (fr.g + 1) * NZ / NG;
-    for (int c = c0; c < c1; ++c) {
-        D xd[NX], ud[NU], yd[NY];
+template <class Fn, class T, class Plan> struct AdLoopBody {
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG;
+        static_assert(Plan::NCHUNK == 1, "run-time column loops use the single-chunk plan");
+        using D = Dual<T, 1>;
+        const int c0 = fr.g * NZ / NG, c1 = (fr.g + 1) * NZ / NG;
+        for (int c = c0; c < c1; ++c) {
+            D xd[NX], ud[NU], yd[NY];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { xd[i].v = fr.x[i]; xd[i].d[0] = (i == c) ? T(1) : T(0); }
+            for (int i = 0; i < NX; ++i) { xd[i].v = fr.x[i]; xd[i].d[0] = (i == c) ? T(1) : T(0); }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { ud[i].v = fr.u[i]; ud[i].d[0] = (NX + i == c) ? T(1) : T(0); }
-        fn.eval(xd, ud, fr.t, fr.h, yd);
-        T col[NY];
-        if (c == 0) {
+            for (int i = 0; i < NU; ++i) { ud[i].v = fr.u[i]; ud[i].d[0] = (NX + i == c) ? T(1) : T(0); }
+            fn.eval(xd, ud, fr.t, fr.h, yd);
+            T col[NY];
+            if (c == 0 && fr.want_y) {
 #pragma unroll
-            for (int i = 0; i < NY; ++i) col[i] = yd[i].v;
-            fr.put_value(col);
+                for (int i = 0; i < NY; ++i) col[i] = yd[i].v;
+                fr.put_value(NZ, col);
+            }
+            const T sc = (c >= NX && fr.term) ? T(0) : T(1);
+#pragma unroll
+            for (int i = 0; i < NY; ++i) col[i] = yd[i].d[0] * sc;
+            fr.put_at(c, col);
         }
-        const T sc = (c >= NX && fr.term) ? T(0) : T(1);
-#pragma unroll
-        for (int i = 0; i < NY; ++i) col[i] = yd[i].d[0] * sc;
-        fr.put_column(c, col);
     }
+};
+template <class Fn, class T, class Plan>
+__global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                     const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_tile_loop<Fn, T, Plan, AdLoopBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
-template <class Fn, class T, int NG>
-__global__ void __launch_bounds__(NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                           const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    RD_JAC_PROLOGUE(NG)
-    T f0[NY];
-    fn.eval(fr.x, fr.u, fr.t, fr.h, f0);
-    if (fr.g == 0) fr.put_value(f0);
-    const int c0 = fr.g * NZ / NG, c1 = (fr.g + 1) * NZ / NG;
-    for (int c = c0; c < c1; ++c) {
-        T x1[NX], u1[NU], f1[NY];
-        T zc = T(0);
+template <class Fn, class T, class Plan> struct FdBody {
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG;
+        static_assert(Plan::NCHUNK == 1, "run-time column loops use the single-chunk plan");
+        T f0[NY];
+        fn.eval(fr.x, fr.u, fr.t, fr.h, f0);
+        if (fr.g == 0 && fr.want_y) fr.put_value(NZ, f0);
+        const int c0 = fr.g * NZ / NG, c1 = (fr.g + 1) * NZ / NG;
+        for (int c = c0; c < c1; ++c) {
+            T x1[NX], u1[NU], f1[NY];
+            T zc = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x1[i] = fr.x[i]; if (i == c) zc = fr.x[i]; }
+            for (int i = 0; i < NX; ++i) { x1[i] = fr.x[i]; if (i == c) zc = fr.x[i]; }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { u1[i] = fr.u[i]; if (NX + i == c) zc = fr.u[i]; }
-        const T se = sqrt_eps<T>();
-        const T az = zc < T(0) ? -zc : zc;
-        const T eps = (se * az > se) ? se * az : se;
-        // a terminal knot point evaluates f with u = 0 for every perturbation (control(z) = false * u)
+            for (int i = 0; i < NU; ++i) { u1[i] = fr.u[i]; if (NX + i == c) zc = fr.u[i]; }
+            const T se = sqrt_eps<T>();
+            const T az = zc < T(0) ? -zc : zc;
+            const T eps = (se * az > se) ? se * az : se;
+            // a terminal knot point evaluates f with u = 0 for every perturbation (control(z) = false * u)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) if (i == c) x1[i] = x1[i] + eps;
+            for (int i = 0; i < NX; ++i) if (i == c) x1[i] = x1[i] + eps;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) if (NX + i == c && !fr.term) u1[i] = u1[i] + eps;
-        fn.eval(x1, u1, fr.t, fr.h, f1);
-        T col[NY];
+            for (int i = 0; i < NU; ++i) if (NX + i == c && !fr.term) u1[i] = u1[i] + eps;
+            fn.eval(x1, u1, fr.t, fr.h, f1);
+            T col[NY];
 #pragma unroll
-        for (int i = 0; i < NY; ++i) col[i] = (f1[i] - f0[i]) / eps;
-        fr.put_column(c, col);
+            for (int i = 0; i < NY; ++i) col[i] = (f1[i] - f0[i]) / eps;
+            fr.put_at(c, col);
+        }
     }
+};
+template <class Fn, class T, class Plan>
+__global__ void __launch_bounds__(Plan::NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_tile_loop<Fn, T, Plan, FdBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
 }  // namespace rd

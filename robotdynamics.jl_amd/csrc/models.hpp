@@ -247,30 +247,33 @@ template <class Mdl, int RULE> struct Fun {
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x[i] + k[i] * h;
         } else if constexpr (RULE == RULE_RK3) {
-            S k1[NX], k2[NX], k3[NX], xs[NX];
+            // x + (k1 + 4 k2 + k3)/6 accumulated left to right as the stages finish (same summation order as
+            // the reference expression, src/integration.jl:134); keeps only {k1, acc, k, xs} live.
+            S k1[NX], k[NX], acc[NX], xs[NX];
             m.f(x, u, k1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x[i] + k1[i] * T(0.5); }
-            m.f(xs, u, k2);
+            m.f(xs, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; xs[i] = x[i] - k1[i] + k2[i] * T(2); }
-            m.f(xs, u, k3);
+            for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = k1[i] + k[i] * T(4); xs[i] = x[i] - k1[i] + k[i] * T(2); }
+            m.f(xs, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) y[i] = x[i] + (k1[i] + k2[i] * T(4) + k3[i] * h) * T(1.0 / 6.0);
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + (acc[i] + k[i] * h) * T(1.0 / 6.0);
         } else {
-            S k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
-            m.f(x, u, k1);
+            // x + (k1 + 2 k2 + 2 k3 + k4)/6, accumulated left to right (src/integration.jl:285); live set {acc, k, xs}
+            S k[NX], acc[NX], xs[NX];
+            m.f(x, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x[i] + k1[i] * T(0.5); }
-            m.f(xs, u, k2);
+            for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = k[i]; xs[i] = x[i] + k[i] * T(0.5); }
+            m.f(xs, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; xs[i] = x[i] + k2[i] * T(0.5); }
-            m.f(xs, u, k3);
+            for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + k[i] * T(2); xs[i] = x[i] + k[i] * T(0.5); }
+            m.f(xs, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { k3[i] = k3[i] * h; xs[i] = x[i] + k3[i]; }
-            m.f(xs, u, k4);
+            for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + k[i] * T(2); xs[i] = x[i] + k[i]; }
+            m.f(xs, u, k);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) y[i] = x[i] + (k1[i] + (k2[i] + k3[i]) * T(2) + k4[i] * h) * T(1.0 / 6.0);
+            for (int i = 0; i < NX; ++i) y[i] = x[i] + (acc[i] + k[i] * h) * T(1.0 / 6.0);
         }
     }
 };

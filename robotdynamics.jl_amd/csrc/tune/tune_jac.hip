@@ -1,0 +1,156 @@
+// tune_jac.hip -- developer tool: within-process A/B timing of flagship Jacobian kernel variants
+// (Satellite world-frame, RK4, ForwardAD, fp64, N = 65536).  Build: hipcc ... tune/tune_jac.hip -o tune_jac ; run on the GPU box.
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include "../kernels.hpp"
+
+using namespace rd;
+using Mdl = RigidBody<double, WRENCH_SATELLITE, false>;
+using Fn = Fun<Mdl, RULE_RK4>;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Variant { const char* name; void (*launch)(const Fn&, long long, const double*, const double*, const double*, double*, double*, hipStream_t); };
+
+template <class Plan> void launch_plan(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
+    constexpr size_t lds = JacLds<Fn, double, Plan>::BYTES;
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_unrolled_kernel<Fn, double, Plan>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
+    const long long ntiles = (N + TILE - 1) / TILE;
+    int per_cu = (int)(160 * 1024 / lds); if (per_cu > 2048 / (Plan::NG * TILE)) per_cu = 2048 / (Plan::NG * TILE); if (per_cu < 1) per_cu = 1;
+    const long long g = 256LL * per_cu;
+    hipLaunchKernelGGL((jac_ad_unrolled_kernel<Fn, double, Plan>), dim3((unsigned)(ntiles < g ? ntiles : g)), dim3(Plan::NG * TILE), lds, s, fn, N, Z, t, dt, J, Y);
+}
+
+template <class Plan, int NC> void launch_split(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
+    constexpr size_t lds = SplitLds<Fn, double, Plan, NC>::BYTES;
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_split_kernel<Fn, double, Plan, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
+    const long long ntiles = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL((jac_ad_split_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
+}
+
+// pure streaming-store references: what the HBM write path sustains for the same 136 MB
+__global__ void __launch_bounds__(256) fill_b64(double* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = (double)i;
+}
+__global__ void __launch_bounds__(256) fill_b128(double2* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = make_double2((double)i, 1.0);
+}
+void launch_fill64(const Fn&, long long N, const double*, const double*, const double*, double* J, double*, hipStream_t s) {
+    hipLaunchKernelGGL(fill_b64, dim3(2048), dim3(256), 0, s, J, N * 247);
+}
+void launch_fill128(const Fn&, long long N, const double*, const double*, const double*, double* J, double*, hipStream_t s) {
+    hipLaunchKernelGGL(fill_b128, dim3(2048), dim3(256), 0, s, (double2*)J, N * 247 / 2);
+}
+void launch_fill128_big(const Fn&, long long N, const double*, const double*, const double*, double* J, double*, hipStream_t s) {
+    hipLaunchKernelGGL(fill_b128, dim3((unsigned)(N * 247 / 2 / 256)), dim3(256), 0, s, (double2*)J, N * 247 / 2);
+}
+
+// experiment: stage the whole 64-knot J tile (64 x 1976 B, contiguous in global memory) in LDS, then copy it out
+// linearly with 16-B stores (full 128-B lines per instruction).  Persistent grid, NW waves per block.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) tile_copy_kernel(long long ntiles, const double* __restrict__ Z, double* __restrict__ J) {
+    extern __shared__ double tile[];   // 64*247 doubles
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const double zz = Z[tl * 64 * 19 + lane * 19];
+        // every wave writes its share of columns for its lane's knot: element (knot=lane, c, i) at lane*247 + c*13 + i
+        for (int c = w; c < 19; c += NW)
+#pragma unroll
+            for (int i = 0; i < 13; ++i) tile[lane * 247 + c * 13 + i] = zz + (double)(c * 13 + i);
+        __syncthreads();
+        double2* dst = (double2*)(J + tl * 64 * 247);
+        const double2* src = (const double2*)tile;
+        for (int u = threadIdx.x; u < 64 * 247 / 2; u += NW * 64) dst[u] = src[u];
+        __syncthreads();
+    }
+}
+// same, but the copy-out goes chunk by chunk over groups of CC columns (runs of CC*104 B per knot, 8-B stores):
+// isolates the cost of partial-line writes at run boundaries.
+template <int NW, int CC>
+__global__ void __launch_bounds__(NW * 64) tile_copy_chunks_kernel(long long ntiles, const double* __restrict__ Z, double* __restrict__ J) {
+    extern __shared__ double tile[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const double zz = Z[tl * 64 * 19 + lane * 19];
+        for (int c = w; c < 19; c += NW)
+#pragma unroll
+            for (int i = 0; i < 13; ++i) tile[lane * 247 + c * 13 + i] = zz + (double)(c * 13 + i);
+        __syncthreads();
+        double* dst = J + tl * 64 * 247;
+        for (int c0 = 0; c0 < 19; c0 += CC) {
+            const int ncol = (19 - c0) < CC ? (19 - c0) : CC;
+            const int run = ncol * 13;                       // doubles per knot in this chunk
+            for (int u = threadIdx.x; u < 64 * run; u += NW * 64) {
+                const int kn = u / run, o = u - kn * run;
+                dst[kn * 247 + c0 * 13 + o] = tile[kn * 247 + c0 * 13 + o];
+            }
+        }
+        __syncthreads();
+    }
+}
+template <int NW, int CC> void launch_tilechunks(const Fn&, long long N, const double* Z, const double*, const double*, double* J, double*, hipStream_t s) {
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)tile_copy_chunks_kernel<NW, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 247 * 8)); init = true; }
+    hipLaunchKernelGGL((tile_copy_chunks_kernel<NW, CC>), dim3(256), dim3(NW * 64), 64 * 247 * 8, s, N / 64, Z, J);
+}
+template <int NW> void launch_tilecopy(const Fn&, long long N, const double* Z, const double*, const double*, double* J, double*, hipStream_t s) {
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)tile_copy_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 247 * 8)); init = true; }
+    hipLaunchKernelGGL((tile_copy_kernel<NW>), dim3(256), dim3(NW * 64), 64 * 247 * 8, s, N / 64, Z, J);
+}
+template <int NW> void launch_tilecopy_np(const Fn&, long long N, const double* Z, const double*, const double*, double* J, double*, hipStream_t s) {
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)tile_copy_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 247 * 8)); init = true; }
+    hipLaunchKernelGGL((tile_copy_kernel<NW>), dim3((unsigned)(N / 64)), dim3(NW * 64), 64 * 247 * 8, s, N / 64, Z, J);
+}
+
+int main(int argc, char** argv) {
+    const long long N = argc > 1 ? atoll(argv[1]) : 65536;
+    const int NZ = 19, NX = 13, NBUF = 4, REPS = 30;
+    std::vector<double> Z(N * NZ), t(N), dt(N, 0.1);
+    unsigned long long st = 88172645463325252ULL;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+    for (long long k = 0; k < N; ++k) {
+        double q[4], nn = 0;
+        for (int i = 0; i < 4; ++i) { double u1 = rnd() + 1e-12, u2 = rnd(); q[i] = std::sqrt(-2 * std::log(u1)) * std::cos(6.283185307179586 * u2); nn += q[i] * q[i]; }
+        for (int i = 0; i < NZ; ++i) Z[k * NZ + i] = rnd();
+        for (int i = 0; i < 4; ++i) Z[k * NZ + 3 + i] = q[i] / std::sqrt(nn);
+        t[k] = 0.1 * k;
+    }
+    double p[10] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Fn fn{Mdl::make(p)};
+    double *dZ, *dt_, *ddt, *dJ[NBUF], *dY[NBUF], *dJref;
+    CK(hipMalloc(&dZ, N * NZ * 8)); CK(hipMalloc(&dt_, N * 8)); CK(hipMalloc(&ddt, N * 8)); CK(hipMalloc(&dJref, N * NX * NZ * 8));
+    for (int b = 0; b < NBUF; ++b) { CK(hipMalloc(&dJ[b], N * NX * NZ * 8)); CK(hipMalloc(&dY[b], N * NX * 8)); }
+    CK(hipMemcpy(dZ, Z.data(), N * NZ * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dt_, t.data(), N * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(ddt, dt.data(), N * 8, hipMemcpyHostToDevice));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    std::vector<Variant> vars = {
+        TUNE_VARIANTS
+    };
+    std::vector<double> ref(N * NX * NZ), out(N * NX * NZ);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = (double)N * (NZ * 8 + 16 + NX * NZ * 8 + NX * 8);
+    for (int round = 0; round < 2; ++round)
+    for (size_t v = 0; v < vars.size(); ++v) {
+        for (int i = 0; i < 5; ++i) vars[v].launch(fn, N, dZ, dt_, ddt, dJ[i % NBUF], dY[i % NBUF], s);
+        CK(hipStreamSynchronize(s));
+        std::vector<float> ms(REPS);
+        for (int i = 0; i < REPS; ++i) {
+            CK(hipEventRecord(e0, s)); vars[v].launch(fn, N, dZ, dt_, ddt, dJ[i % NBUF], dY[i % NBUF], s); CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[i], e0, e1));
+        }
+        CK(hipGetLastError());
+        std::sort(ms.begin(), ms.end());
+        CK(hipMemcpy(out.data(), dJ[0], N * NX * NZ * 8, hipMemcpyDeviceToHost));
+        if (v == 0 && round == 0) ref = out;
+        double md = 0; for (size_t i = 0; i < out.size(); ++i) md = std::max(md, std::fabs(out[i] - ref[i]));
+        printf("round %d  %-28s median %7.2f us  min %7.2f us   %6.0f GB/s (median)  frac %.3f   maxdiff_vs_v0 %.2e\n", round, vars[v].name, ms[REPS / 2] * 1e3, ms[0] * 1e3,
+               bytes / (ms[REPS / 2] * 1e-3) / 1e9, bytes / (ms[REPS / 2] * 1e-3) / 8e12, md);
+    }
+    return 0;
+}

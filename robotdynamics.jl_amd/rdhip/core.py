@@ -203,6 +203,8 @@ def _dense(a, shape, name, transposed_last2=False):
     transposed_last2: logical (N, r, c) must be stored as C-order (N, c, r) (Julia column-major r x c x N)."""
     if tuple(a.shape) != tuple(shape):
         raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")   # DimensionMismatch
+    if any(s == 0 for s in shape):
+        return a
     if _is_torch(a):
         st = tuple(a.stride())
         item = 1
@@ -940,7 +942,7 @@ def _split_args(args):
         return args[0]
     x, u = np.asarray(args[0], dtype=np.float64), np.asarray(args[1], dtype=np.float64)
     t = args[2] if len(args) > 2 else 0.0
-    dt = args[3] if len(args) > 3 else np.nan    # continuous dynamics never reads dt; NaN is "not terminal"
+    dt = args[3] if len(args) > 3 else np.inf    # continuous dynamics never reads dt; Inf is "not terminal" (src/trajectories.jl:104)
     return KnotPoint(len(x), len(u), np.concatenate([x, u]), t, dt)
 
 
