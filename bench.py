@@ -107,18 +107,20 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    # kernel time: HIP events on the stream the kernel is launched on (rdhip borrows torch's current stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # kernel time: ONE pair of HIP events around the K launches of the timed region, recorded on the stream the kernels
+    # are launched on (rdhip borrows torch's current stream): kernel_ms = event time / K = the average launch duration
+    # including the inter-launch gap, i.e. what a caller looping over batches sees per launch.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = _time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        evs[i][0].record()
         step(i)
-        evs[i][1].record()
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = _time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
