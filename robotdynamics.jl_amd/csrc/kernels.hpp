@@ -437,6 +437,172 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split_kernel(Fn
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
+// ---- one WAVE per (tile, column group): the flagship ForwardAD organisation -----------------------------------------
+// Measured on MI355X (tools/fp64_ubench.hip): a one-shot grid of small workgroups streams stores ~25 % faster
+// than a persistent grid with a static tile partition (hardware workgroup dispatch balances the per-CU differences in
+// achieved HBM bandwidth), and with only 4 tiles per CU at N = 65 536 a persistent pipeline pays its un-overlapped
+// first compute phase four times over.  So: workgroup = ONE wave = 64 knot points x one group of Jacobian columns
+// (compile-time column list, structural zeros folded), ~10 KB of LDS and ~128 VGPRs, so that ~16 such waves live on a
+// CU in different phases: some computing, some with their stores draining.  A wave
+//   1. stages its tile's z (coalesced global loads -> LDS slice -> one knot point per lane),
+//   2. computes its columns in registers (AdRun below),
+//   3. transposes each run of columns through an LDS slice of SL knot points and stores it as lane-contiguous
+//      8-byte elements: a run is (ncols * NY) consecutive values per knot point, rows NY*NZ apart.
+// Blocks are numbered so that all column groups of a tile land on the same XCD (blockIdx % 8 is the XCD): the
+// tile's z is fetched into ONE L2, and the partially written 128-B lines at run boundaries merge in that L2.
+template <int NZ, int NG_> struct GroupPlan {          // default: NG contiguous column ranges, f(z) emitted by group 0
+    static constexpr int NGROUPS = NG_, NRUNS = 1;
+    static constexpr int run_begin(int g, int) { return g * NZ / NG_; }
+    static constexpr int run_end(int g, int) { return (g + 1) * NZ / NG_; }
+    static constexpr int value_group = 0;
+};
+
+template <class Fn, class T, class Plan, int SL> struct WaveLds {
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
+    static constexpr int max_cols() {
+        int m = 1;
+        for (int g = 0; g < Plan::NGROUPS; ++g) for (int r = 0; r < Plan::NRUNS; ++r) { const int c = Plan::run_end(g, r) - Plan::run_begin(g, r); m = c > m ? c : m; }
+        return m;
+    }
+    static constexpr int RS = (max_cols() * NY) | 1;          // odd row stride: conflict-free lane-strided ds_write_b64
+    static constexpr int ZS = NZ | 1;
+    static constexpr size_t ELEMS = (size_t)SL * (RS > ZS ? RS : ZS);
+    static constexpr size_t BYTES = ELEMS * sizeof(T);
+};
+
+// columns [C, C1) of one run, one tangent direction per pass with a compile-time seed; results land in out[(c-C0)*NY + i]
+template <class Fn, class T, int C0, int C, int C1> struct AdRun {
+    static RD_DEV void run(const Fn& fn, const T (&x)[Fn::NX], const T (&u)[Fn::NU], T t, T h, bool term, T* out) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY;
+        if constexpr (C < C1) {
+            using D = Dual<T, 1>;
+            D xd[NX], ud[NU], yd[NY];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xd[i].v = x[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
+            fn.eval(xd, ud, t, h, yd);
+            const T sc = (C >= NX && term) ? T(0) : T(1);      // control columns of a terminal knot point are zero
+#pragma unroll
+            for (int i = 0; i < NY; ++i) out[(C - C0) * NY + i] = yd[i].d[0] * sc;
+            AdRun<Fn, T, C0, C + 1, C1>::run(fn, x, u, t, h, term, out);
+        }
+    }
+};
+
+// transpose R values per lane (lane = knot point) through LDS slices of SL knot points and store them to
+// dst[row * pitch + j], j < R, rows < nk: consecutive lanes write consecutive 8-byte (4-byte) elements.
+template <class T, int R, int RS, int SL>
+RD_DEV void wave_flush(T* lds, const T (&vals)[R], T* __restrict__ dst, int pitch, int nk, int lane) {
+#pragma unroll
+    for (int s = 0; s < TILE / SL; ++s) {
+        wave_sync();
+        if ((lane / SL) == s) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) lds[(lane % SL) * RS + j] = vals[j];
+        }
+        wave_sync();
+        const int rows = nk - s * SL;                      // valid rows of this slice (may be <= 0 or > SL)
+        T* d = dst + (long long)s * SL * pitch;
+#pragma unroll
+        for (int e0 = 0; e0 < SL * R; e0 += TILE) {
+            const int e = e0 + lane;
+            const int row = e / R, col = e - row * R;
+            if (e < SL * R && row < rows) d[row * pitch + col] = lds[row * RS + col];
+        }
+    }
+}
+
+template <class Fn, class T, class Plan, int SL, int G> struct WaveGroup {
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY;
+    using L = WaveLds<Fn, T, Plan, SL>;
+    template <int RUN> static RD_DEV void runs(const Fn& fn, const T (&x)[NX], const T (&u)[NU], T t, T h, bool term, T* lds, T* __restrict__ Jt, int nk, int lane) {
+        if constexpr (RUN < Plan::NRUNS) {
+            constexpr int C0 = Plan::run_begin(G, RUN), C1 = Plan::run_end(G, RUN);
+            if constexpr (C1 > C0) {
+                T out[(C1 - C0) * NY];
+                AdRun<Fn, T, C0, C0, C1>::run(fn, x, u, t, h, term, out);
+                wave_flush<T, (C1 - C0) * NY, L::RS, SL>(lds, out, Jt + C0 * NY, NY * NZ, nk, lane);
+            }
+            runs<RUN + 1>(fn, x, u, t, h, term, lds, Jt, nk, lane);
+        }
+    }
+    static RD_DEV void run(const Fn& fn, const T (&x)[NX], const T (&u)[NU], T t, T h, bool term, T* lds, T* __restrict__ Jt, T* __restrict__ Yt, int nk, int lane) {
+        if constexpr (G == Plan::value_group) {
+            if (Yt) {
+                T y[NY];
+                fn.eval(x, u, t, h, y);
+                wave_flush<T, NY, L::RS, SL>(lds, y, Yt, NY, nk, lane);
+            }
+        }
+        runs<0>(fn, x, u, t, h, term, lds, Jt, nk, lane);
+    }
+};
+
+template <class Fn, class T, class Plan, int SL, int G> struct WaveDispatch {
+    static RD_DEV void go(int g, const Fn& fn, const T (&x)[Fn::NX], const T (&u)[Fn::NU], T t, T h, bool term, T* lds, T* __restrict__ Jt, T* __restrict__ Yt, int nk, int lane) {
+        if constexpr (G < Plan::NGROUPS) {
+            if (g == G) WaveGroup<Fn, T, Plan, SL, G>::run(fn, x, u, t, h, term, lds, Jt, Yt, nk, lane);
+            else WaveDispatch<Fn, T, Plan, SL, G + 1>::go(g, fn, x, u, t, h, term, lds, Jt, Yt, nk, lane);
+        }
+    }
+};
+
+template <class Fn, class T, class Plan, int SL, int OCC>
+__global__ void __launch_bounds__(TILE, OCC) jac_ad_wave_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                           const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NGR = Plan::NGROUPS;
+    using L = WaveLds<Fn, T, Plan, SL>;
+    static_assert(TILE % SL == 0, "slice must divide the wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // dynamic: L::BYTES (the compiler's static-LDS occupancy guess assumes 64 KB per CU)
+    T* lds = reinterpret_cast<T*>(smem);
+    const int lane = threadIdx.x;
+    // bundle of 8*NGR consecutive blocks = 8 tiles x NGR groups; block j of a bundle: XCD x = j % 8 owns tile x of the bundle
+    const long long b = blockIdx.x;
+    const int j = (int)(b % (8 * NGR));
+    const int g = j / 8;
+    const long long tile = (b / (8 * NGR)) * 8 + (j % 8);
+    const long long k0 = tile * TILE;
+    if (k0 >= N) return;
+    const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+    const int kl = lane < nk ? lane : nk - 1;              // lanes past a ragged end recompute the last knot point (never stored)
+    const double hd = dtt[k0 + kl];
+    const T t = (T)tt[k0 + kl], h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    // ---- stage z: all global loads first, then slice by slice through LDS
+    constexpr int ZPS = (SL * NZ + TILE - 1) / TILE;        // elements per lane per slice
+    T zr[TILE / SL][ZPS];
+#pragma unroll
+    for (int s = 0; s < TILE / SL; ++s)
+#pragma unroll
+        for (int r = 0; r < ZPS; ++r) {
+            const int e = r * TILE + lane;
+            const long long ge = (k0 + s * SL) * NZ + e;
+            zr[s][r] = (e < SL * NZ && ge < N * NZ) ? Z[ge] : T(0);
+        }
+    T x[NX], u[NU];
+#pragma unroll
+    for (int s = 0; s < TILE / SL; ++s) {
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < ZPS; ++r) {
+            const int e = r * TILE + lane;
+            if (e < SL * NZ) { const int row = e / NZ, col = e - row * NZ; lds[row * L::ZS + col] = zr[s][r]; }
+        }
+        wave_sync();
+        const int ks = kl - s * SL;                         // this lane's row in slice s, if it belongs to it
+        if (ks >= 0 && ks < SL) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = lds[ks * L::ZS + i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : lds[ks * L::ZS + NX + i];
+        }
+    }
+    T* Jt = J + k0 * (NY * NZ);
+    T* Yt = Y ? Y + k0 * NY : nullptr;
+    WaveDispatch<Fn, T, Plan, SL, 0>::go(g, fn, x, u, t, h, term, lds, Jt, Yt, nk, lane);
+}
+
 // ---- ForwardAD, run-time column loop (compact code for the long tail of model x rule combinations) -----------
 template <class Fn, class T, class Plan> struct AdLoopBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {

@@ -33,6 +33,45 @@ template <class Plan, int NC> void launch_split(const Fn& fn, long long N, const
     hipLaunchKernelGGL((jac_ad_split_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
 }
 
+template <class Plan, int SL, int OCC> void launch_wave(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
+    const long long ntiles = (N + TILE - 1) / TILE;
+    const long long grid = (ntiles + 7) / 8 * 8 * Plan::NGROUPS;
+    using WL = WaveLds<Fn, double, Plan, SL>;
+    constexpr unsigned lds = (unsigned)WL::BYTES;
+    hipLaunchKernelGGL((jac_ad_wave_kernel<Fn, double, Plan, SL, OCC>), dim3((unsigned)grid), dim3(TILE), lds, s, fn, N, Z, t, dt, J, Y);
+}
+// hand-balanced satellite plans (columns: r 0-2, q 3-6, v 7-9, w 10-12, uF 13-15, tau 16-18)
+struct SatPlanBal8 {
+    static constexpr int NGROUPS = 8, NRUNS = 2;
+    static constexpr int B[8][2] = {{10, 0}, {11, 7}, {12, 0}, {14, 0}, {17, 0}, {18, 0}, {3, 0}, {5, 0}};
+    static constexpr int E[8][2] = {{11, 3}, {12, 10}, {14, 0}, {17, 0}, {18, 0}, {19, 0}, {5, 0}, {7, 0}};
+    static constexpr int run_begin(int g, int r) { return B[g][r]; }
+    static constexpr int run_end(int g, int r) { return E[g][r]; }
+    static constexpr int value_group = 4;
+};
+struct SatPlanCont8 {   // contiguous, cost-aware boundaries
+    static constexpr int NGROUPS = 8, NRUNS = 1;
+    static constexpr int Bd[9] = {0, 4, 6, 10, 11, 12, 14, 17, 19};
+    static constexpr int run_begin(int g, int) { return Bd[g]; }
+    static constexpr int run_end(int g, int) { return Bd[g + 1]; }
+    static constexpr int value_group = 0;
+};
+struct SatPlanCont10 {
+    static constexpr int NGROUPS = 10, NRUNS = 1;
+    static constexpr int Bd[11] = {0, 4, 6, 10, 11, 12, 14, 16, 17, 18, 19};
+    static constexpr int run_begin(int g, int) { return Bd[g]; }
+    static constexpr int run_end(int g, int) { return Bd[g + 1]; }
+    static constexpr int value_group = 0;
+};
+struct SatPlan4x2 {     // 4 groups, two sequential runs each (less primal replication)
+    static constexpr int NGROUPS = 4, NRUNS = 2;
+    static constexpr int B[4][2] = {{0, 3}, {5, 7}, {11, 13}, {15, 17}};
+    static constexpr int E[4][2] = {{3, 5}, {7, 11}, {13, 15}, {17, 19}};
+    static constexpr int run_begin(int g, int r) { return B[g][r]; }
+    static constexpr int run_end(int g, int r) { return E[g][r]; }
+    static constexpr int value_group = 0;
+};
+
 // pure streaming-store references: what the HBM write path sustains for the same 136 MB
 __global__ void __launch_bounds__(256) fill_b64(double* __restrict__ p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = (double)i;

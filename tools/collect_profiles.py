@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""tools/collect_profiles.py <tag> [<dest>] -- copy the judged rocprofv3 summaries of gpurun_out/<tag>/ (written by
+tools/gpu_profile.sh on the GPU box) into profiles/<dest>/ and derive profiles/hbm_traffic.json.
+
+HBM traffic per launch = WRITE_SIZE x f_w + FETCH_SIZE x f_r (both counters are in KiB), where the correction factors come
+from the calibration runs of the same session: tools/fp64_ubench `calib` streams exactly 1 GiB through a 16-B/lane fill and
+16-B and 8-B/lane reads under the same --pmc pass (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half the
+bytes of a coalesced streaming read; WRITE_SIZE must be calibrated on a known byte count)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+dest = sys.argv[2] if len(sys.argv) > 2 else tag
+src = os.path.join(ROOT, "gpurun_out", tag)
+out = os.path.join(ROOT, "profiles", dest)
+os.makedirs(out, exist_ok=True)
+
+
+def counters(path):
+    agg = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def pick(agg, needle, counter):
+    best = None
+    for (k, c), v in agg.items():
+        if needle in k and c == counter and (best is None or len(v) > len(best[1])):
+            best = (k, v)
+    return best
+
+
+GIB_KIB = float(1 << 20)
+summary = {"tag": tag}
+cal_w = pick(counters(os.path.join(src, "cal_write", "cal_counter_collection.csv")), "fill16(", "WRITE_SIZE")
+cal_r16 = pick(counters(os.path.join(src, "cal_fetch", "cal_counter_collection.csv")), "read16(", "FETCH_SIZE")
+cal_r8 = pick(counters(os.path.join(src, "cal_fetch", "cal_counter_collection.csv")), "read8(", "FETCH_SIZE")
+f_w = GIB_KIB / max(cal_w[1]) if cal_w else 1.0
+f_r16 = GIB_KIB / max(cal_r16[1]) if cal_r16 else 2.0
+f_r8 = GIB_KIB / max(cal_r8[1]) if cal_r8 else f_r16
+summary["calibration"] = {"write_factor": f_w, "read16_factor": f_r16, "read8_factor": f_r8,
+                          "method": "1 GiB streaming fill/read under the same --pmc pass; factor = true KiB / counter KiB"}
+kern = None
+for name in ("pmc_write", "pmc_fetch"):
+    p = os.path.join(src, name, f"{tag}_counter_collection.csv")
+    agg = counters(p)
+    rows = []
+    for (k, c), v in sorted(agg.items()):
+        rows.append({"kernel": k, "counter": c, "launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)})
+    summary[name] = rows
+    with open(os.path.join(out, f"{name}_summary.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["kernel", "counter", "launches", "mean_KiB", "min_KiB", "max_KiB"])
+        w.writeheader()
+        w.writerows(rows)
+stats = os.path.join(src, "trace", f"{tag}_kernel_stats.csv")
+if os.path.exists(stats):
+    shutil.copy(stats, os.path.join(out, "kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    kern = rows[0]["Name"]
+    summary["dominant_kernel"] = {"name": kern, "calls": int(rows[0]["Calls"]), "avg_ns": float(rows[0]["AverageNs"]),
+                                  "min_ns": float(rows[0]["MinNs"]), "max_ns": float(rows[0]["MaxNs"])}
+for f in ("bench.json", "pytest_gpu.log"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(out, f))
+if kern:
+    key = kern.split("(")[0][:60]
+    w = pick(counters(os.path.join(src, "pmc_write", f"{tag}_counter_collection.csv")), key, "WRITE_SIZE")
+    r = pick(counters(os.path.join(src, "pmc_fetch", f"{tag}_counter_collection.csv")), key, "FETCH_SIZE")
+    if w and r:
+        wb = sum(w[1]) / len(w[1]) * 1024 * f_w
+        rb = sum(r[1]) / len(r[1]) * 1024 * f_r8          # the kernel's input loads are 8 B per lane
+        summary["traffic"] = {"write_bytes_per_launch": wb, "read_bytes_per_launch": rb, "bytes_per_launch": wb + rb}
+        json.dump({"bytes_per_launch": wb + rb, "write_bytes": wb, "read_bytes": rb, "kernel": kern, "source": f"profiles/{dest}/ (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes, calibrated)"},
+                  open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
