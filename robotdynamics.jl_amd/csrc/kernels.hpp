@@ -20,6 +20,14 @@ template <> RD_DEV float sqrt_eps<float>() { return 3.4526698300124393e-04f; }  
 // carries a control, src/trajectories.jl:104) would be undefined.
 RD_DEV bool is_terminal_dt(double h) { return (__double_as_longlong(h) << 1) == 0; }
 
+#ifdef RD_STAMP   // tuning only: per-wave phase time stamps (100 MHz wall clock) into a global buffer
+__device__ long long* g_stamps;
+RD_DEV void stamp(int slot, int ev) { if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[slot * 64 + ev] = wall_clock64(); }
+#define RD_STAMP_AT(slot, ev) stamp(slot, ev)
+#else
+#define RD_STAMP_AT(slot, ev) do {} while (0)
+#endif
+
 RD_DEV void wave_sync() {
     // LDS hand-off inside ONE wave: DS ops of a wave execute in order, we only need the compiler to keep them so.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -113,6 +121,26 @@ template <int NZ, int NG_> struct ContiguousPlan {
     static constexpr int chunk_end(int) { return NZ; }
     static constexpr int wave_of(int c) { int g = 0; while (!(c >= g * NZ / NG && c < (g + 1) * NZ / NG)) ++g; return g; }
     static constexpr int value_chunk = 0, value_wave = 0;
+};
+
+// Cost-balanced single-chunk plan from a column -> wave table (columns of one wave need not be contiguous: the tile is
+// assembled in LDS and leaves as one linear sweep).
+template <int NZ, int NG_, int VW, int... W> struct TablePlan {
+    static_assert(sizeof...(W) == NZ, "one wave index per Jacobian column");
+    static constexpr int NG = NG_, NCHUNK = 1;
+    static constexpr int chunk_begin(int) { return 0; }
+    static constexpr int chunk_end(int) { return NZ; }
+    static constexpr int wave_of(int c) { constexpr int w[NZ] = {W...}; return w[c]; }
+    static constexpr int value_chunk = 0, value_wave = VW;
+};
+// Two column chunks [0, SPLIT) and [SPLIT, NZ) with a column -> wave table; f(z) travels with the second chunk.
+template <int NZ, int NG_, int SPLIT, int VW, int... W> struct TablePlan2 {
+    static_assert(sizeof...(W) == NZ, "one wave index per Jacobian column");
+    static constexpr int NG = NG_, NCHUNK = 2;
+    static constexpr int chunk_begin(int ch) { return ch == 0 ? 0 : SPLIT; }
+    static constexpr int chunk_end(int ch) { return ch == 0 ? SPLIT : NZ; }
+    static constexpr int wave_of(int c) { constexpr int w[NZ] = {W...}; return w[c]; }
+    static constexpr int value_chunk = 1, value_wave = VW;
 };
 
 template <class Fn, class T, class Plan> struct JacLds {
@@ -316,6 +344,13 @@ __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_unrolled_kernel(Fn fn,
 //                     -------- barrier B (LDS free) -------------
 // so the HBM write stream of tile t runs under the arithmetic of tile t+1.  Requires 16-byte aligned J and Y (the
 // copy is a linear 16-byte sweep over the tile, which is one contiguous slab of global memory).
+// tile stores are streaming (written once, never re-read by this kernel): the non-temporal hint measured 3-5 % faster
+// than plain stores on MI355X (less dirty data left in L2 for the end-of-kernel write-back); -DRD_PLAIN_STORES reverts
+#if defined(RD_PLAIN_STORES)
+#define RD_TILE_STORE(p, v) (*(p) = (v))
+#else
+#define RD_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 template <class Fn, class T, class Plan, int NC> struct SplitLds {
     static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
     static constexpr size_t J_ELEMS = (size_t)TILE * NY * NZ, Y_ELEMS = (size_t)TILE * NY, Z_ELEMS = (size_t)TILE * NZ;
@@ -390,6 +425,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         const int ct = threadIdx.x - NG * TILE;            // 0 .. NC*64-1
         const V4* jsrc = reinterpret_cast<const V4*>(jt);
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
+        __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
         __syncthreads();                                   // barrier 0
         for (; tile < ntiles; tile += gridDim.x) {
             const long long k0 = tile * TILE;
@@ -408,7 +444,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
 #pragma unroll
             for (int r = 0; r < L::JPL; ++r) {
                 const int u = r * (NC * TILE) + ct;
-                if (u * 16 + 16 <= jbytes) jdst[u] = jv[r];
+                if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
                 else if (u * 16 < jbytes) {                // partial last unit of a ragged tile: element-wise
                     const T* pv = reinterpret_cast<const T*>(&jv[r]);
                     T* pd = reinterpret_cast<T*>(jdst + u);
@@ -420,7 +456,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
 #pragma unroll
                 for (int r = 0; r < L::YPL; ++r) {
                     const int u = r * (NC * TILE) + ct;
-                    if (u * 16 + 16 <= ybytes) ydst[u] = yv[r];
+                    if (u * 16 + 16 <= ybytes) RD_TILE_STORE(ydst + u, yv[r]);
                     else if (u * 16 < ybytes) {
                         const T* pv = reinterpret_cast<const T*>(&yv[r]);
                         T* pd = reinterpret_cast<T*>(ydst + u);
@@ -435,6 +471,193 @@ template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+}
+
+// ---- double-buffered two-chunk split-role kernel ----------------------------------------------------------------------
+// Measured on the single-buffer split kernel above (phase time stamps): per tile the store chain is
+// [barrier A] -> LDS->registers (0.5 us) -> [barrier B] -> store issue (3.5-4 us, HBM-bound: all CUs are in lock step),
+// the compute chain is 3-3.5 us, the first tile's compute (3.7 us) has no stores under it.  Here the tile is produced in
+// TWO column chunks into TWO LDS buffers: the compute waves fill buffer c%2 with chunk c while the copy waves stream
+// chunk c-1 from the other buffer straight to global memory (ds_read -> global_store, a few units in flight, no register
+// staging of a whole tile).  ONE workgroup barrier per chunk: barrier k = "chunk k complete AND chunk k-1 drained".
+// The un-overlapped prologue shrinks to half a tile of arithmetic and the copy waves never wait for an LDS hand-off.
+// A chunk's rows are runs of (ncols*NY) values per knot point at a pitch of NY*NZ: stored as lane-contiguous elements.
+template <class T> constexpr int lds_row_stride(int r) {
+    // rows must start 16-B aligned in LDS (ds_read_b128) -> stride multiple of V = 16/sizeof(T); among those pick one whose
+    // dword stride is not a multiple of 16 banks (fp64: stride = 2 mod 4 doubles -> 2-way conflicts on the lane-strided writes)
+    constexpr int V = 16 / (int)sizeof(T);
+    int rs = (r + V - 1) / V * V;
+    while ((rs / V) % 2 == 0) rs += V;
+    return rs;
+}
+template <class Fn, class T, class Plan> struct Split2Lds {
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
+    static_assert(Plan::NCHUNK == 2, "two column chunks");
+    static constexpr int R0 = (Plan::chunk_end(0) - Plan::chunk_begin(0)) * NY;          // values per knot point, chunk 0
+    static constexpr int R1 = (Plan::chunk_end(1) - Plan::chunk_begin(1)) * NY;          // chunk 1
+    static constexpr int RS0 = lds_row_stride<T>(R0), RS1 = lds_row_stride<T>(R1);
+    static constexpr size_t B0_BYTES = (size_t)TILE * RS0 * sizeof(T);
+    static constexpr size_t B1_BYTES = (size_t)TILE * RS1 * sizeof(T);
+    static constexpr size_t Y_BYTES = ((size_t)TILE * NY * sizeof(T) + 15) / 16 * 16;    // f(z) tile, dense (a contiguous slab of Y)
+    static constexpr size_t Z_ELEMS = (size_t)TILE * NZ;
+    static constexpr size_t IN_BYTES = (Z_ELEMS * sizeof(T) + 2 * TILE * sizeof(double) + 15) / 16 * 16;
+    static constexpr size_t BYTES = B0_BYTES + B1_BYTES + Y_BYTES + 2 * IN_BYTES;
+};
+
+// copy R values per row from LDS rows (stride RS, 16-B aligned) to global rows (stride pitch, element aligned), ROWS rows,
+// by NTH copy threads (`ct` = my index): 16-B units, then the odd tail of each row element-wise.  Full tiles only.
+template <class T, int R, int RS, int ROWS, int NTH>
+RD_DEV void drain_rows(const T* __restrict__ lds, T* __restrict__ dst, int pitch, int ct) {
+    using VA = typename Vec16<T>::type;                                        // element-aligned 16-B vector (global side)
+    typedef T VL __attribute__((ext_vector_type(16 / sizeof(T))));           // 16-B aligned vector (LDS side)
+    constexpr int V = 16 / (int)sizeof(T), UPR = R / V, TAILN = R - UPR * V, UNITS = ROWS * UPR;
+#pragma unroll
+    for (int e0 = 0; e0 < UNITS; e0 += NTH) {
+        const int e = e0 + ct;
+        if (e0 + NTH <= UNITS || e < UNITS) {
+            const int row = e / UPR, u = e - row * UPR;
+            const VL v = *reinterpret_cast<const VL*>(lds + row * RS + u * V);
+            VA o;
+#pragma unroll
+            for (int q = 0; q < V; ++q) o[q] = v[q];
+            *reinterpret_cast<VA*>(dst + row * pitch + u * V) = o;
+        }
+    }
+    if constexpr (TAILN > 0) {
+#pragma unroll
+        for (int e0 = 0; e0 < ROWS * TAILN; e0 += NTH) {
+            const int e = e0 + ct;
+            if (e < ROWS * TAILN) { const int row = e / TAILN, j = e - row * TAILN; dst[row * pitch + UPR * V + j] = lds[row * RS + UPR * V + j]; }
+        }
+    }
+}
+// ragged last tile: element-wise with a row predicate
+template <class T, int R, int RS, int NTH>
+RD_DEV void drain_rows_ragged(const T* __restrict__ lds, T* __restrict__ dst, int pitch, int nk, int ct) {
+    for (int e = ct; e < TILE * R; e += NTH) {
+        const int row = e / R, col = e - row * R;
+        if (row < nk) dst[row * pitch + col] = lds[row * RS + col];
+    }
+}
+
+template <class Fn, class T, class Plan, int NC, class Body>
+RD_DEV void jac_split2_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                            T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG;
+    using L = Split2Lds<Fn, T, Plan>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* b0 = reinterpret_cast<T*>(smem);
+    T* b1 = reinterpret_cast<T*>(smem + L::B0_BYTES);
+    T* yb = reinterpret_cast<T*>(smem + L::B0_BYTES + L::B1_BYTES);
+    unsigned char* in0 = smem + L::B0_BYTES + L::B1_BYTES + L::Y_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: role and column branches are scalar branches
+    const long long ntiles = (N + TILE - 1) / TILE;
+    long long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    // The compute waves never touch global memory: a VMEM instruction of a wave whose CU is saturated with stores blocks AT
+    // ISSUE (measured: 1.8 us per tile at the input prefetch), so the copy waves -- which live in the memory pipeline anyway --
+    // also fetch the next tile's z/t/dt (issued ahead of a drain) and stage them into the other LDS input buffer.
+    if (wave < NG) {
+        // =========================== compute waves ===========================
+        JacFrame<Fn, T> fr;
+        fr.g = wave;
+        fr.yrow = yb + lane * NY;
+        fr.want_y = (Y != nullptr);
+        __syncthreads();                                   // barrier: first inputs staged
+        int buf = 0;
+        for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+            const T* zs = reinterpret_cast<const T*>(in0 + buf * L::IN_BYTES);
+            const double* ts = reinterpret_cast<const double*>(zs + L::Z_ELEMS);
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            const int kl = lane < nk ? lane : nk - 1;
+            const double hd = ts[TILE + kl];
+            fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
+            read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
+            [[maybe_unused]] const int it_ = (int)((tile - blockIdx.x) / gridDim.x);
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 0);
+            fr.row = b0 + lane * L::RS0;
+            Body::template run<0>(fn, fr);
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 1);
+            __syncthreads();                               // chunk 0 complete (and the previous tile's chunk 1 drained)
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 2);
+            fr.row = b1 + lane * L::RS1;
+            Body::template run<1>(fn, fr);
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 3);
+            __syncthreads();                               // chunk 1 complete (and chunk 0 drained), next inputs visible
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 4);
+        }
+    } else {
+        // =========================== copy waves ==============================
+        constexpr int NTK = NC * TILE;
+        constexpr int ZPT = (TILE * NZ + NTK - 1) / NTK;
+        const int ct = threadIdx.x - NG * TILE;            // 0 .. NC*64-1
+        {
+            T* zs = reinterpret_cast<T*>(in0);
+            double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            for (int e = ct; e < nk * NZ; e += NTK) zs[e] = Z[k0 * NZ + e];
+            if (ct < nk) ts[ct] = tt[k0 + ct];
+            else if (ct >= TILE && ct < TILE + nk) ts[ct] = dtt[k0 + ct - TILE];
+        }
+        // inputs of tile i+1 are LOADED (into registers) right after the barrier "chunk 1 of tile i-1 complete" and WRITTEN to
+        // the other LDS input buffer right after the barrier "chunk 0 of tile i complete": the wait for those loads then
+        // sits behind a compute-bound barrier wait, not behind this wave's own freshly issued stores.
+        T zpre[ZPT]; double tpre;
+        auto load_inputs = [&](long long tl) {
+            const long long k1 = tl * TILE;
+            const int nk1 = (tl < ntiles) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTK + ct; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }   // unconditional loads
+            const double* tp = (ct < TILE) ? tt : dtt;
+            const int idx = ct & (TILE - 1);
+            tpre = tp[(ct < 2 * TILE && idx < nk1) ? k1 + idx : 0];
+        };
+        load_inputs(tile + gridDim.x);
+        __syncthreads();                                   // barrier: first inputs staged
+        int buf = 0;
+        for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+            const long long k0 = tile * TILE;
+            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            T* Jt = J + k0 * (NY * NZ);
+            T* zn = reinterpret_cast<T*>(in0 + (buf ^ 1) * L::IN_BYTES);
+            double* tn = reinterpret_cast<double*>(zn + L::Z_ELEMS);
+            [[maybe_unused]] const int it_ = (int)((tile - blockIdx.x) / gridDim.x);
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 0);
+            __syncthreads();                               // chunk 0 complete
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 1);
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTK + ct; if (e < TILE * NZ) zn[e] = zpre[r]; }      // inputs of the next tile
+            if (ct < 2 * TILE) tn[ct] = tpre;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nk == TILE) drain_rows<T, L::R0, L::RS0, TILE, NTK>(b0, Jt + Plan::chunk_begin(0) * NY, NY * NZ, ct);
+            else drain_rows_ragged<T, L::R0, L::RS0, NTK>(b0, Jt + Plan::chunk_begin(0) * NY, NY * NZ, nk, ct);
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 2);
+            __syncthreads();                               // chunk 1 complete; next inputs visible
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 3);
+            load_inputs(tile + 2 * (long long)gridDim.x);  // ahead of the drain in the memory pipeline
+            __builtin_amdgcn_sched_barrier(0);
+            if (nk == TILE) {
+                drain_rows<T, L::R1, L::RS1, TILE, NTK>(b1, Jt + Plan::chunk_begin(1) * NY, NY * NZ, ct);
+                if (Y) drain_rows<T, TILE * NY, TILE * NY, 1, NTK>(yb, Y + k0 * NY, 0, ct);               // the f(z) tile is one dense row
+            } else {
+                drain_rows_ragged<T, L::R1, L::RS1, NTK>(b1, Jt + Plan::chunk_begin(1) * NY, NY * NZ, nk, ct);
+                if (Y) for (int e = ct; e < nk * NY; e += NTK) Y[k0 * NY + e] = yb[e];
+            }
+            RD_STAMP_AT(blockIdx.x * 8 + wave, it_ * 5 + 4);
+        }
+#ifdef RD_STAMP
+        __builtin_amdgcn_s_waitcnt(0x0F70); RD_STAMP_AT(blockIdx.x * 8 + wave, 60);   // all stores complete
+#endif
+    }
+}
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split2_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_split2_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
 // ---- one WAVE per (tile, column group): the flagship ForwardAD organisation -----------------------------------------

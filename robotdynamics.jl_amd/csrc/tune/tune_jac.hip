@@ -8,7 +8,10 @@
 #include "../kernels.hpp"
 
 using namespace rd;
-using Mdl = RigidBody<double, WRENCH_SATELLITE, false>;
+#ifndef TUNE_DIAGJ
+#define TUNE_DIAGJ true
+#endif
+using Mdl = RigidBody<double, WRENCH_SATELLITE, false, TUNE_DIAGJ>;
 using Fn = Fun<Mdl, RULE_RK4>;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -33,6 +36,22 @@ template <class Plan, int NC> void launch_split(const Fn& fn, long long N, const
     hipLaunchKernelGGL((jac_ad_split_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
 }
 
+template <class Plan, int NC> void launch_split2(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
+    using L2 = Split2Lds<Fn, double, Plan>;
+    constexpr size_t lds = L2::BYTES;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_split2_kernel<Fn, double, Plan, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
+    const long long ntiles = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL((jac_ad_split2_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
+}
+// two-chunk plans: chunk 0 = r,q,v,w10,w11 (cols 0-11), chunk 1 = w12,uF,tau (+ f(z)).  wave table per chunk:
+//   chunk 0: q3,q4 -> 0 ; q5,q6 -> 1 ; w10 (+r) -> 2 ; w11 (+v) -> 3        chunk 1: w12 -> 0 ; tau16,uF13 -> 1 ; tau17,uF14 -> 2 ; tau18,uF15 (+y) -> 3
+using Sat2A = TablePlan2<19, 4, 12, 3, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 2, 3, 0, /*uF*/ 1, 2, 3, /*tau*/ 1, 2, 3>;
+// same, but f(z) and all uF columns with the lightest chunk-1 wave pair
+using Sat2C = TablePlan2<19, 4, 12, 3, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 2, 3, 0, /*uF*/ 3, 3, 3, /*tau*/ 1, 2, 2>;
+// chunk 0 = cols 0-9 (r,q,v), chunk 1 = w,uF,tau
+using Sat2B = TablePlan2<19, 4, 10, 3, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 2, 3, /*w*/ 0, 1, 2, /*uF*/ 3, 3, 3, /*tau*/ 3, 0, 1>;
 template <class Plan, int SL, int OCC> void launch_wave(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
     const long long ntiles = (N + TILE - 1) / TILE;
     const long long grid = (ntiles + 7) / 8 * 8 * Plan::NGROUPS;
@@ -41,6 +60,9 @@ template <class Plan, int SL, int OCC> void launch_wave(const Fn& fn, long long 
     hipLaunchKernelGGL((jac_ad_wave_kernel<Fn, double, Plan, SL, OCC>), dim3((unsigned)grid), dim3(TILE), lds, s, fn, N, Z, t, dt, J, Y);
 }
 // hand-balanced satellite plans (columns: r 0-2, q 3-6, v 7-9, w 10-12, uF 13-15, tau 16-18)
+using SatPlanA = TablePlan<19, 4, 2, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3>;
+using SatPlanB = TablePlan<19, 4, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 2>;   // q | w10,w11 | w12,uF,tau18 | tau16,tau17 (+y)
+using SatPlan5 = TablePlan<19, 5, 4, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 2, 2, 3, 4, 4, 4, 3, 4, 4>;   // 5 compute waves
 struct SatPlanBal8 {
     static constexpr int NGROUPS = 8, NRUNS = 2;
     static constexpr int B[8][2] = {{10, 0}, {11, 7}, {12, 0}, {14, 0}, {17, 0}, {18, 0}, {3, 0}, {5, 0}};
@@ -191,5 +213,40 @@ int main(int argc, char** argv) {
         printf("round %d  %-28s median %7.2f us  min %7.2f us   %6.0f GB/s (median)  frac %.3f   maxdiff_vs_v0 %.2e\n", round, vars[v].name, ms[REPS / 2] * 1e3, ms[0] * 1e3,
                bytes / (ms[REPS / 2] * 1e-3) / 1e9, bytes / (ms[REPS / 2] * 1e-3) / 8e12, md);
     }
+#ifdef RD_STAMP
+    {   // phase time stamps of variant 0 (a split-role kernel with 8 waves: compute wave 0 and copy wave 4 are printed)
+#ifndef STAMP_EV
+#define STAMP_EV 4      // events per tile
+#endif
+        long long* st; const int nslots = 256 * 8; CK(hipMalloc(&st, nslots * 64 * 8)); CK(hipMemset(st, 0, nslots * 64 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(rd::g_stamps), &st, sizeof st));
+        for (int i = 0; i < 8; ++i) vars[0].launch(fn, N, dZ, dt_, ddt, dJ[i % NBUF], dY[i % NBUF], s);
+        CK(hipStreamSynchronize(s));
+        std::vector<long long> h(nslots * 64); CK(hipMemcpy(h.data(), st, nslots * 64 * 8, hipMemcpyDeviceToHost));
+        long long t0 = -1; for (int b = 0; b < 256; ++b) { long long v = h[(b * 8 + 0) * 64 + 0]; if (v && (t0 < 0 || v < t0)) t0 = v; }
+        auto us = [&](long long v) { return v ? (v - t0) / 100.0 : -1.0; };
+        const int NE = STAMP_EV * 4;
+        printf("phase stamps (us since first compute start), %d events per tile; C = compute wave 0..3, K = copy wave 4\n", STAMP_EV);
+        for (int b : {0, 1, 37, 128, 255}) {
+            for (int w = 0; w < 4; ++w) { printf(" blk %3d C%d:", b, w); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + w) * 64 + e])); printf("\n"); }
+            printf("         K :"); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + 4) * 64 + e])); printf("  done %6.2f\n", us(h[(b * 8 + 4) * 64 + 60]));
+        }
+        std::vector<double> done; std::vector<double> dsum(STAMP_EV, 0.0), ksum(STAMP_EV, 0.0); int cn = 0;
+        for (int b = 0; b < 256; ++b) {
+            for (int it = 0; it < 4; ++it) {
+                const long long* c = &h[(b * 8 + 0) * 64 + it * STAMP_EV]; const long long* k = &h[(b * 8 + 4) * 64 + it * STAMP_EV];
+                bool ok = true; for (int e = 0; e < STAMP_EV; ++e) ok = ok && c[e] && k[e];
+                if (!ok) continue;
+                for (int e = 1; e < STAMP_EV; ++e) { dsum[e] += (c[e] - c[e - 1]) / 100.0; ksum[e] += (k[e] - k[e - 1]) / 100.0; }
+                ++cn;
+            }
+            done.push_back(us(h[(b * 8 + 4) * 64 + 60]));
+        }
+        std::sort(done.begin(), done.end());
+        printf("mean event-to-event (us), compute wave 0:"); for (int e = 1; e < STAMP_EV; ++e) printf(" %.2f", dsum[e] / cn);
+        printf(" | copy wave 4:"); for (int e = 1; e < STAMP_EV; ++e) printf(" %.2f", ksum[e] / cn); printf("  (n=%d)\n", cn);
+        printf("block completion (all stores done): min %.2f p10 %.2f med %.2f p90 %.2f max %.2f\n", done[0], done[25], done[128], done[230], done[255]);
+    }
+#endif
     return 0;
 }

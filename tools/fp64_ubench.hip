@@ -81,6 +81,22 @@ __global__ void __launch_bounds__(256) fill16_dyn(double2* __restrict__ p, long 
         const long long i = ch * 256 + threadIdx.x; if (i < n) p[i] = make_double2((double)i, 1.0);
     }
 }
+// one-shot grid, but block b writes the 4 KB chunk number perm(b): NS interleaved sequential streams (stream = b % NS)
+__global__ void __launch_bounds__(256) fill16_streams(double2* __restrict__ p, long long n, int NS) {
+    const long long nchunks = n / 256;
+    const long long per = nchunks / NS;                    // chunks per stream
+    const long long b = blockIdx.x;
+    const long long chunk = (b % NS) * per + (b / NS);
+    if (b / NS >= per) return;
+    p[chunk * 256 + threadIdx.x] = make_double2((double)chunk, 1.0);
+}
+// persistent static grid-stride fill that records each block's finish time
+__global__ void __launch_bounds__(256) fill16_stamp(double2* __restrict__ p, long long n, long long* stamps) {
+    const long long t0 = wall_clock64();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = make_double2((double)i, 1.0);
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = wall_clock64(); }
+}
 __global__ void __launch_bounds__(256) read8(const double* __restrict__ p, long long n, double* out) {
     double s = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += p[i];
@@ -130,6 +146,22 @@ int main(int argc, char** argv) {
         time_it("fill16_chunk<20> (20KB/wave) x4 rot", [&](int i) { hipLaunchKernelGGL(fill16_chunk<20>, dim3((unsigned)((jb / 16 + 64 * 20 - 1) / (64 * 20))), dim3(64), 0, 0, b4[i % 4], jb / 16); }, (double)jb, 40);
         time_it("fill16_chunk<8> (8KB/wave) x4 rot", [&](int i) { hipLaunchKernelGGL(fill16_chunk<8>, dim3((unsigned)((jb / 16 + 64 * 8 - 1) / (64 * 8))), dim3(64), 0, 0, b4[i % 4], jb / 16); }, (double)jb, 40);
         time_it("fill16_dyn persistent 2048 WG", [&](int i) { CK(hipMemsetAsync(ctr, 0, 4, 0)); hipLaunchKernelGGL(fill16_dyn, dim3(2048), dim3(256), 0, 0, b4[i % 4], jb / 16, ctr); }, (double)jb, 40);
+        for (int ns : {1, 8, 64, 256, 1024, 4096}) {
+            char nm[64]; snprintf(nm, 64, "fill16_streams NS=%d x4 rot", ns);
+            time_it(nm, [&](int i) { hipLaunchKernelGGL(fill16_streams, dim3((unsigned)(jb / 16 / 256)), dim3(256), 0, 0, b4[i % 4], jb / 16, ns); }, (double)jb, 40);
+        }
+        {
+            long long* st; CK(hipMalloc(&st, 2048 * 16));
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(fill16_stamp, dim3(2048), dim3(256), 0, 0, b4[rep % 4], jb / 16, st);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> h(4096); CK(hipMemcpy(h.data(), st, 2048 * 16, hipMemcpyDeviceToHost));
+            long long tmin = h[0]; for (int i = 0; i < 2048; ++i) tmin = std::min(tmin, h[2 * i]);
+            std::vector<double> fin(2048), sta(2048); for (int i = 0; i < 2048; ++i) { fin[i] = (h[2 * i + 1] - tmin) / 100.0; sta[i] = (h[2 * i] - tmin) / 100.0; }   // wall_clock64 = 100 MHz
+            std::vector<double> f2 = fin; std::sort(f2.begin(), f2.end()); std::vector<double> s2 = sta; std::sort(s2.begin(), s2.end());
+            printf("fill16_stamp persistent 2048 blocks: start us min %.2f med %.2f max %.2f | finish us min %.2f p10 %.2f med %.2f p90 %.2f max %.2f\n", s2[0], s2[1024], s2[2047], f2[0], f2[204], f2[1024], f2[1843], f2[2047]);
+            // by XCD (block % 8)
+            for (int x = 0; x < 8; ++x) { double m = 0, mx = 0; int c = 0; for (int i = x; i < 2048; i += 8) { m += fin[i]; mx = std::max(mx, fin[i]); ++c; } printf("   xcd %d mean finish %.2f max %.2f\n", x, m / c, mx); }
+        }
         time_it("read8 1GiB", [&](int) { hipLaunchKernelGGL(read8, dim3(8192), dim3(256), 0, 0, (const double*)buf, big / 8, d); }, (double)big, 10);
         time_it("fill16 141.8MB same buffer", [&](int) { hipLaunchKernelGGL(fill16, dim3((unsigned)(jb / 16 / 256)), dim3(256), 0, 0, buf, jb / 16); }, (double)jb, 40);
     }
