@@ -81,8 +81,11 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
         }
     } else if (diff == RDHIP_FINITE_DIFF) {
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
+    } else if (diff == RDHIP_USER_DEFINED) {
+        if constexpr (Mdl::HAS_USER_JACOBIAN) return launch_jac_kernel<Fn, T, DefPlan>(jac_chain_kernel<Fn, T, DefPlan>, fn, a);
+        else return RDHIP_ERR_NOT_IMPLEMENTED;           // jacobian!(fun, J, y, x, u) not defined for this model (src/functionbase.jl:257)
     }
-    return RDHIP_ERR_NOT_IMPLEMENTED;
+    return RDHIP_ERR_INVALID_ARG;
 }
 
 template <class Mdl> int dispatch_eval_rule(const Mdl& m, int rule, const LaunchArgs& a) {

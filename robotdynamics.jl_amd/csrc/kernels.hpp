@@ -859,6 +859,100 @@ __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, lon
     jac_tile_loop<Fn, T, Plan, AdLoopBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
+// ---- UserDefined: the integrators' chain rule over continuous stage Jacobians -----------------------------------------
+// src/integration.jl:85-93 (Euler), :149-177 (RK3), :302-337 (RK4); RK2 = explicit midpoint, A_d = I + A2 (I + A1 h/2) h.
+//   dA1 = A1 h ; dA2 = A2 (I + dA1/2) h ; dA3 = A3 (I + dA2/2) h ; dA4 = A4 (I + dA3) h ; A_d = I + (dA1 + 2dA2 + 2dA3 + dA4)/6
+//   dB1 = B1 h ; dB2 = B2 h + A2 dB1 h/2 ; ...                                       B_d =     (dB1 + 2dB2 + 2dB3 + dB4)/6
+// evaluated one column at a time: every product A_i w + B_i w_u is a Jacobian-vector product of the CONTINUOUS model at the
+// stage point x_i (the k_i are computed once per knot point exactly as the reference does), taken matrix-free with a forward
+// dual.  The reference's analytic RigidBody Jacobian (src/rigidbody.jl:260-313) is not executable as written;
+// its blocks equal these products.  Models without a user-defined Jacobian in the reference return NOT_IMPLEMENTED.
+template <class Fn, class T, class Plan> struct ChainBody {
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, RULE = Fn::RULE_ID;
+    using D = Dual<T, 1>;
+    // (A w + B wu) at stage point xs
+    static RD_DEV void jvp(const Fn& fn, const T (&xs)[NX], const T (&u)[NU], const T (&w)[NX], const T (&wu)[NU], T (&o)[NX]) {
+        D xd[NX], ud[NU], fd[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xd[i].v = xs[i]; xd[i].d[0] = w[i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = wu[i]; }
+        fn.m.f(xd, ud, fd);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) o[i] = fd[i].d[0];
+    }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        static_assert(Plan::NCHUNK == 1, "run-time column loops use the single-chunk plan");
+        const T h = fr.h;
+        // stage points (StaticReturn form of the reference: k_i = f(.) h)
+        T x2[NX], x3[NX], x4[NX], k1[NX], k2[NX], k3[NX];
+        if constexpr (RULE != RULE_CONTINUOUS && RULE != RULE_EULER) {
+            fn.m.f(fr.x, fr.u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; x2[i] = fr.x[i] + k1[i] * T(0.5); }
+            if constexpr (RULE == RULE_RK3 || RULE == RULE_RK4) {
+                fn.m.f(x2, fr.u, k2);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; x3[i] = (RULE == RULE_RK3) ? fr.x[i] - k1[i] + k2[i] * T(2) : fr.x[i] + k2[i] * T(0.5); }
+            }
+            if constexpr (RULE == RULE_RK4) {
+                fn.m.f(x3, fr.u, k3);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x4[i] = fr.x[i] + k3[i] * h;
+            }
+        }
+        if (fr.g == 0 && fr.want_y) {
+            T y[NY]; fn.eval(fr.x, fr.u, fr.t, fr.h, y);
+            fr.put_value(NZ, y);
+        }
+        const int c0 = fr.g * NZ / NG, c1 = (fr.g + 1) * NZ / NG;
+        for (int c = c0; c < c1; ++c) {
+            T w[NX], wu[NU], d1[NX], d2[NX], d3[NX], d4[NX], ws[NX], col[NY];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) w[i] = (i == c) ? T(1) : T(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) wu[i] = (NX + i == c && !fr.term) ? T(1) : T(0);   // terminal knot point: control columns are zero
+            jvp(fn, fr.x, fr.u, w, wu, d1);
+            if constexpr (RULE == RULE_CONTINUOUS) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) col[i] = d1[i];
+            } else if constexpr (RULE == RULE_EULER) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) col[i] = w[i] + d1[i] * h;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { d1[i] = d1[i] * h; ws[i] = w[i] + d1[i] * T(0.5); }
+                jvp(fn, x2, fr.u, ws, wu, d2);
+                if constexpr (RULE == RULE_RK2) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = w[i] + d2[i] * h;
+                } else if constexpr (RULE == RULE_RK3) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] - d1[i] + d2[i] * T(2); }
+                    jvp(fn, x3, fr.u, ws, wu, d3);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(4) + d3[i] * h) / T(6);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] + d2[i] * T(0.5); }
+                    jvp(fn, x3, fr.u, ws, wu, d3);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { d3[i] = d3[i] * h; ws[i] = w[i] + d3[i]; }
+                    jvp(fn, x4, fr.u, ws, wu, d4);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(2) + d3[i] * T(2) + d4[i] * h) / T(6);
+                }
+            }
+            fr.put_at(c, col);
+        }
+    }
+};
+template <class Fn, class T, class Plan>
+__global__ void __launch_bounds__(Plan::NG * TILE) jac_chain_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                   const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_tile_loop<Fn, T, Plan, ChainBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+}
+
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
 template <class Fn, class T, class Plan> struct FdBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {

@@ -73,6 +73,7 @@ inline void host_inv3(const double* A, double* Ai) {
 template <class T_> struct Cartpole {
     using T = T_;
     static constexpr int NX = 4, NU = 1;
+    static constexpr bool HAS_USER_JACOBIAN = true;     // test/cartpole_model.jl:32-55
     T mc, mp, l, g;
     static Cartpole make(const double* p) { return Cartpole{T(p[0]), T(p[1]), T(p[2]), T(p[3])}; }
     template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
@@ -91,6 +92,7 @@ template <class T_> struct Cartpole {
 template <class T_, int D> struct DoubleIntegrator {
     using T = T_;
     static constexpr int NX = 2 * D, NU = D;
+    static constexpr bool HAS_USER_JACOBIAN = true;     // test/double_integrator.jl:119-127
     static DoubleIntegrator make(const double*) { return DoubleIntegrator{}; }
     template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
 #pragma unroll
@@ -101,6 +103,7 @@ template <class T_, int D> struct DoubleIntegrator {
 template <class T_, int N_, int M_> struct Linear {
     using T = T_;
     static constexpr int NX = N_, NU = M_;
+    static constexpr bool HAS_USER_JACOBIAN = true;
     T A[N_ * N_], B[N_ * M_];
     static Linear make(const double* p) {
         Linear L;
@@ -129,6 +132,7 @@ enum { WRENCH_SATELLITE = 0, WRENCH_QUADROTOR = 1 };
 template <class T_, int WRENCH, bool BODY, bool DIAGJ = false> struct RigidBody {
     using T = T_;
     static constexpr int NX = 13, NU = (WRENCH == WRENCH_SATELLITE) ? 6 : 4;
+    static constexpr bool HAS_USER_JACOBIAN = true;     // src/rigidbody.jl:260-313 (analytic blocks)
     T mass, inv_mass;
     T J[9], Jinv[9];
     T grav[3];          // mass * gravity (quadrotor)
@@ -187,6 +191,7 @@ inline bool host_is_diag3(const double* A) { return A[1] == 0 && A[2] == 0 && A[
 template <class T_> struct SatellitePair {
     using T = T_;
     static constexpr int NX = 14, NU = 6;
+    static constexpr bool HAS_USER_JACOBIAN = false;    // examples/satellite_pair.jl defines none -> NotImplementedError (src/functionbase.jl:257)
     T J[2][9], Jinv[2][9];
     static SatellitePair make(const double* p) {
         SatellitePair M;
@@ -213,6 +218,7 @@ template <class T_> struct SatellitePair {
 template <class T_> struct LieSatellite {
     using T = T_;
     static constexpr int NX = 7, NU = 3;
+    static constexpr bool HAS_USER_JACOBIAN = false;    // test/liemodel.jl defines none
     T Jd[3], Jdinv[3];
     static LieSatellite make(const double* p) {
         LieSatellite M;
@@ -236,7 +242,7 @@ template <class T_> struct LieSatellite {
 // methods (k_i = f(.) * h ; x + k1/2 ...), src/integration.jl:130-135 and :280-286.
 template <class Mdl, int RULE> struct Fun {
     using T = typename Mdl::T;
-    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, RULE_ID = RULE;
     Mdl m;
     template <class S> RD_DEV void eval(const S* x, const S* u, T /*t*/, T h, S* y) const {
         if constexpr (RULE == RULE_CONTINUOUS) {

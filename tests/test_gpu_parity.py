@@ -71,6 +71,19 @@ def test_golden_dynamics_and_jacobians(name, where):
         RD.jacobian_(RD.InPlace(), RD.FiniteDifference(), dm, J, None, Z)
         scale = max(1.0, np.abs(d["Jd_" + rn]).max())
         np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=1e-6 * scale)
+        # UserDefined: the integrator's chain rule over continuous stage Jacobians == AD through the step to 1e-10
+        # (test/integration_tests.jl:7-18); models without a user Jacobian raise NotImplementedError (src/functionbase.jl:257)
+        if name.startswith(("satpair", "liesat")):
+            with pytest.raises(NotImplementedError):
+                RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), dm, J, Y, Z)
+        else:
+            J.fill(7.0) if isinstance(J, np.ndarray) else J.fill_(7.0)
+            RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), dm, J, Y, Z)
+            np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=TOL * scale)
+            np.testing.assert_allclose(host(Y), d["xn_" + rn], rtol=0, atol=TOL)
+    if not name.startswith(("satpair", "liesat")):
+        RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), model, J, Y, Z)
+        np.testing.assert_allclose(host(J), d["Jc"], rtol=0, atol=TOL * max(1.0, np.abs(d["Jc"]).max()))
 
 
 @pytest.mark.parametrize("tag,mk", [("rigid", RD.Satellite), ("satpair", RD.SatellitePair), ("liesat", RD.LieSatellite)])
@@ -145,6 +158,12 @@ def test_random_vs_oracle_ragged_sizes(name, mk, omk, gen, N):
     np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
     np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
     np.testing.assert_allclose(host(RD.discrete_dynamics(RD.DiscretizedDynamics(model, RD.RK3), Z)), om.discrete_dynamics(O.RK3, Zn, t, dt), rtol=0, atol=TOL)
+    # UserDefined chain rule (src/integration.jl:302-337) against the oracle's literal matrix form of the same formulas
+    J2 = RD.alloc_jacobians(dm, N, Z.data)
+    RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), dm, J2, Y, Z)
+    Ju, Yu = om.jacobian(O.RK4, O.USER, Zn, t, dt)
+    np.testing.assert_allclose(host(J2), Ju, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y), Yu, rtol=0, atol=TOL)
     if N > 2:
         n = RD.state_dim(model)
         assert np.all(host(J)[-1, :, n:] == 0.0)
