@@ -7,6 +7,7 @@
 // These kernels are pure bandwidth (12 non-trivial values per 13x12 G): one thread per OUTPUT element, so every
 // store instruction writes 64 consecutive elements; the quaternion is re-read through L1/L2 (104 B per knot).
 #include "common.hpp"
+#include <cstdint>
 
 namespace rd {
 
@@ -42,6 +43,59 @@ __global__ void __launch_bounds__(256) errstate_clear_kernel(LieDesc d, long lon
         }
     }
     G[idx] = val;
+}
+
+// Tile version of the two "clear" kernels (dense G or dense nablaG, everything overwritten): pure streaming stores, so the
+// per-element index arithmetic of the kernel above (an integer division by a run-time n*e for every 8 bytes) is the cost,
+// not the memory system (measured 1.8 TB/s).  Here a workgroup owns TK knot points: the (TK x per) output tile -- one
+// contiguous slab of G -- is zero-filled in LDS with 16-B writes, ONE lane per knot point scatters its few non-zeros
+// (identity ones + 12 quaternion entries per rotation, or 3 diagonal entries per rotation for nablaG), and the tile leaves
+// as a linear sweep of 16-B-per-lane stores.  One-shot grid (hardware workgroup dispatch balances the CUs).
+// MODE 0: errstate Jacobian (n x e per knot)   MODE 1: nabla errstate Jacobian (e x e per knot)
+template <class T, int MODE, int TK>
+__global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ Xb, int ldxb, T* __restrict__ G) {
+    typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int VN = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    T* tile = reinterpret_cast<T*>(smem_);
+    const int rows = MODE == 0 ? d.n : d.e;
+    const int per = rows * d.e;
+    const long long k0 = (long long)blockIdx.x * TK;
+    const int nk = (int)((N - k0) < TK ? (N - k0) : TK);
+    const int total = nk * per;                              // elements of this tile (TK*per is a multiple of VN: TK = 64)
+    V zero;
+#pragma unroll
+    for (int q = 0; q < VN; ++q) zero[q] = T(0);
+    for (int i = threadIdx.x * VN; i < TK * per; i += 256 * VN) *reinterpret_cast<V*>(tile + i) = zero;
+    __syncthreads();
+    if (threadIdx.x < nk) {
+        T* g = tile + threadIdx.x * per;
+        const T* x = X + (k0 + threadIdx.x) * ldx;
+        if (MODE == 0) {
+            for (int r = 0; r < d.n; ++r) if (d.row_kind[r] == 0) g[r + d.row_col[r] * d.n] = T(1);
+        }
+        for (int rot = 0; rot < d.nrot; ++rot) {
+            const int r0 = d.rot_row0[rot], c0 = d.rot_col0[rot];
+            const T q0 = x[r0], q1 = x[r0 + 1], q2 = x[r0 + 2], q3 = x[r0 + 3];
+            const T inv = rsqrt_<T>(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+            if (MODE == 0) {
+                const T a = q0 * inv, b = q1 * inv, c = q2 * inv, e = q3 * inv;      // L(q) H, q normalised (QuatRotation constructor)
+                T* g0 = g + r0 + c0 * d.n;
+                g0[0] = -b; g0[1] = a;  g0[2] = e;  g0[3] = -c;  g0 += d.n;
+                g0[0] = -c; g0[1] = -e; g0[2] = a;  g0[3] = b;   g0 += d.n;
+                g0[0] = -e; g0[1] = c;  g0[2] = -b; g0[3] = a;
+            } else {
+                const T* bq = Xb + (k0 + threadIdx.x) * ldxb + r0;
+                const T val = -((q0 * bq[0] + q1 * bq[1] + q2 * bq[2] + q3 * bq[3]) * inv);
+                for (int j = 0; j < 3; ++j) g[(c0 + j) * (d.e + 1)] = val;
+            }
+        }
+    }
+    __syncthreads();
+    T* out = G + k0 * per;
+    const int nv = total / VN;
+    for (int i = threadIdx.x; i < nv; i += 256) reinterpret_cast<V*>(out)[i] = reinterpret_cast<const V*>(tile)[i];
+    for (int i = nv * VN + threadIdx.x; i < total; i += 256) out[i] = tile[i];
 }
 
 // reference-exact variant: touch only the pattern entries (ones + rotation blocks), leave the rest of G alone
@@ -136,7 +190,15 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
     if (d.nrot == 0) {   // EuclideanState: G = I (always cleared, src/statevectortype.jl:149-155)
         hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d.n, d.e, N, (T*)G, 1);
     } else if (clear) {
-        hipLaunchKernelGGL((errstate_clear_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
+        constexpr int TK = 64;
+        const size_t lds = (size_t)TK * d.n * d.e * sizeof(T);
+        if (lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
+            auto kern = errstate_tile_kernel<T, 0, TK>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)nullptr, 0, (T*)G);
+        } else {
+            hipLaunchKernelGGL((errstate_clear_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
+        }
     } else {
         const long long per = (d.n - 4 * d.nrot) + 12 * d.nrot;
         hipLaunchKernelGGL((errstate_pattern_kernel<T>), dim3(nblk(N * per)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
@@ -158,6 +220,14 @@ template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long
     if (N == 0) return RDHIP_OK;
     if (d.nrot == 0) {   // EuclideanState: nablaG .= 0 (src/statevectortype.jl:147)
         hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.e * d.e)), dim3(256), 0, s, d.e, d.e, N, (T*)H, 0);
+        return st(hipGetLastError());
+    }
+    constexpr int TK = 64;
+    const size_t lds = (size_t)TK * d.e * d.e * sizeof(T);
+    if (clear && lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
+        auto kern = errstate_tile_kernel<T, 1, TK>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, (T*)H);
         return st(hipGetLastError());
     }
     const long long per = clear ? (long long)d.e * d.e : 9LL * d.nrot;

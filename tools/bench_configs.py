@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""tools/bench_configs.py -- single-GPU timing of every BASELINE.json config and of the secondary kernels, plus the N-sweep
+that shows the launch-bound -> bandwidth-bound transition.  One JSON line per measurement:
+  {"name", "N", "dtype", "us_per_launch", "units_per_s", "alg_bytes", "GBps", "frac_of_8TBps"}
+Kernel time = one HIP-event pair around `reps` back-to-back launches on torch's current stream (what rdhip borrows).
+Outputs rotate over enough buffers to exceed the 256 MiB Infinity Cache when they are large."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "robotdynamics.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import rdhip as RD  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rigid_inputs(N, m, rng, lo=0.0, hi=1.0):
+    q = rng.standard_normal((N, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    u = lo + (hi - lo) * rng.random((N, m))
+    return np.concatenate([rng.random((N, 3)), q, rng.random((N, 6)), u], axis=1)
+
+
+def timed(fn, reps, warm=5):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps    # us
+
+
+def emit(name, N, dtype, us, alg_bytes, extra=None):
+    out = {"name": name, "N": N, "dtype": dtype, "us_per_launch": round(us, 3), "units_per_s": N / (us * 1e-6),
+           "alg_bytes": alg_bytes, "GBps": alg_bytes / (us * 1e-6) / 1e9, "frac_of_8TBps": alg_bytes / (us * 1e-6) / 8e12}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def nbuf_for(bytes_per_buf):
+    return max(2, min(8, int(600e6 // max(bytes_per_buf, 1)) + 1))
+
+
+def jac_case(name, model, Zn, rule, diff, dtype, reps, with_y=True):
+    N = Zn.shape[0]
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    fun = RD.DiscretizedDynamics(model, rule) if rule is not None else model
+    Z = RD.PackedTrajectory(n, m, Zn.astype(dtype), np.arange(N) * 0.1, np.full(N, 0.1)).to(DEV)
+    nb = nbuf_for(N * n * (n + m) * T)
+    Js = [RD.alloc_jacobians(fun, N, Z.data) for _ in range(nb)]
+    Ys = [torch.empty((N, n), dtype=Z.data.dtype, device=DEV) for _ in range(nb)]
+    sig = RD.StaticReturn()
+    us = timed(lambda i: RD.jacobian_(sig, diff, fun, Js[i % nb], Ys[i % nb] if with_y else None, Z), reps)
+    alg = N * ((n + m) * T + 16 + n * (n + m) * T + (n * T if with_y else 0))
+    emit(name, N, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb})
+
+
+def eval_case(name, model, Zn, rule, dtype, reps):
+    N = Zn.shape[0]
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    fun = RD.DiscretizedDynamics(model, rule) if rule is not None else model
+    Z = RD.PackedTrajectory(n, m, Zn.astype(dtype), np.arange(N) * 0.1, np.full(N, 0.1)).to(DEV)
+    nb = nbuf_for(N * n * T)
+    Ys = [torch.empty((N, n), dtype=Z.data.dtype, device=DEV) for _ in range(nb)]
+    us = timed(lambda i: RD.evaluate_(fun, Ys[i % nb], Z), reps)
+    emit(name, N, "f64" if T == 8 else "f32", us, N * ((n + m) * T + 16 + n * T), {"output_buffers": nb})
+
+
+def errstate_case(name, model, Zn, reps, clear):
+    N = Zn.shape[0]
+    n, m, e = RD.state_dim(model), RD.control_dim(model), RD.errstate_dim(model)
+    Z = RD.PackedTrajectory(n, m, Zn, np.arange(N) * 0.1, np.full(N, 0.1)).to(DEV)
+    nb = nbuf_for(N * n * e * 8)
+    Gs = [RD.alloc_errstate_jacobians(model, N, Z.data) for _ in range(nb)]
+    us = timed(lambda i: RD.errstate_jacobian_(model, Gs[i % nb], Z, clear=clear), reps)
+    alg = N * (n * 8 + (n * e * 8 if clear else (n - 4 + 12) * 8))
+    emit(name, N, "f64", us, alg, {"output_buffers": nb, "clear": clear})
+
+
+def rollout_case(name, model, M, K, rule, dtype, reps, rng):
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    Zn = (rigid_inputs(M * K, m, rng) if n == 13 else rng.random((M * K, n + m))).astype(dtype)
+    data = torch.from_numpy(Zn.reshape(M, K, n + m)).to(DEV)
+    t = torch.from_numpy(np.tile(np.arange(K) * 0.01, (M, 1))).to(DEV)
+    dt = torch.full((M, K), 0.01, dtype=torch.float64, device=DEV)
+    fun = RD.DiscretizedDynamics(model, rule)
+    us = timed(lambda i: RD.rollout_(RD.StaticReturn(), fun, {"data": data, "t": t, "dt": dt}), reps, warm=2)
+    emit(name, M * K, "f64" if T == 8 else "f32", us, M * K * ((n + m) * T + 16 + n * T), {"trajectories": M, "knots": K})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sweep", action="store_true", help="also run the N sweep 2^12 .. 2^22 for C2/C3")
+    ap.add_argument("--reps", type=int, default=50)
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(7)
+    f64, f32 = np.float64, np.float32
+    sat, cart, quad = RD.Satellite(), RD.Cartpole(), RD.Quadrotor()
+    AD, FD, UD = RD.ForwardAD(), RD.FiniteDifference(), RD.UserDefined()
+
+    # C2: Cartpole RK4 discrete Jacobian, N = 4096
+    jac_case("C2 cartpole RK4 jacobian ForwardAD", cart, rng.random((4096, 5)), RD.RK4, AD, f64, a.reps)
+    # C3: Satellite RK4 dynamics + Jacobian, N = 65536
+    Zs = rigid_inputs(65536, 6, rng)
+    eval_case("C3 satellite RK4 discrete_dynamics", sat, Zs, RD.RK4, f64, a.reps)
+    eval_case("C3 satellite continuous dynamics", sat, Zs, None, f64, a.reps)
+    jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
+    jac_case("C3 satellite RK4 jacobian ForwardAD (J only)", sat, Zs, RD.RK4, AD, f64, a.reps, with_y=False)
+    jac_case("C3 satellite RK4 jacobian UserDefined (chain rule)", sat, Zs, RD.RK4, UD, f64, a.reps)
+    jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
+    jac_case("C3 satellite continuous jacobian ForwardAD", sat, Zs, None, AD, f64, a.reps)
+    jac_case("C3 satellite RK3 jacobian ForwardAD", sat, Zs, RD.RK3, AD, f64, a.reps)
+    jac_case("satellite full-inertia RK4 jacobian ForwardAD", RD.Satellite(mass=1.5, J=np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), Zs, RD.RK4, AD, f64, a.reps)
+    jac_case("quadrotor RK4 jacobian ForwardAD", quad, rigid_inputs(65536, 4, rng, 0.6, 1.9), RD.RK4, AD, f64, a.reps)
+    # C4: Quadrotor errstate Jacobian, 262144 knot points = 8 x 32768; one rank's share and the whole
+    for N in (32768, 262144):
+        Zq = rigid_inputs(N, 4, rng, 0.6, 1.9)
+        errstate_case(f"C4 quadrotor errstate_jacobian clear=True N={N}", quad, Zq, a.reps, True)
+        errstate_case(f"C4 quadrotor errstate_jacobian reference pattern-only N={N}", quad, Zq, a.reps, False)
+    # C5: mixed-model Monte-Carlo, fp32: 1024 trajectories x 256 knots per GPU, half cartpole / half satellite
+    nk = 512 * 256
+    jac_case("C5 cartpole RK4 jacobian fp32 (512 traj x 256 knots)", cart, rng.random((nk, 5)), RD.RK4, AD, f32, a.reps)
+    jac_case("C5 satellite RK4 jacobian fp32 (512 traj x 256 knots)", sat, rigid_inputs(nk, 6, rng), RD.RK4, AD, f32, a.reps)
+    rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+    rollout_case("C5 cartpole RK4 rollout fp32 512 traj x 256 knots", cart, 512, 256, RD.RK4, f32, 10, rng)
+    rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+    if a.sweep:
+        for p in range(12, 23):
+            N = 1 << p
+            jac_case("sweep satellite RK4 jacobian ForwardAD", sat, rigid_inputs(N, 6, rng), RD.RK4, AD, f64, max(5, min(a.reps, (1 << 24) // N)))
+        for p in range(12, 23, 2):
+            N = 1 << p
+            jac_case("sweep cartpole RK4 jacobian ForwardAD", cart, rng.random((N, 5)), RD.RK4, AD, f64, max(5, min(a.reps, (1 << 25) // N)))
+
+
+if __name__ == "__main__":
+    main()
