@@ -67,7 +67,15 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (UnrollPolicy<Mdl, RULE>::value) {
+        if constexpr (NZ <= 10) {
+            // small models: one wave = 64 knot points x all columns (no per-wave replication of the primal)
+            constexpr size_t lds = SmallLds<Fn, T>::BYTES;
+            auto kern = jac_ad_small_kernel<Fn, T>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+            const long long ntiles = (a.N + TILE - 1) / TILE;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+            return hip_status(hipGetLastError());
+        } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
             constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
             if constexpr (NC > 0) {

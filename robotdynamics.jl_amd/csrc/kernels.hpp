@@ -826,6 +826,73 @@ __global__ void __launch_bounds__(TILE, OCC) jac_ad_wave_kernel(Fn fn, long long
     WaveDispatch<Fn, T, Plan, SL, 0>::go(g, fn, x, u, t, h, term, lds, Jt, Yt, nk, lane);
 }
 
+// ---- small models (n + m <= 10): ONE wave owns 64 knot points and ALL Jacobian columns ---------------------------------
+// For a small model the per-wave column split above replicates the primal (and, for the cartpole, its sin/cos and divisions)
+// once per wave for a few hundred bytes of output.  Here a lane propagates all n+m tangents at once (Dual<T, n+m>, seeds are
+// compile-time constants so structural zeros fold), the wave's 64 x (n x (n+m) + n) results are transposed through a
+// wave-private LDS region and leave as linear 16-B-per-lane sweeps (a wave's J and f(z) tiles are contiguous slabs).
+// Four independent waves per workgroup (no workgroup barrier), one-shot grid.
+template <class Fn, class T> struct SmallLds {
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
+    static constexpr int RS = (NY * NZ + NY) | 1;                       // J then f(z) per lane, odd stride
+    static constexpr size_t WAVE_ELEMS = (size_t)TILE * RS;
+    static constexpr size_t BYTES = 4 * WAVE_ELEMS * sizeof(T);
+};
+template <class Fn, class T>
+__global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, JN = NY * NZ;
+    using L = SmallLds<Fn, T>;
+    using D = Dual<T, NZ>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    T* lds = reinterpret_cast<T*>(smem) + wave * L::WAVE_ELEMS;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long k0 = tile * TILE;
+    if (k0 >= N) return;
+    const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+    const int kl = lane < nk ? lane : nk - 1;
+    // stage z: lane-contiguous loads of the tile's nk*NZ values -> LDS -> one knot point per lane
+    for (int e = lane; e < nk * NZ; e += TILE) lds[e] = Z[k0 * NZ + e];
+    const double hd = dtt[k0 + kl];
+    const T t = (T)tt[k0 + kl], h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    wave_sync();
+    D xd[NX], ud[NU], yd[NY];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        xd[i].v = lds[kl * NZ + i];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) xd[i].d[j] = (i == j) ? T(1) : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        ud[i].v = term ? T(0) : lds[kl * NZ + NX + i];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) ud[i].d[j] = (NX + i == j) ? T(1) : T(0);
+    }
+    wave_sync();                                            // everybody has read its inputs: the region becomes the output tile
+    fn.eval(xd, ud, t, h, yd);
+    T* row = lds + lane * L::RS;
+#pragma unroll
+    for (int c = 0; c < NZ; ++c) {
+        const T sc = (c >= NX && term) ? T(0) : T(1);       // control columns of a terminal knot point are zero
+#pragma unroll
+        for (int i = 0; i < NY; ++i) row[c * NY + i] = yd[i].d[c] * sc;
+    }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) row[JN + i] = yd[i].v;
+    wave_sync();
+    // copy-out: element e of the J tile is (knot e / JN, offset e % JN); consecutive lanes -> consecutive addresses
+    T* Jt = J + k0 * JN;
+    for (int e = lane; e < nk * JN; e += TILE) { const int r = e / JN; Jt[e] = lds[r * L::RS + (e - r * JN)]; }
+    if (Y) {
+        T* Yt = Y + k0 * NY;
+        for (int e = lane; e < nk * NY; e += TILE) { const int r = e / NY; Yt[e] = lds[r * L::RS + JN + (e - r * NY)]; }
+    }
+}
+
 // ---- ForwardAD, run-time column loop (compact code for the long tail of model x rule combinations) -----------
 template <class Fn, class T, class Plan> struct AdLoopBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
