@@ -5,7 +5,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
-#include "../kernels.hpp"
+#include "experimental_kernels.hpp"
 
 using namespace rd;
 #ifndef TUNE_DIAGJ
@@ -44,6 +44,15 @@ template <class Plan, int NC> void launch_split2(const Fn& fn, long long N, cons
     if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_split2_kernel<Fn, double, Plan, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
     const long long ntiles = (N + TILE - 1) / TILE;
     hipLaunchKernelGGL((jac_ad_split2_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
+}
+template <class Plan> void launch_split3(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {
+    using L3 = Split3Lds<Fn, double, Plan>;
+    constexpr size_t lds = L3::BYTES;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool init = false;
+    if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_split3_kernel<Fn, double, Plan>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
+    const long long ntiles = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL((jac_ad_split3_kernel<Fn, double, Plan>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + 4) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
 }
 // two-chunk plans: chunk 0 = r,q,v,w10,w11 (cols 0-11), chunk 1 = w12,uF,tau (+ f(z)).  wave table per chunk:
 //   chunk 0: q3,q4 -> 0 ; q5,q6 -> 1 ; w10 (+r) -> 2 ; w11 (+v) -> 3        chunk 1: w12 -> 0 ; tau16,uF13 -> 1 ; tau17,uF14 -> 2 ; tau18,uF15 (+y) -> 3
@@ -229,7 +238,8 @@ int main(int argc, char** argv) {
         printf("phase stamps (us since first compute start), %d events per tile; C = compute wave 0..3, K = copy wave 4\n", STAMP_EV);
         for (int b : {0, 1, 37, 128, 255}) {
             for (int w = 0; w < 4; ++w) { printf(" blk %3d C%d:", b, w); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + w) * 64 + e])); printf("\n"); }
-            printf("         K :"); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + 4) * 64 + e])); printf("  done %6.2f\n", us(h[(b * 8 + 4) * 64 + 60]));
+            printf("         K4:"); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + 4) * 64 + e])); printf("  done %6.2f\n", us(h[(b * 8 + 4) * 64 + 60]));
+            printf("         K6:"); for (int e = 0; e < NE; ++e) printf(" %6.2f", us(h[(b * 8 + 6) * 64 + e])); printf("\n");
         }
         std::vector<double> done; std::vector<double> dsum(STAMP_EV, 0.0), ksum(STAMP_EV, 0.0); int cn = 0;
         for (int b = 0; b < 256; ++b) {
