@@ -97,16 +97,24 @@ def main():
     ap.add_argument("--gather", choices=["none", "all", "root"], default="all", help="also time the RCCL exchange of the stacked Jacobians (N>1 only; reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank, local_rank, world = P.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the scalar MAX-reductions live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     N = args.knots
     Zn, t, dt = synthetic_inputs(N, seed=3 + rank)
@@ -144,14 +152,14 @@ def main():
     elapsed = _time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     value = world * N * args.steps / elapsed
 
     gather = None
-    if world > 1 and args.gather != "none":
+    if world > 1 and args.gather != "none" and args.backend == "nccl":
         reps = 5
         P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)     # warm (dense (N, n+m, n) slabs)
         torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
@@ -160,7 +168,7 @@ def main():
             step(i)
             P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
         torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=dev)
+        gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(gl, op=dist.ReduceOp.MAX)
         gather = {"mode": args.gather, "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps,
                   "bytes_per_rank": N * NX * NZ * 8}
