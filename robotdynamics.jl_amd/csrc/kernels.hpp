@@ -302,6 +302,9 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 #pragma unroll
                 for (int i = 0; i < NY; ++i) col[i] = yd[i].d[0] * sc;
                 fr.put_at(C - C0, col);
+#if defined(RD_COL_BARRIER)
+                __builtin_amdgcn_sched_barrier(0);          // finish this column before the scheduler starts interleaving the next one (register pressure)
+#endif
                 AdCols<Fn, T, Plan, CH, G, C + 1, false>::run(fn, fr);
             } else {
                 AdCols<Fn, T, Plan, CH, G, C + 1, VALUE_PENDING>::run(fn, fr);
