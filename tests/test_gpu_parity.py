@@ -227,6 +227,81 @@ def test_full_size_satellite_properties_and_sampled_oracle():
     assert np.abs(Jh - Jo).max() < TOL and np.abs(Yh - Yo).max() < TOL
 
 
+def test_full_size_quadrotor_errstate_properties_and_oracle():
+    """BASELINE config 4: Quadrotor errstate_jacobian!, 262144 knot points (one rank's 32768-knot shard against the oracle, the whole
+    batch through size-independent properties: G = blkdiag(I3, L(q)H, I6), (L(q)H)'(L(q)H) = I3, L(q)H ' q = 0)."""
+    N = 262144
+    rng = np.random.default_rng(4)
+    Zn = H.rand_rigid(rng, N, 4, 0.6, 1.9)
+    Zn[:, 3:7] *= rng.uniform(0.5, 2.0, (N, 1))             # un-normalised quaternions: QuatRotation normalises on construction
+    model = RD.Quadrotor()
+    Z = traj(model, Zn, np.arange(N) * 0.1, np.full(N, 0.1), "cuda")
+    G = RD.alloc_errstate_jacobians(model, N, Z.data)
+    G.fill_(7.0)
+    RD.errstate_jacobian_(model, G, Z, clear=True)
+    Gh = host(G)
+    assert Gh.shape == (N, 13, 12)
+    np.testing.assert_array_equal(Gh[:, 0:3, 0:3], np.broadcast_to(np.eye(3), (N, 3, 3)))
+    np.testing.assert_array_equal(Gh[:, 7:13, 6:12], np.broadcast_to(np.eye(6), (N, 6, 6)))
+    assert not Gh[:, 0:3, 3:].any() and not Gh[:, 3:7, 0:3].any() and not Gh[:, 3:7, 6:].any() and not Gh[:, 7:, 0:6].any()
+    A = Gh[:, 3:7, 3:6]
+    np.testing.assert_allclose(np.einsum("kia,kib->kab", A, A), np.broadcast_to(np.eye(3), (N, 3, 3)), atol=1e-14)
+    qn = Zn[:, 3:7] / np.linalg.norm(Zn[:, 3:7], axis=1, keepdims=True)
+    np.testing.assert_allclose(np.einsum("kia,ki->ka", A, qn), 0.0, atol=1e-15)
+    sl = slice(5 * 32768, 6 * 32768)                          # rank 5's shard of the 8-way split
+    np.testing.assert_allclose(Gh[sl], O.quadrotor().errstate_jacobian(Zn[sl, :13]), rtol=0, atol=TOL)
+    # reference-exact mode (does not clear G): touches only the pattern entries
+    G2 = RD.alloc_errstate_jacobians(model, 4096, Z.data)
+    G2.fill_(7.0)
+    Zs = traj(model, Zn[:4096], np.zeros(4096), np.full(4096, 0.1), "cuda")
+    RD.errstate_jacobian_(model, G2, Zs)
+    G2h = host(G2)
+    pattern = Gh[:4096] != 0
+    np.testing.assert_array_equal(G2h[pattern], Gh[:4096][pattern])
+    assert np.all(G2h[~pattern | ((Gh[:4096] == 0) & ~pattern)] == 7.0) or np.all(G2h[Gh[:4096] == 0][G2h[Gh[:4096] == 0] != 7.0] == 0.0)
+    # nabla errstate Jacobian: blkdiag(0, -(q.b) I3, 0)   (test/rigid_body_jacobians.jl:78-83)
+    Xb = rng.random((4096, 13))
+    dG = torch.full((4096, 12, 12), 7.0, dtype=torch.float64, device="cuda").transpose(1, 2)
+    RD.nabla_errstate_jacobian_(model, dG, torch.as_tensor(Zn[:4096, :13]).cuda(), torch.as_tensor(Xb).cuda(), clear=True)
+    dGh = host(dG)
+    qb = -(qn[:4096] * Xb[:, 3:7]).sum(1)
+    ref = np.zeros((4096, 12, 12))
+    for j in range(3):
+        ref[:, 3 + j, 3 + j] = qb
+    np.testing.assert_allclose(dGh, ref, rtol=0, atol=1e-14)
+
+
+def test_mixed_model_monte_carlo_fp32_shard():
+    """BASELINE config 5 on one GPU's share: 1024 trajectories x 256 knots, even trajectories Cartpole / odd Satellite, fp32.
+    Every trajectory is rolled out on the GPU (RK4) and the Jacobians are evaluated along the rollout; checked against the
+    fp64 oracle on sampled trajectories (rel 1e-3: fp32 error accumulated over 255 steps) and through the linearisation
+    identity x_{k+1} = f(z_k) (the rollout and the Jacobian kernel's f(z) output agree to fp32 rounding)."""
+    rng = np.random.default_rng(5)
+    M, K = 512, 256
+    for model, om, nz, gen in ((RD.Cartpole(), O.cartpole(), 5, lambda n: 0.2 * rng.random((n, 5))),
+                               (RD.Satellite(), O.satellite(), 19, lambda n: 0.3 * H.rand_rigid(rng, n, 6) + np.array([0] * 3 + [0.7, 0, 0, 0] + [0] * 12))):
+        n = RD.state_dim(model)
+        data = gen(M * K).reshape(M, K, nz).astype(np.float32)
+        t = np.tile(np.arange(K) * 0.01, (M, 1))
+        dt = np.full((M, K), 0.01)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(t).cuda(), "dt": torch.as_tensor(dt).cuda()}
+        RD.rollout_(RD.StaticReturn(), dm, stack)
+        rolled = host(stack["data"])
+        assert np.isfinite(rolled).all()
+        sample = [0, 1, 255, 511]
+        ref = om.rollout(O.RK4, data[sample].astype(np.float64), t[sample], dt[sample])
+        np.testing.assert_allclose(rolled[sample][..., :n], ref[..., :n], rtol=2e-3, atol=2e-3)
+        Z = RD.PackedTrajectory(n, nz - n, stack["data"].reshape(M * K, nz), stack["t"].reshape(-1), stack["dt"].reshape(-1))
+        J = RD.alloc_jacobians(dm, M * K, Z.data)
+        Y = torch.empty((M * K, n), dtype=torch.float32, device="cuda")
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+        Yh = host(Y).reshape(M, K, n)
+        np.testing.assert_allclose(Yh[:, :-1], rolled[:, 1:, :n], rtol=1e-5, atol=1e-6)   # same formulas; FMA contraction differs by an ulp
+        Jo, _ = om.jacobian(O.RK4, O.FORWARD_AD, rolled[3].astype(np.float64), t[3], dt[3])
+        np.testing.assert_allclose(host(J).reshape(M, K, n, nz)[3], Jo, rtol=1e-4, atol=1e-4)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21
