@@ -127,6 +127,21 @@ int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, 
 int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                    const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);
 
+/* dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2) (src/discrete_dynamics.jl:134-135; in-place :146-156) for
+ * the N-1 consecutive knot-point pairs (z1, z2) = (Z[k], Z[k+1]) of a packed trajectory: E[:, k] = f(z_k) - x_{k+1}, k = 0..N-2.
+ * E: n x (N-1).  N < 2 is a no-op. */
+int rdhip_dynamics_error(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
+                         const void* Z, const double* t, const double* dt, void* E, int memspace);
+
+/* dynamics_error_jacobian!(sig, diff, model, J2, J1, y2, y1, z2, z1) (src/discrete_dynamics.jl:158-201; generated for ForwardAD /
+ * FiniteDifference at src/jacobian_gen.jl:556-588,:714-745) for the same N-1 pairs and an explicit rule:
+ *   J1[k] = d e_k / d z_k     = [A_k  B_k]   (the discrete dynamics Jacobian at z_k),
+ *   J2[k] = d e_k / d z_{k+1} = [-I   0  ]   ("for explicit integration methods J2 should be equal to [-I(n) zeros(n,m)]", :176-177).
+ * J1, J2: n x (n+m) x (N-1), either may be NULL (skipped); E: n x (N-1) or NULL receives the error itself (what the reference's
+ * InPlace methods leave in y2). */
+int rdhip_dynamics_error_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
+                                  const void* Z, const double* t, const double* dt, void* J2, void* J1, void* E, int memspace);
+
 /* errstate_jacobian!(model, G, x) (v0.3: state_diff_jacobian!(G, model, z)): src/statevectortype.jl:119-122,149-155,
  * src/liestate.jl:262-298.  X: states, column k at X + k*ldx (ldx >= n; pass Z with ldx = n+m to read states out of
  * a packed trajectory).  G: n x e x N column-major.  clear != 0: G is fully overwritten (zeros elsewhere);

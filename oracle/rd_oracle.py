@@ -157,6 +157,20 @@ class Model:
             raise NotImplementedError(f"oracle_jacobian rc={rc}")
         return J.transpose(0, 2, 1), Y
 
+    def dynamics_error(self, rule, Z, t, dt):
+        """dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2) for consecutive pairs of one trajectory
+        (reference src/discrete_dynamics.jl:134-135).  Z (N, n+m) -> (N-1, n)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        return self.discrete_dynamics(rule, Z[:-1], np.asarray(t)[:-1], np.asarray(dt)[:-1]) - Z[1:, :self.n]
+
+    def dynamics_error_jacobian(self, rule, diff, Z, t, dt):
+        """(J2, J1, e): J1 = [A B] at z1, J2 = [-I 0] (reference src/discrete_dynamics.jl:170-177)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        J1, y = self.jacobian(rule, diff, Z[:-1], np.asarray(t)[:-1], np.asarray(dt)[:-1])
+        J2 = np.zeros_like(J1)
+        J2[:, np.arange(self.n), np.arange(self.n)] = -1.0
+        return J2, J1, y - Z[1:, :self.n]
+
     def errstate_jacobian(self, X, clear=True, G0=None):
         """G0: optional (N, n, e) initial content (the reference does not clear G)."""
         X = np.ascontiguousarray(X, dtype=np.float64)

@@ -336,6 +336,41 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
     return s.finish(kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what));
 }
 
+// dynamics_error / dynamics_error_jacobian!: the discrete dynamics (Jacobian) of the first N-1 knot points, minus the next state
+static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
+                         void* J2, void* J1, void* E, bool want_jac, int memspace, const char* what) {
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: an explicit quadrature rule is required (got %d)", what, rule);
+    if (want_jac && (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
+    const long long P = N - 1;
+    if (P <= 0) return RDHIP_OK;
+    if (!Z || !t || !dt || (!want_jac && !E)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d; const int nz = d.n + d.m;
+    Stage s(c);
+    const void* dZ = Z; const double* dtm = t; const double* ddt = dt; void* dJ2 = J2; void* dJ1 = J1; void* dE = E;
+    if (memspace == RDHIP_HOST) {
+        dZ = s.in(Z, (size_t)N * nz * ts); dtm = (const double*)s.in(t, (size_t)N * 8); ddt = (const double*)s.in(dt, (size_t)N * 8);
+        dJ2 = s.out(J2, (size_t)P * d.n * nz * ts); dJ1 = s.out(J1, (size_t)P * d.n * nz * ts); dE = s.out(E, (size_t)P * d.n * ts);
+        if (s.rc) return s.rc;
+    }
+    LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = dZ; a.t = dtm; a.dt = ddt;
+    int k = RDHIP_OK;
+    if (want_jac && dJ1) { a.J = dJ1; a.Y = dE; k = family_jacobian(d, rule, diff, dtype, a); }       // f(z_k) lands in E
+    else if (dE) { a.Y = dE; k = family_eval(d, rule, dtype, a); }
+    if (k == RDHIP_OK && dE) k = launch_sub_next_state(dtype, c->stream, P, d.n, nz, dZ, dE);
+    if (k == RDHIP_OK && want_jac && dJ2) k = launch_fill_neg_identity(dtype, c->stream, P, d.n, nz, dJ2);
+    k = kernel_status(c, k, what);
+    return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
+int rdhip_dynamics_error(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt, void* E, int memspace) {
+    return dynerr_common(c, M, rule, RDHIP_FORWARD_AD, dtype, N, Z, t, dt, nullptr, nullptr, E, false, memspace, "rdhip_dynamics_error");
+}
+int rdhip_dynamics_error_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
+                                  void* J2, void* J1, void* E, int memspace) {
+    return dynerr_common(c, M, rule, diff, dtype, N, Z, t, dt, J2, J1, E, true, memspace, "rdhip_dynamics_error_jacobian");
+}
+
 int rdhip_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, int clear, void* G, int memspace) {
     const char* what = "rdhip_errstate_jacobian";
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;

@@ -50,6 +50,9 @@ struct LieDesc {
 };
 int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G);
 int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX);
+// dynamics-error helpers (errstate.hip): E[:,k] -= Z[0:n, k+1] ; J2[k] = [-I 0]
+int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E);
+int launch_fill_neg_identity(int dtype, hipStream_t s, long long pairs, int n, int nz, void* J2);
 int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H);
 
 }  // namespace rd

@@ -182,6 +182,25 @@ __global__ void __launch_bounds__(256) fill_identity_kernel(int n, int e, long l
     G[idx] = (identity && (rc / n) == (rc % n)) ? T(1) : T(0);
 }
 
+// E[i, k] -= Z[i, k+1]  (i < n): one thread per element, consecutive threads -> consecutive addresses of E
+template <class T>
+__global__ void __launch_bounds__(256) sub_next_state_kernel(long long pairs, int n, int nz, const T* __restrict__ Z, T* __restrict__ E) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pairs * n) return;
+    const long long k = idx / n;
+    const int i = (int)(idx - k * n);
+    E[idx] -= Z[(k + 1) * nz + i];
+}
+// J2[:, :, k] = [-I 0], n x nz column-major
+template <class T>
+__global__ void __launch_bounds__(256) fill_neg_identity_kernel(long long pairs, int n, int nz, T* __restrict__ J2) {
+    const long long per = (long long)n * nz;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pairs * per) return;
+    const int rc = (int)(idx % per);
+    J2[idx] = ((rc / n) == (rc % n)) ? T(-1) : T(0);
+}
+
 static inline int st(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_ERR_HIP; }
 static inline unsigned nblk(long long work) { return (unsigned)((work + 255) / 256); }
 
@@ -236,6 +255,19 @@ template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long
 }
 int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H) {
     return dtype == RDHIP_F64 ? nabla_T<double>(d, s, N, X, ldx, Xb, ldxb, clear, H) : nabla_T<float>(d, s, N, X, ldx, Xb, ldxb, clear, H);
+}
+
+int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E) {
+    if (pairs <= 0) return RDHIP_OK;
+    if (dtype == RDHIP_F64) hipLaunchKernelGGL((sub_next_state_kernel<double>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const double*)Z, (double*)E);
+    else hipLaunchKernelGGL((sub_next_state_kernel<float>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const float*)Z, (float*)E);
+    return st(hipGetLastError());
+}
+int launch_fill_neg_identity(int dtype, hipStream_t s, long long pairs, int n, int nz, void* J2) {
+    if (pairs <= 0) return RDHIP_OK;
+    if (dtype == RDHIP_F64) hipLaunchKernelGGL((fill_neg_identity_kernel<double>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (double*)J2);
+    else hipLaunchKernelGGL((fill_neg_identity_kernel<float>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (float*)J2);
+    return st(hipGetLastError());
 }
 
 }  // namespace rd

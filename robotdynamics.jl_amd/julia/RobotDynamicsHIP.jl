@@ -197,6 +197,21 @@ function RD.errstate_jacobian!(fun::RD.AbstractModel, G::Array{T,3}, Z::PackedTr
     check(ctx, rc)
 end
 
+# dynamics_error_jacobian!(sig, diff, model, J2[:,:,k], J1[:,:,k], y2[:,k], y1, Z[k+1], Z[k]) for all consecutive pairs
+# (src/discrete_dynamics.jl:158-201): J1 = [A B] at Z[k], J2 = [-I 0], y2 = f(Z[k]) - state(Z[k+1])
+function RD.dynamics_error_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.DiscretizedDynamics, J2::Array{T,3}, J1::Array{T,3},
+                                     Y2::Union{Nothing,Matrix{T}}, Y1, Z::PackedTrajectory{n,m,T}; ctx::Context=default_context()) where {n,m,T}
+    N = length(Z)
+    size(J1) == size(J2) == (n, n + m, N - 1) || throw(DimensionMismatch("J1, J2 must be n x (n+m) x (N-1)"))
+    GC.@preserve J2 J1 Y2 Z begin
+        rc = ccall((:rdhip_dynamics_error_jacobian, librdhip), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Clonglong, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   ctx.ptr, handle(fun), rulecode(fun), diffcode(diff), dtypecode(T), N, Z.data, Z.t, Z.dt, J2, J1,
+                   Y2 === nothing ? C_NULL : pointer(Y2), HOST)
+    end
+    check(ctx, rc)
+end
+
 # v0.3 spellings (README.md:73-82,128-136; SURVEY.md App. B)
 discrete_jacobian!(::Type{Q}, D::Array{T,3}, model::RD.ContinuousDynamics, Z::PackedTrajectory{n,m,T}) where {Q<:RD.QuadratureRule,n,m,T} =
     RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics{Q}(model), D, nothing, Z)

@@ -1046,6 +1046,80 @@ def discrete_jacobian_(Q, J, model, z):
     return jacobian_(default_signature(fun), ForwardAD(), fun, J, None, z)
 
 
+def _pair_traj(fun, z2, z1):
+    """(z2, z1) knot points -> the two-knot PackedTrajectory [z1, z2]."""
+    if not (isinstance(z2, AbstractKnotPoint) and isinstance(z1, AbstractKnotPoint)):
+        raise TypeError("expected two knot points (z2, z1)")
+    data = np.ascontiguousarray(np.stack([np.asarray(z1.z, dtype=np.float64), np.asarray(z2.z, dtype=np.float64)]))
+    return PackedTrajectory(z1.n, z1.m, data, [z1.t, z2.t], [z1.dt, z2.dt])
+
+
+def dynamics_error(fun, *args):
+    """dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2): src/discrete_dynamics.jl:134-135.
+    dynamics_error(model, Z) with a PackedTrajectory returns the (N-1, n) errors of all consecutive pairs (Z[k], Z[k+1])."""
+    model, rule = _model_rule(fun)
+    if rule == L.CONTINUOUS:
+        raise TypeError("dynamics_error needs a DiscreteDynamics model")
+    single = len(args) == 2
+    Z = _pair_traj(fun, *args) if single else args[0]
+    n, m = _check_traj(fun, Z)
+    N = len(Z)
+    E = _empty_like_data(Z.data, (max(N - 1, 0), n))
+    if N >= 2:
+        az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+        ae = _Arg(E, "E", az.dtype)
+        ctx, space = _resolve_ctx([az, at, adt, ae])
+        L.check(L.lib().rdhip_dynamics_error(ctx.handle, model._handle, rule, az.dtype, N, az.ptr, at.ptr, adt.ptr, ae.ptr, space), ctx.handle)
+    return E[0] if single else E
+
+
+def dynamics_error_(fun, y2, y1, *args):
+    """dynamics_error!(model, y2, y1, z2, z1): src/discrete_dynamics.jl:146-156 (y1 is scratch in the reference; unused here)."""
+    y2[...] = dynamics_error(fun, *args)
+    return None
+
+
+def dynamics_error_jacobian_(sig, diff, fun, J2, J1, y2, y1, *args):
+    """dynamics_error_jacobian!(sig, diff, model, J2, J1, y2, y1, z2, z1): src/discrete_dynamics.jl:158-201.  Explicit rules:
+    J1 = [A B] at z1, J2 = [-I 0].  Batched form: pass ONE PackedTrajectory instead of (z2, z1); J2, J1 are (N-1, n, n+m) stacks
+    from alloc_jacobians (either may be None), y2 (N-1, n) or None receives the error, y1 is ignored."""
+    if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+        raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+    model, rule = _model_rule(fun)
+    if rule == L.CONTINUOUS:
+        raise TypeError("dynamics_error_jacobian! needs a DiscreteDynamics model")
+    if len(args) == 2:
+        Z = _pair_traj(fun, *args)
+        n, m = _check_traj(fun, Z)
+        J2b, J1b = alloc_jacobians(fun, 1, Z.data), alloc_jacobians(fun, 1, Z.data)
+        yb = np.empty((1, n))
+        dynamics_error_jacobian_(sig, diff, fun, J2b, J1b, yb, None, Z)
+        if J2 is not None:
+            get_data(J2)[...] = J2b[0]
+        if J1 is not None:
+            get_data(J1)[...] = J1b[0]
+        if y2 is not None:
+            y2[...] = yb[0]
+        return None
+    Z = args[0]
+    n, m = _check_traj(fun, Z)
+    N = len(Z)
+    P = max(N - 1, 0)
+    for name, Jx in (("J2", J2), ("J1", J1)):
+        if Jx is not None:
+            _dense(Jx, (P, n, n + m), name, transposed_last2=True)
+    if y2 is not None:
+        _dense(y2, (P, n), "y2")
+    if N < 2:
+        return None
+    az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+    a2, a1, ay = _Arg(J2, "J2", az.dtype), _Arg(J1, "J1", az.dtype), _Arg(y2, "y2", az.dtype)
+    ctx, space = _resolve_ctx([az, at, adt, a2, a1, ay])
+    L.check(L.lib().rdhip_dynamics_error_jacobian(ctx.handle, model._handle, rule, diff.code, az.dtype, N, az.ptr, at.ptr, adt.ptr,
+                                                  a2.ptr, a1.ptr, ay.ptr, space), ctx.handle)
+    return None
+
+
 def _states_of(model, x):
     """(array, ld, N, single): states from a PackedTrajectory / KnotPoint / (N, >=n) array / single vector."""
     n = state_dim(model)

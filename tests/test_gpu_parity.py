@@ -302,6 +302,44 @@ def test_mixed_model_monte_carlo_fp32_shard():
         np.testing.assert_allclose(host(J).reshape(M, K, n, nz)[3], Jo, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_dynamics_error_and_jacobian(where):
+    """dynamics_error / dynamics_error_jacobian! (src/discrete_dynamics.jl:134-201): e_k = f(z_k) - x_{k+1}, J1 = [A B], J2 = [-I 0];
+    a rolled-out trajectory has zero dynamics error (test/discrete_dynamics_test.jl pattern)."""
+    rng = np.random.default_rng(11)
+    for model, om, Zn in ((RD.Cartpole(), O.cartpole(), rng.random((130, 5))), (RD.Satellite(), O.satellite(), H.rand_rigid(rng, 130, 6))):
+        N = Zn.shape[0]
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        Z = traj(model, Zn, t, dt, "cuda" if where == "cuda" else None)
+        np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), om.dynamics_error(O.RK4, Zn, t, dt), rtol=0, atol=TOL)
+        J2, J1 = RD.alloc_jacobians(dm, N - 1, Z.data), RD.alloc_jacobians(dm, N - 1, Z.data)
+        y2 = RD.evaluate(dm, Z)[: N - 1] * 0 + 5
+        for diff, tol in ((RD.ForwardAD(), TOL), (RD.UserDefined(), TOL), (RD.FiniteDifference(), 1e-5)):
+            RD.dynamics_error_jacobian_(RD.StaticReturn(), diff, dm, J2, J1, y2, None, Z)
+            J2o, J1o, eo = om.dynamics_error_jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+            np.testing.assert_array_equal(host(J2), J2o)
+            np.testing.assert_allclose(host(J1), J1o, rtol=0, atol=tol * max(1.0, np.abs(J1o).max()))
+            np.testing.assert_allclose(host(y2), eo, rtol=0, atol=TOL)
+        # per-knot form reads like the reference
+        z1, z2 = RD.KnotPoint(Zn[3, :n], Zn[3, n:], t[3], dt[3]), RD.KnotPoint(Zn[4, :n], Zn[4, n:], t[4], dt[4])
+        np.testing.assert_allclose(RD.dynamics_error(dm, z2, z1), om.dynamics_error(O.RK4, Zn[3:5], t[3:5], dt[3:5])[0], rtol=0, atol=TOL)
+        D2, D1 = RD.DynamicsJacobian(n, m), RD.DynamicsJacobian(n, m)
+        RD.dynamics_error_jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, D2, D1, np.zeros(n), np.zeros(n), z2, z1)
+        np.testing.assert_allclose(np.asarray(D1), J1o[3], rtol=0, atol=TOL)
+        np.testing.assert_array_equal(np.asarray(D2), J2o[3])
+        # rollout => zero error
+        stack = {"data": np.ascontiguousarray(Zn[None].copy()), "t": t[None].copy(), "dt": dt[None].copy()}
+        if where == "cuda":
+            stack = {k: torch.as_tensor(v).cuda() for k, v in stack.items()}
+        RD.rollout_(RD.StaticReturn(), dm, stack)
+        Zr = RD.PackedTrajectory(n, m, stack["data"][0], stack["t"][0], stack["dt"][0])
+        assert np.abs(host(RD.dynamics_error(dm, Zr))).max() < 1e-13
+    with pytest.raises(TypeError):
+        RD.dynamics_error(RD.Cartpole(), Z)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21
