@@ -1,0 +1,29 @@
+// fam_rigid.hpp -- shared by the rigid-body translation units: model aliases, column plans and the per-variant entry points.
+// Each (wrench, velocity frame, inertia structure) variant is its own translation unit so that the compile-time-column
+// ForwardAD kernels (one instantiation per rule and dtype, ~10-20 s each) build in parallel.
+#pragma once
+#include "dispatch.hpp"
+namespace rd {
+// Satellite columns: r 0-2, q 3-6, v 7-9, w 10-12, uF 13-15, tau 16-18.  Measured fp64 instruction counts per column of the RK4
+// tangent (diagonal J): r 0, v 2, q ~225, w ~343, uF ~57, tau ~257 (+ ~150-200 shared per wave) -> four waves of ~850-950
+// instead of 380/840/1260/1020 for contiguous ranges:  wave 0: r, q3-q5, v   wave 1: w10, w11   wave 2: q6, w12, uF (+ f(z))   wave 3: tau
+using SatPlan = TablePlan<19, 4, 2, /*r*/ 0, 0, 0, /*q*/ 0, 0, 0, 2, /*v*/ 0, 0, 0, /*w*/ 1, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
+// Quadrotor columns: r 0-2, q 3-6, v 7-9, w 10-12, u 13-16 (each rotor thrust feeds both F and tau)
+using QuadPlan = TablePlan<17, 4, 0, /*r*/ 0, 0, 0, /*q*/ 0, 0, 0, 1, /*v*/ 0, 0, 0, /*w*/ 1, 2, 2, /*u*/ 3, 3, 3, 1>;
+// every rule of the rigid bodies gets the compile-time-column (structural zeros folded) split-role kernel
+template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
+template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
+
+#define RD_RIGID_VARIANT_DECL(name)                                                                       \
+    int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                       \
+    int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);         \
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+#define RD_RIGID_VARIANT_DEFINE(name, WRENCH, BODY, DIAG)                                                 \
+    template <class T> using name##_M = RigidBody<T, WRENCH, BODY, DIAG>;                                 \
+    int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_eval<name##_M>(md, rule, dtype, a); } \
+    int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_jacobian<name##_M>(md, rule, diff, dtype, a); } \
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); }
+RD_RIGID_VARIANT_DECL(sat_wd) RD_RIGID_VARIANT_DECL(sat_wf) RD_RIGID_VARIANT_DECL(sat_bd) RD_RIGID_VARIANT_DECL(sat_bf)
+RD_RIGID_VARIANT_DECL(quad_wd) RD_RIGID_VARIANT_DECL(quad_wf) RD_RIGID_VARIANT_DECL(quad_bd) RD_RIGID_VARIANT_DECL(quad_bf)
+inline bool diag_inertia(const ModelDesc& md) { return host_is_diag3(md.params + 1); }
+}  // namespace rd
