@@ -9,7 +9,7 @@ namespace rd {
 inline int hip_status(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_ERR_HIP; }
 
 // which (model, rule) pairs get the compile-time-column ForwardAD kernel (big code, structural sparsity folded)
-template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; };
+template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; static constexpr int NC = 0; using Plan = void; };
 
 template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
@@ -90,7 +90,15 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     } else if (diff == RDHIP_FINITE_DIFF) {
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
     } else if (diff == RDHIP_USER_DEFINED) {
-        if constexpr (Mdl::HAS_USER_JACOBIAN) return launch_jac_kernel<Fn, T, DefPlan>(jac_chain_kernel<Fn, T, DefPlan>, fn, a);
+        if constexpr (Mdl::HAS_USER_JACOBIAN) {
+            if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
+                using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+                constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+                if (aligned16(a.J) && aligned16(a.Y))
+                    return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, fn, a);
+            }
+            return launch_jac_kernel<Fn, T, DefPlan>(jac_chain_kernel<Fn, T, DefPlan>, fn, a);
+        }
         else return RDHIP_ERR_NOT_IMPLEMENTED;           // jacobian!(fun, J, y, x, u) not defined for this model (src/functionbase.jl:257)
     }
     return RDHIP_ERR_INVALID_ARG;

@@ -660,6 +660,100 @@ __global__ void __launch_bounds__(Plan::NG * TILE) jac_chain_kernel(Fn fn, long 
     jac_tile_loop<Fn, T, Plan, ChainBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
+// compile-time-column form of the chain rule for the split-role kernel: the direction w = e_C is a constant, so the stage
+// Jacobian-vector products fold exactly like the ForwardAD columns do
+template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDING> struct ChainCols {
+    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&x2)[Fn::NX], const T (&x3)[Fn::NX], const T (&x4)[Fn::NX]) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY, RULE = Fn::RULE_ID;
+        constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
+        using CB = ChainBody<Fn, T, Plan>;
+        if constexpr (C < C1) {
+            if constexpr (Plan::wave_of(C) == G) {
+                if constexpr (VALUE_PENDING) {
+                    if (fr.want_y) { T y[NY]; fn.eval(fr.x, fr.u, fr.t, fr.h, y); fr.put_value(C1 - C0, y); }
+                }
+                const T h = fr.h;
+                T w[NX], wu[NU], d1[NX], d2[NX], d3[NX], d4[NX], ws[NX], col[NY];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) w[i] = (i == C) ? T(1) : T(0);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) wu[i] = (NX + i == C) ? (fr.term ? T(0) : T(1)) : T(0);
+                CB::jvp(fn, fr.x, fr.u, w, wu, d1);
+                if constexpr (RULE == RULE_CONTINUOUS) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = d1[i];
+                } else if constexpr (RULE == RULE_EULER) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = w[i] + d1[i] * h;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { d1[i] = d1[i] * h; ws[i] = w[i] + d1[i] * T(0.5); }
+                    CB::jvp(fn, x2, fr.u, ws, wu, d2);
+                    if constexpr (RULE == RULE_RK2) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) col[i] = w[i] + d2[i] * h;
+                    } else if constexpr (RULE == RULE_RK3) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] - d1[i] + d2[i] * T(2); }
+                        CB::jvp(fn, x3, fr.u, ws, wu, d3);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(4) + d3[i] * h) / T(6);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] + d2[i] * T(0.5); }
+                        CB::jvp(fn, x3, fr.u, ws, wu, d3);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { d3[i] = d3[i] * h; ws[i] = w[i] + d3[i]; }
+                        CB::jvp(fn, x4, fr.u, ws, wu, d4);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(2) + d3[i] * T(2) + d4[i] * h) / T(6);
+                    }
+                }
+                fr.put_at(C - C0, col);
+                ChainCols<Fn, T, Plan, CH, G, C + 1, false>::run(fn, fr, x2, x3, x4);
+            } else {
+                ChainCols<Fn, T, Plan, CH, G, C + 1, VALUE_PENDING>::run(fn, fr, x2, x3, x4);
+            }
+        }
+    }
+};
+template <class Fn, class T, class Plan> struct ChainUnrolledBody {
+    template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&x2)[Fn::NX], const T (&x3)[Fn::NX], const T (&x4)[Fn::NX]) {
+        if constexpr (G < Plan::NG) {
+            if (fr.g == G) ChainCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr, x2, x3, x4);
+            else waves<CH, G + 1>(fn, fr, x2, x3, x4);
+        }
+    }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        constexpr int NX = Fn::NX, RULE = Fn::RULE_ID;
+        const T h = fr.h;
+        T x2[NX], x3[NX], x4[NX], k1[NX], k2[NX], k3[NX];     // stage points, k_i = f(.) h as in the reference
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x2[i] = x3[i] = x4[i] = fr.x[i];
+        if constexpr (RULE != RULE_CONTINUOUS && RULE != RULE_EULER) {
+            fn.m.f(fr.x, fr.u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; x2[i] = fr.x[i] + k1[i] * T(0.5); }
+            if constexpr (RULE == RULE_RK3 || RULE == RULE_RK4) {
+                fn.m.f(x2, fr.u, k2);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; x3[i] = (RULE == RULE_RK3) ? fr.x[i] - k1[i] + k2[i] * T(2) : fr.x[i] + k2[i] * T(0.5); }
+            }
+            if constexpr (RULE == RULE_RK4) {
+                fn.m.f(x3, fr.u, k3);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x4[i] = fr.x[i] + k3[i] * h;
+            }
+        }
+        waves<CH, 0>(fn, fr, x2, x3, x4);
+    }
+};
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_chain_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                                  const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+}
+
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
 template <class Fn, class T, class Plan> struct FdBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
