@@ -3,4 +3,4 @@
 set -e
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-signed-zeros -ffinite-math-only -DTUNE_VARIANTS="$1" $2 -o ${3:-tune_jac} -Rpass-analysis=kernel-resource-usage tune_jac.hip 2> remarks.txt || { grep -E "error" -A3 remarks.txt | head -40; exit 1; }
-python ../kstat.py 'jac_' < remarks.txt
+python kstat.py 'jac_' < remarks.txt
