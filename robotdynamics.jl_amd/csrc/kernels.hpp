@@ -368,8 +368,20 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
     double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = (N + TILE - 1) / TILE;
+    // tile schedule of this workgroup: tile, tile + tstep, ... < tend
+#if defined(RD_TILE_MAP) && RD_TILE_MAP == 1     // tuning: a contiguous block of tiles per workgroup
+    const long long tpw = (ntiles + gridDim.x - 1) / gridDim.x;
+    long long tile = blockIdx.x * tpw;
+    const long long tend = (tile + tpw < ntiles) ? tile + tpw : ntiles, tstep = 1;
+#elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: a contiguous range of tiles per XCD (blockIdx % 8), strided inside it
+    const long long ntx = (ntiles + 7) / 8, xcd = blockIdx.x % 8;
+    long long tile = xcd * ntx + blockIdx.x / 8;
+    const long long tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles, tstep = gridDim.x / 8;
+#else
     long long tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    const long long tend = ntiles, tstep = gridDim.x;
+#endif
+    if (tile >= tend) return;
 
     if (wave < NG) {
         // =========================== compute waves ===========================
@@ -387,12 +399,12 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
             else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
         }
         __syncthreads();                                   // barrier 0
-        for (; tile < ntiles; tile += gridDim.x) {
+        for (; tile < tend; tile += tstep) {
             const long long k0 = tile * TILE;
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
-            const long long nxt = tile + gridDim.x;
+            const long long nxt = tile + tstep;
             const long long k1 = nxt * TILE;
-            const int nk1 = (nxt < ntiles) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+            const int nk1 = (nxt < tend) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
@@ -420,7 +432,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
         __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
         __syncthreads();                                   // barrier 0
-        for (; tile < ntiles; tile += gridDim.x) {
+        for (; tile < tend; tile += tstep) {
             const long long k0 = tile * TILE;
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
             V4 jv[L::JPL], yv[L::YPL];

@@ -170,6 +170,29 @@ def test_random_vs_oracle_ragged_sizes(name, mk, omk, gen, N):
         np.testing.assert_array_equal(host(J)[-1, :, :n], np.eye(n))
 
 
+def test_unaligned_output_slabs_take_the_fallback_kernel():
+    """The split-role kernel copies tiles as 16-byte units and needs 16-byte aligned J / Y; an 8-byte aligned slab (a view into
+    a larger buffer, as a Julia `view` would produce) must still give identical results through the element-wise kernel."""
+    rng = np.random.default_rng(21)
+    N = 333
+    model, om = RD.Satellite(), O.satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Zn = H.rand_rigid(rng, N, 6)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    Z = traj(model, Zn, t, dt, "cuda")
+    Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    for diff in (RD.ForwardAD(), RD.UserDefined()):
+        bufJ = torch.zeros(N * 247 + 1, dtype=torch.float64, device="cuda")
+        bufY = torch.zeros(N * 13 + 1, dtype=torch.float64, device="cuda")
+        J = bufJ[1:].view(N, 19, 13).transpose(1, 2)          # data_ptr is 8 mod 16
+        Y = bufY[1:].view(N, 13)
+        assert J.data_ptr() % 16 == 8 and Y.data_ptr() % 16 == 8
+        RD.jacobian_(RD.StaticReturn(), diff, dm, J, Y, Z)
+        np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        assert float(bufJ[0]) == 0.0 and float(bufY[0]) == 0.0   # nothing written in front of the slab
+
+
 def test_empty_batch_is_a_noop():
     model = RD.Satellite()
     dm = RD.DiscretizedDynamics(model, RD.RK4)
