@@ -125,8 +125,11 @@ def main():
     Ys = [torch.empty((N, NX), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     sig, diff = RD.StaticReturn(), RD.ForwardAD()
 
+    # argument checking once per output buffer (rdhip.prepare_jacobian); a step is then the bare C-ABI call, as from a Julia ccall
+    calls = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Z) for b in range(NBUF)]
+
     def step(i):
-        RD.jacobian_(sig, diff, dmodel, Js[i % NBUF], Ys[i % NBUF], Z)
+        calls[i % NBUF]()
 
     def barrier():
         if world > 1:

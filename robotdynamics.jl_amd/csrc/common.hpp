@@ -1,9 +1,31 @@
 // common.hpp -- host-side descriptors shared by the C-ABI layer (api.hip) and the per-family kernel TUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 #include "../../include/rdhip.h"
 
 namespace rd {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch (keyed by the kernel's
+// address: kernel function-pointer TYPES are shared between different kernels, so a per-type static would not do)
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t lds) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned long long> done;     // bit = device ordinal
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = done.find(kernel);
+        if (it != done.end() && (it->second & bit)) return hipSuccess;
+    }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(mu); done[kernel] |= bit; }
+    return e;
+}
+
 
 struct ModelDesc {
     int kind, rot, frame;

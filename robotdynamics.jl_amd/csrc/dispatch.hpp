@@ -39,7 +39,7 @@ inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
 template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
     constexpr size_t lds = JacLds<Fn, T, Plan>::BYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
@@ -49,7 +49,7 @@ template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel
 template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
     constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
@@ -71,7 +71,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             // small models: one wave = 64 knot points x all columns (no per-wave replication of the primal)
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_kernel<Fn, T>;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             const long long ntiles = (a.N + TILE - 1) / TILE;
             hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
             return hip_status(hipGetLastError());

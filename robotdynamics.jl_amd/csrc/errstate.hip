@@ -213,7 +213,7 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
         const size_t lds = (size_t)TK * d.n * d.e * sizeof(T);
         if (lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
             auto kern = errstate_tile_kernel<T, 0, TK>;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 80 * 1024) != hipSuccess) return RDHIP_ERR_HIP;
             hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)nullptr, 0, (T*)G);
         } else {
             hipLaunchKernelGGL((errstate_clear_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
@@ -245,7 +245,7 @@ template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long
     const size_t lds = (size_t)TK * d.e * d.e * sizeof(T);
     if (clear && lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
         auto kern = errstate_tile_kernel<T, 1, TK>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return RDHIP_ERR_HIP;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 80 * 1024) != hipSuccess) return RDHIP_ERR_HIP;
         hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, (T*)H);
         return st(hipGetLastError());
     }

@@ -1040,6 +1040,43 @@ def jacobian_(*args):
     return None
 
 
+class PreparedJacobian:
+    """jacobian!(sig, diff, fun, J, y, Z) with the argument checking done ONCE: calling the object re-issues the same batched
+    call on the same arrays (their contents may change, their memory may not).  For solver loops that evaluate the same packed
+    trajectory every iteration: the per-call host cost drops from ~15 us of Python checks to the bare C call (~5 us; a Julia
+    `ccall` host pays only that anyway).  Device arrays: launched on torch's current stream at call time."""
+
+    def __init__(self, sig, diff, fun, J, y, Z):
+        if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+            raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+        if not isinstance(Z, PackedTrajectory):
+            raise TypeError("PreparedJacobian needs a PackedTrajectory")
+        model, rule = _model_rule(fun)
+        n, m = _check_traj(fun, Z)
+        N = len(Z)
+        _dense(J, (N, n, n + m), "J", transposed_last2=True)
+        az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+        aj, ay = _Arg(J, "J", az.dtype), _Arg(y, "y", az.dtype)
+        if y is not None:
+            _dense(y, (N, n), "y")
+        ctx, space = _resolve_ctx([az, at, adt, aj, ay])
+        self._keep = (fun, model, J, y, Z)                  # keep the arrays (and the native model handle) alive
+        self._space, self._dev = space, az.device
+        self._fn = L.lib().rdhip_jacobian
+        self._args = (model._handle, rule, diff.code, az.dtype, N, az.ptr, at.ptr, adt.ptr, aj.ptr, ay.ptr, space)
+        self._ctx = ctx
+
+    def __call__(self):
+        ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
+        rc = self._fn(ctx.handle, *self._args)
+        if rc:
+            L.check(rc, ctx.handle)
+
+
+def prepare_jacobian(sig, diff, fun, J, y, Z):
+    return PreparedJacobian(sig, diff, fun, J, y, Z)
+
+
 def discrete_jacobian_(Q, J, model, z):
     """v0.3 discrete_jacobian!(Q, D, model, z) == jacobian!(sig, ForwardAD(), DiscretizedDynamics{Q}(model), D, y, z)."""
     fun = DiscretizedDynamics(model, Q)

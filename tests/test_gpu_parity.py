@@ -193,6 +193,26 @@ def test_unaligned_output_slabs_take_the_fallback_kernel():
         assert float(bufJ[0]) == 0.0 and float(bufY[0]) == 0.0   # nothing written in front of the slab
 
 
+def test_prepared_jacobian_matches_the_checked_call():
+    rng = np.random.default_rng(22)
+    N = 200
+    model = RD.Satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Z = traj(model, H.rand_rigid(rng, N, 6), np.zeros(N), np.full(N, 0.1), "cuda")
+    J1, J2 = RD.alloc_jacobians(dm, N, Z.data), RD.alloc_jacobians(dm, N, Z.data)
+    Y1, Y2 = torch.empty((N, 13), dtype=torch.float64, device="cuda"), torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J1, Y1, Z)
+    call = RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dm, J2, Y2, Z)
+    call()
+    assert torch.equal(J1, J2) and torch.equal(Y1, Y2)
+    Z.data.mul_(0.5)                       # contents may change between calls
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J1, Y1, Z)
+    call()
+    assert torch.equal(J1, J2) and torch.equal(Y1, Y2)
+    with pytest.raises(ValueError):
+        RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dm, J2[:, :, :5], Y2, Z)
+
+
 def test_empty_batch_is_a_noop():
     model = RD.Satellite()
     dm = RD.DiscretizedDynamics(model, RD.RK4)

@@ -64,7 +64,8 @@ def jac_case(name, model, Zn, rule, diff, dtype, reps, with_y=True):
     Js = [RD.alloc_jacobians(fun, N, Z.data) for _ in range(nb)]
     Ys = [torch.empty((N, n), dtype=Z.data.dtype, device=DEV) for _ in range(nb)]
     sig = RD.StaticReturn()
-    us = timed(lambda i: RD.jacobian_(sig, diff, fun, Js[i % nb], Ys[i % nb] if with_y else None, Z), reps)
+    calls = [RD.prepare_jacobian(sig, diff, fun, Js[b], Ys[b] if with_y else None, Z) for b in range(nb)]
+    us = timed(lambda i: calls[i % nb](), reps)
     alg = N * ((n + m) * T + 16 + n * (n + m) * T + (n * T if with_y else 0))
     emit(name, N, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb})
 
