@@ -142,6 +142,17 @@ int rdhip_dynamics_error(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
 int rdhip_dynamics_error_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                                   const void* Z, const double* t, const double* dt, void* J2, void* J1, void* E, int memspace);
 
+/* Error-state expansion of the discrete dynamics along a trajectory (what TrajectoryOptimization.jl / Altro.jl build from this path's
+ * outputs per knot point, `error_expansion!`: D.A = G2' * A * G1, D.B = G2' * B):
+ *     Ebar[k] = [ G(x_{k+1})' A_k G(x_k)  |  G(x_{k+1})' B_k ],   k = 0..N-2,
+ * with [A_k B_k] = the ForwardAD Jacobian of discrete_dynamics(DiscretizedDynamics{rule}(model), z_k) (src/discretized_dynamics.jl:169)
+ * and G = errstate_jacobian! (src/liestate.jl:262-298; identity for EuclideanState models, src/statevectortype.jl:149-155).
+ * Fused into the Jacobian kernel for RigidBody{QuatRotation} models (the n x (n+m) Jacobian never reaches memory); EuclideanState
+ * models return [A_k B_k]; other LieGroupModels: RDHIP_ERR_UNSUPPORTED.
+ * Ebar: e x (e+m) x (N-1), each slab column-major; Y: n x (N-1) or NULL receives f(z_k).  Device pointers must be 16-byte aligned. */
+int rdhip_error_expansion(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
+                          const void* Z, const double* t, const double* dt, void* Ebar, void* Y, int memspace);
+
 /* errstate_jacobian!(model, G, x) (v0.3: state_diff_jacobian!(G, model, z)): src/statevectortype.jl:119-122,149-155,
  * src/liestate.jl:262-298.  X: states, column k at X + k*ldx (ldx >= n; pass Z with ldx = n+m to read states out of
  * a packed trajectory).  G: n x e x N column-major.  clear != 0: G is fully overwritten (zeros elsewhere);

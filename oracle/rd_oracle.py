@@ -171,6 +171,21 @@ class Model:
         J2[:, np.arange(self.n), np.arange(self.n)] = -1.0
         return J2, J1, y - Z[1:, :self.n]
 
+    def error_expansion(self, rule, Z, t, dt):
+        """[G2' A G1 | G2' B] for consecutive pairs (TrajectoryOptimization.jl error_expansion!: D.A = G2'A G1, D.B = G2'B), built from
+        this oracle's own ForwardAD Jacobian and errstate_jacobian (reference src/liestate.jl:262-298).  Z (N, n+m) -> (N-1, e, e+m)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        J, y = self.jacobian(rule, FORWARD_AD, Z[:-1], np.asarray(t)[:-1], np.asarray(dt)[:-1])
+        n = self.n
+        if self.liestate() is None:          # EuclideanState: G = I
+            return J, y
+        G = self.errstate_jacobian(Z[:, :n])
+        A, B = J[:, :, :n], J[:, :, n:]
+        G1, G2 = G[:-1], G[1:]
+        Ab = np.einsum("kia,kij,kjb->kab", G2, A, G1)
+        Bb = np.einsum("kia,kij->kaj", G2, B)
+        return np.concatenate([Ab, Bb], axis=2), y
+
     def errstate_jacobian(self, X, clear=True, G0=None):
         """G0: optional (N, n, e) initial content (the reference does not clear G)."""
         X = np.ascontiguousarray(X, dtype=np.float64)

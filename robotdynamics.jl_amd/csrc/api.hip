@@ -3,6 +3,7 @@
 // No compute happens on the CPU here; without a GPU every compute entry point returns RDHIP_ERR_NO_DEVICE.
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -369,6 +370,37 @@ int rdhip_dynamics_error(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype
 int rdhip_dynamics_error_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                                   void* J2, void* J1, void* E, int memspace) {
     return dynerr_common(c, M, rule, diff, dtype, N, Z, t, dt, J2, J1, E, true, memspace, "rdhip_dynamics_error_jacobian");
+}
+
+int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt,
+                          void* Ebar, void* Y, int memspace) {
+    const char* what = "rdhip_error_expansion";
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: an explicit quadrature rule is required (got %d)", what, rule);
+    const long long P = N - 1;
+    if (P <= 0) return RDHIP_OK;
+    if (!Z || !t || !dt || !Ebar) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const ModelDesc& d = M->d;
+    const bool rigid = d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR;
+    if (d.lie_nP > 0 && !rigid) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: fused error-state expansion is built for RigidBody models only", what);
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = d.n + d.m;
+    Stage s(c);
+    LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = Z; a.t = t; a.dt = dt; a.J = Ebar; a.Y = Y;
+    if (memspace == RDHIP_HOST) {
+        a.Z = s.in(Z, (size_t)N * nz * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
+        a.J = s.out(Ebar, (size_t)P * d.e * (d.e + d.m) * ts); a.Y = s.out(Y, (size_t)P * d.n * ts);
+        if (s.rc) return s.rc;
+    }
+    int k;
+    if (!rigid) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);          // EuclideanState: G = I
+    else {
+        if ((reinterpret_cast<uintptr_t>(a.J) & 15) || (reinterpret_cast<uintptr_t>(a.Y) & 15))
+            return fail(c, RDHIP_ERR_INVALID_ARG, "%s: Ebar and Y must be 16-byte aligned", what);
+        k = d.kind == RDHIP_MODEL_SATELLITE ? fam_satellite_errexp(d, rule, dtype, a) : fam_quadrotor_errexp(d, rule, dtype, a);
+    }
+    k = kernel_status(c, k, what);
+    return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
 
 int rdhip_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, int clear, void* G, int memspace) {

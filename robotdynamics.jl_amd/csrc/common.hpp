@@ -57,7 +57,9 @@ RD_DECLARE_FAMILY(fam_cartpole)
 RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)
 RD_DECLARE_FAMILY(fam_quadrotor)
-RD_DECLARE_FAMILY(fam_lie)         // satellite pair, lie satellite
+RD_DECLARE_FAMILY(fam_lie)
+int fam_satellite_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);         // satellite pair, lie satellite
 
 // error-state kernels (errstate.hip)
 struct LieDesc {

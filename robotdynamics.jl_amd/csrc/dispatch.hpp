@@ -104,6 +104,33 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     return RDHIP_ERR_INVALID_ARG;
 }
 
+// error-state expansion (rigid bodies: fused kernel; needs 16-byte aligned outputs)
+template <class Mdl, int RULE> struct ErrPlanOf;      // column plan over the e+m error-state columns, defined next to the model's other plans
+template <class Mdl, int RULE> int launch_errexp(const Mdl& m, const LaunchArgs& a) {
+    using Fn = ErrFun<Mdl, RULE>;
+    using T = typename Fn::T;
+    using Plan = typename ErrPlanOf<Mdl, RULE>::Plan;
+    constexpr int NC = 4;
+    if (a.N == 0) return RDHIP_OK;
+    if (!aligned16(a.J) || !aligned16(a.Y)) return RDHIP_ERR_INVALID_ARG;
+    Fn fn{{m}};
+    return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, fn, a);
+}
+template <class Mdl> int dispatch_errexp_rule(const Mdl& m, int rule, const LaunchArgs& a) {
+    switch (rule) {
+        case RDHIP_EULER: return launch_errexp<Mdl, RULE_EULER>(m, a);
+        case RDHIP_RK2: return launch_errexp<Mdl, RULE_RK2>(m, a);
+        case RDHIP_RK3: return launch_errexp<Mdl, RULE_RK3>(m, a);
+        case RDHIP_RK4: return launch_errexp<Mdl, RULE_RK4>(m, a);
+    }
+    return RDHIP_ERR_INVALID_ARG;
+}
+template <template <class> class MT> int dispatch_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
+    if (dtype == RDHIP_F64) return dispatch_errexp_rule(MT<double>::make(md.params), rule, a);
+    if (dtype == RDHIP_F32) return dispatch_errexp_rule(MT<float>::make(md.params), rule, a);
+    return RDHIP_ERR_INVALID_ARG;
+}
+
 template <class Mdl> int dispatch_eval_rule(const Mdl& m, int rule, const LaunchArgs& a) {
     switch (rule) {
         case RDHIP_CONTINUOUS: return launch_eval(Fun<Mdl, RULE_CONTINUOUS>{m}, a);

@@ -14,7 +14,14 @@ using QuadPlan = TablePlan<17, 4, 0, /*r*/ 0, 0, 0, /*q*/ 0, 0, 0, 1, /*v*/ 0, 0
 template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
 template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
 
+// error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls
+using SatErrPlan = TablePlan<18, 4, 2, /*r*/ 0, 0, 0, /*phi*/ 0, 0, 0, /*v*/ 0, 0, 0, /*w*/ 1, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
+using QuadErrPlan = TablePlan<16, 4, 0, /*r*/ 0, 0, 0, /*phi*/ 0, 0, 1, /*v*/ 0, 0, 0, /*w*/ 1, 2, 2, /*u*/ 3, 3, 3, 1>;
+template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { using Plan = SatErrPlan; };
+template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { using Plan = QuadErrPlan; };
+
 #define RD_RIGID_VARIANT_DECL(name)                                                                       \
+    int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                     \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                       \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);         \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
@@ -22,7 +29,8 @@ template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WR
     template <class T> using name##_M = RigidBody<T, WRENCH, BODY, DIAG>;                                 \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_eval<name##_M>(md, rule, dtype, a); } \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_jacobian<name##_M>(md, rule, diff, dtype, a); } \
-    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); }
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); } \
+    int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_errexp<name##_M>(md, rule, dtype, a); }
 RD_RIGID_VARIANT_DECL(sat_wd) RD_RIGID_VARIANT_DECL(sat_wf) RD_RIGID_VARIANT_DECL(sat_bd) RD_RIGID_VARIANT_DECL(sat_bf)
 RD_RIGID_VARIANT_DECL(quad_wd) RD_RIGID_VARIANT_DECL(quad_wf) RD_RIGID_VARIANT_DECL(quad_bd) RD_RIGID_VARIANT_DECL(quad_bf)
 inline bool diag_inertia(const ModelDesc& md) { return host_is_diag3(md.params + 1); }

@@ -143,7 +143,9 @@ template <class Fn, class T, class Plan> struct JacLds {
 };
 
 template <class Fn, class T> struct JacFrame {
-    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY;
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NVAL = Fn::NVAL;
+    const T* zs;     // the staged input tile (bodies with Fn::NEXT read the following knot point from it)
+    int kl;          // this lane's knot point inside the tile
     T x[NX], u[NU];
     T t, h;
     bool term;
@@ -156,11 +158,14 @@ template <class Fn, class T> struct JacFrame {
 #pragma unroll
         for (int i = 0; i < NY; ++i) row[pos * NY + i] = col[i];
     }
-    RD_DEV void put_value(int pos_after_columns, const T (&y)[NY]) {
+    RD_DEV void put_value(int pos_after_columns, const T (&y)[NVAL]) {
         if (yrow) {
 #pragma unroll
-            for (int i = 0; i < NY; ++i) yrow[i] = y[i];
-        } else put_at(pos_after_columns, y);
+            for (int i = 0; i < NVAL; ++i) yrow[i] = y[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVAL; ++i) row[pos_after_columns * NY + i] = y[i];
+        }
     }
 };
 
@@ -345,10 +350,10 @@ __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_unrolled_kernel(Fn fn,
 #define RD_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #endif
 template <class Fn, class T, class Plan, int NC> struct SplitLds {
-    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
-    static constexpr size_t J_ELEMS = (size_t)TILE * NY * NZ, Y_ELEMS = (size_t)TILE * NY, Z_ELEMS = (size_t)TILE * NZ;
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT;
+    static constexpr size_t J_ELEMS = (size_t)TILE * OW, Y_ELEMS = (size_t)TILE * NVAL, Z_ELEMS = (size_t)TIN * NZ;
     static constexpr size_t J_BYTES = (J_ELEMS * sizeof(T) + 15) / 16 * 16, Y_BYTES = (Y_ELEMS * sizeof(T) + 15) / 16 * 16;
-    static constexpr size_t BYTES = J_BYTES + Y_BYTES + Z_ELEMS * sizeof(T) + 2 * TILE * sizeof(double);
+    static constexpr size_t BYTES = J_BYTES + Y_BYTES + (Z_ELEMS * sizeof(T) + 15) / 16 * 16 + 2 * TILE * sizeof(double);
     static constexpr int JU = (int)(J_ELEMS * sizeof(T) / 16), YU = (int)(Y_ELEMS * sizeof(T) / 16);   // whole 16-B units per full tile
     static constexpr int JPL = (JU + NC * TILE - 1) / (NC * TILE), YPL = (YU + NC * TILE - 1) / (NC * TILE);   // units per copy lane
     static_assert(J_ELEMS * sizeof(T) % 16 == 0 && Y_ELEMS * sizeof(T) % 16 == 0, "tile slabs must be multiples of 16 bytes");
@@ -357,7 +362,9 @@ template <class Fn, class T, class Plan, int NC> struct SplitLds {
 template <class Fn, class T, class Plan, int NC, class Body>
 RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
                            T* __restrict__ J, T* __restrict__ Y) {
-    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, NTC = NG * TILE;
+    // N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
+    const long long NIN = N + Fn::NEXT;
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -365,7 +372,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
     T* jt = reinterpret_cast<T*>(smem);
     T* yt = reinterpret_cast<T*>(smem + L::J_BYTES);
     T* zs = reinterpret_cast<T*>(smem + L::J_BYTES + L::Y_BYTES);
-    double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);
+    double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = (N + TILE - 1) / TILE;
     // tile schedule of this workgroup: tile, tile + tstep, ... < tend
@@ -385,16 +392,18 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
 
     if (wave < NG) {
         // =========================== compute waves ===========================
-        constexpr int ZPT = (TILE * NZ + NTC - 1) / NTC;
+        constexpr int ZPT = (TIN * NZ + NTC - 1) / NTC;
         JacFrame<Fn, T> fr;
         fr.g = wave;
-        fr.row = jt + lane * (NY * NZ);
-        fr.yrow = yt + lane * NY;
+        fr.row = jt + lane * OW;
+        fr.yrow = yt + lane * NVAL;
+        fr.zs = zs;
         fr.want_y = (Y != nullptr);
         {
             const long long k0 = tile * TILE;
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
-            for (int e = threadIdx.x; e < nk * NZ; e += NTC) zs[e] = Z[k0 * NZ + e];
+            const int nin = (int)((NIN - k0) < TIN ? (NIN - k0) : TIN);
+            for (int e = threadIdx.x; e < nin * NZ; e += NTC) zs[e] = Z[k0 * NZ + e];
             if (threadIdx.x < nk) ts[threadIdx.x] = tt[k0 + threadIdx.x];
             else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
         }
@@ -405,9 +414,10 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
             const long long nxt = tile + tstep;
             const long long k1 = nxt * TILE;
             const int nk1 = (nxt < tend) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+            const int nin1 = (nxt < tend) ? (int)((NIN - k1) < TIN ? (NIN - k1) : TIN) : 0;
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nin1 * NZ) ? k1 * NZ + e : 0]; }
             {
                 const double* tp = (threadIdx.x < TILE) ? tt : dtt;
                 const int idx = threadIdx.x & (TILE - 1);
@@ -418,10 +428,11 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
             const double hd = ts[TILE + kl];
             fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
             read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
+            fr.kl = kl;
             Body::template run<0>(fn, fr);
             __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TILE * NZ) zs[e] = zpre[r]; }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
             __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
         }
@@ -443,9 +454,9 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
             for (int r = 0; r < L::YPL; ++r) { const int u = r * (NC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the tile is in registers
             __syncthreads();                               // barrier B
-            // number of valid bytes of a ragged last tile is nk*NY*NZ*sizeof(T), a multiple of sizeof(T) only
-            const int jbytes = nk * NY * NZ * (int)sizeof(T), ybytes = nk * NY * (int)sizeof(T);
-            V4* jdst = reinterpret_cast<V4*>(J + k0 * (NY * NZ));
+            // number of valid bytes of a ragged last tile is nk*OW*sizeof(T), a multiple of sizeof(T) only
+            const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
+            V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
 #pragma unroll
             for (int r = 0; r < L::JPL; ++r) {
                 const int u = r * (NC * TILE) + ct;
@@ -457,7 +468,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
                 }
             }
             if (Y) {
-                V4* ydst = reinterpret_cast<V4*>(Y + k0 * NY);
+                V4* ydst = reinterpret_cast<V4*>(Y + k0 * NVAL);
 #pragma unroll
                 for (int r = 0; r < L::YPL; ++r) {
                     const int u = r * (NC * TILE) + ct;
@@ -476,6 +487,105 @@ template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+}
+
+// ---- error-state expansion: [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k] fused into the Jacobian kernel ----------------------
+// (error_expansion! of TrajectoryOptimization.jl; G = errstate_jacobian!, src/liestate.jl:262-298).  G is block diagonal with
+// identities except for the 4x3 blocks L(q)H of the normalised quaternions, so the projection costs no extra pass:
+//   columns: the tangent is seeded in ERROR coordinates -- a unit vector for a vector part (compile-time constant, folds), the
+//            column j of L(q)H on the quaternion entries for an attitude part (3 passes per rotation instead of 4);
+//   rows:    the 4 quaternion rows of every finished column are contracted with L(q+)H of the NEXT knot point's quaternion.
+// Output per knot point: e x (e+m) instead of n x (n+m) (12x18 vs 13x19 for a rigid body: 12.5 % fewer bytes).
+template <class T> RD_DEV void lh_column(const T (&q)[4], int j, T (&c)[4]) {     // column j of L(q) H, q = [w x y z]
+    if (j == 0) { c[0] = -q[1]; c[1] = q[0]; c[2] = q[3]; c[3] = -q[2]; }
+    else if (j == 1) { c[0] = -q[2]; c[1] = -q[3]; c[2] = q[0]; c[3] = q[1]; }
+    else { c[0] = -q[3]; c[1] = q[2]; c[2] = -q[1]; c[3] = q[0]; }
+}
+// rows of one finished column: vector rows are copied, the 4 quaternion rows of rotation r contract with L(q+)H (compile-time row index)
+template <class Mdl, class T, int R, int NE> struct ErrRows {
+    template <class D> static RD_DEV void apply(const D* yd, const T (&qn)[Mdl::NROT > 0 ? Mdl::NROT : 1][4], T sc, T (&out)[NE]) {
+        if constexpr (R < NE) {
+            constexpr ErrSlot sl = err_slot<Mdl>(R);
+            if constexpr (sl.rot < 0) out[R] = yd[sl.s].d[0] * sc;
+            else {
+                T col[4]; lh_column<T>(qn[sl.rot], sl.j, col);
+                out[R] = (col[0] * yd[sl.s].d[0] + col[1] * yd[sl.s + 1].d[0] + col[2] * yd[sl.s + 2].d[0] + col[3] * yd[sl.s + 3].d[0]) * sc;
+            }
+            ErrRows<Mdl, T, R + 1, NE>::apply(yd, qn, sc, out);
+        }
+    }
+};
+template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDING> struct ErrCols {
+    using Mdl = decltype(Fn::m);
+    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&qc)[Mdl::NROT > 0 ? Mdl::NROT : 1][4], const T (&qn)[Mdl::NROT > 0 ? Mdl::NROT : 1][4]) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NE = Fn::NE;
+        constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
+        if constexpr (C < C1) {
+            if constexpr (Plan::wave_of(C) == G) {
+                using D = Dual<T, 1>;
+                D xd[NX], ud[NU], yd[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xd[i].v = fr.x[i]; xd[i].d[0] = T(0); }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { ud[i].v = fr.u[i]; ud[i].d[0] = (NE + i == C) ? T(1) : T(0); }
+                if constexpr (C < NE) {
+                    constexpr ErrSlot sl = err_slot<Mdl>(C);
+                    if constexpr (sl.rot < 0) xd[sl.s].d[0] = T(1);
+                    else {
+                        T col[4]; lh_column<T>(qc[sl.rot], sl.j, col);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xd[sl.s + i].d[0] = col[i];
+                    }
+                }
+                fn.eval(xd, ud, fr.t, fr.h, yd);
+                if constexpr (VALUE_PENDING) {
+                    if (fr.want_y) {
+                        T val[NX];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) val[i] = yd[i].v;
+                        fr.put_value(C1 - C0, val);
+                    }
+                }
+                const T sc = (C >= NE && fr.term) ? T(0) : T(1);       // control columns of a terminal knot point are zero
+                T out[NE];
+                ErrRows<Mdl, T, 0, NE>::apply(yd, qn, sc, out);
+                fr.put_at(C - C0, out);
+                ErrCols<Fn, T, Plan, CH, G, C + 1, false>::run(fn, fr, qc, qn);
+            } else {
+                ErrCols<Fn, T, Plan, CH, G, C + 1, VALUE_PENDING>::run(fn, fr, qc, qn);
+            }
+        }
+    }
+};
+template <class Fn, class T, class Plan> struct ErrUnrolledBody {
+    using Mdl = decltype(Fn::m);
+    static constexpr int NR = Mdl::NROT > 0 ? Mdl::NROT : 1;
+    template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&qc)[NR][4], const T (&qn)[NR][4]) {
+        if constexpr (G < Plan::NG) {
+            if (fr.g == G) ErrCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr, qc, qn);
+            else waves<CH, G + 1>(fn, fr, qc, qn);
+        }
+    }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        constexpr int NZ = Fn::NX + Fn::NU;
+        T qc[NR][4], qn[NR][4];                              // normalised quaternions of this and of the next knot point
+#pragma unroll
+        for (int r = 0; r < Mdl::NROT; ++r) {
+            const int s0 = Mdl::rot_start(r);
+            const T* xn = fr.zs + (fr.kl + 1) * NZ + s0;
+            const T a0 = fr.x[s0], a1 = fr.x[s0 + 1], a2 = fr.x[s0 + 2], a3 = fr.x[s0 + 3];
+            const T b0 = xn[0], b1 = xn[1], b2 = xn[2], b3 = xn[3];
+            const T ia = T(1) / sqrt_(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3), ib = T(1) / sqrt_(b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3);
+            qc[r][0] = a0 * ia; qc[r][1] = a1 * ia; qc[r][2] = a2 * ia; qc[r][3] = a3 * ia;
+            qn[r][0] = b0 * ib; qn[r][1] = b1 * ib; qn[r][2] = b2 * ib; qn[r][3] = b3 * ib;
+        }
+        waves<CH, 0>(fn, fr, qc, qn);
+    }
+};
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_errexp_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                                   const double* __restrict__ dtt, T* __restrict__ E, T* __restrict__ Y) {
+    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, E, Y);
 }
 
 // ---- small models (n + m <= 10): ONE wave owns 64 knot points and ALL Jacobian columns ---------------------------------

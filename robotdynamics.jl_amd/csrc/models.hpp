@@ -132,6 +132,8 @@ enum { WRENCH_SATELLITE = 0, WRENCH_QUADROTOR = 1 };
 template <class T_, int WRENCH, bool BODY, bool DIAGJ = false> struct RigidBody {
     using T = T_;
     static constexpr int NX = 13, NU = (WRENCH == WRENCH_SATELLITE) ? 6 : 4;
+    static constexpr int NROT = 1;                       // LieState{QuatRotation,(3,6)}: one quaternion at state index 3 (src/rigidbody.jl:36-40)
+    static constexpr int rot_start(int) { return 3; }
     static constexpr bool HAS_USER_JACOBIAN = true;     // src/rigidbody.jl:260-313 (analytic blocks)
     T mass, inv_mass;
     T J[9], Jinv[9];
@@ -243,6 +245,9 @@ template <class T_> struct LieSatellite {
 template <class Mdl, int RULE> struct Fun {
     using T = typename Mdl::T;
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, RULE_ID = RULE;
+    // output tile of the Jacobian kernels: NY rows x NCOLS columns per knot point, NVAL function values; NEXT = 1 if the
+    // kernel also needs the state of the following knot point
+    static constexpr int NCOLS = Mdl::NX + Mdl::NU, NVAL = Mdl::NX, NEXT = 0;
     Mdl m;
     template <class S> RD_DEV void eval(const S* x, const S* u, T /*t*/, T h, S* y) const {
         if constexpr (RULE == RULE_CONTINUOUS) {
@@ -291,6 +296,30 @@ template <class Mdl, int RULE> struct Fun {
             for (int i = 0; i < NX; ++i) y[i] = x[i] + (acc[i] + k[i]) * h6;
         }
     }
+};
+
+// ---- error-state layout of a LieState{QuatRotation,P} model (src/liestate.jl:75-131) at compile time --------------------
+// error index e <-> either a vector state index, or (rotation r, component j of its 3-vector)
+struct ErrSlot { int rot; int j; int s; };      // rot < 0: vector part, state index s ; rot >= 0: quaternion starting at state index s
+template <class Mdl> constexpr int err_dim() { return Mdl::NX - Mdl::NROT; }
+template <class Mdl> constexpr ErrSlot err_slot(int e) {
+    int s = 0, c = 0, r = 0;
+    while (s < Mdl::NX) {
+        if (r < Mdl::NROT && s == Mdl::rot_start(r)) {
+            if (e >= c && e < c + 3) return ErrSlot{r, e - c, s};
+            s += 4; c += 3; ++r;
+        } else {
+            if (e == c) return ErrSlot{-1, 0, s};
+            ++s; ++c;
+        }
+    }
+    return ErrSlot{-1, 0, 0};
+}
+// DiscretizedDynamics{RULE}(model) seen through the error state: rows and state columns are error-state coordinates.
+// error_expansion! of TrajectoryOptimization.jl (the consumer named in SURVEY 8f-2):  [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k]
+template <class Mdl, int RULE> struct ErrFun : Fun<Mdl, RULE> {
+    static constexpr int NE = err_dim<Mdl>();
+    static constexpr int NY = NE, NCOLS = NE + Mdl::NU, NVAL = Mdl::NX, NEXT = 1;
 };
 
 }  // namespace rd

@@ -212,6 +212,19 @@ function RD.dynamics_error_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod
     check(ctx, rc)
 end
 
+# error-state expansion along a trajectory: E[:,:,k] = [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k] (what TrajectoryOptimization.jl's
+# error_expansion! assembles per knot point); fused into the Jacobian kernel for RigidBody models
+function error_expansion!(fun::RD.DiscretizedDynamics, E::Array{T,3}, Y::Union{Nothing,Matrix{T}}, Z::PackedTrajectory{n,m,T}; ctx::Context=default_context()) where {n,m,T}
+    N = length(Z); e = RD.errstate_dim(fun)
+    size(E) == (e, e + m, N - 1) || throw(DimensionMismatch("E must be e x (e+m) x (N-1)"))
+    GC.@preserve E Y Z begin
+        rc = ccall((:rdhip_error_expansion, librdhip), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Clonglong, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   ctx.ptr, handle(fun), rulecode(fun), dtypecode(T), N, Z.data, Z.t, Z.dt, E, Y === nothing ? C_NULL : pointer(Y), HOST)
+    end
+    check(ctx, rc)
+end
+
 # v0.3 spellings (README.md:73-82,128-136; SURVEY.md App. B)
 discrete_jacobian!(::Type{Q}, D::Array{T,3}, model::RD.ContinuousDynamics, Z::PackedTrajectory{n,m,T}) where {Q<:RD.QuadratureRule,n,m,T} =
     RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics{Q}(model), D, nothing, Z)

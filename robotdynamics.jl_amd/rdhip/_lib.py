@@ -68,6 +68,7 @@ _SIGS = {
     "rdhip_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_dynamics_error": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_dynamics_error_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, _P, C.c_int]),
+    "rdhip_error_expansion": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rdhip_state_diff": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "rdhip_nabla_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),

@@ -1157,6 +1157,37 @@ def dynamics_error_jacobian_(sig, diff, fun, J2, J1, y2, y1, *args):
     return None
 
 
+def alloc_error_expansions(model, N, like=None, dtype=None):
+    """(N-1, e, e+m) stack of error-state expansions [G2'AG1 | G2'B] with column-major slabs (like alloc_jacobians)."""
+    e, m = errstate_dim(model), control_dim(model)
+    base = _alloc((max(N - 1, 0), e + m, e), like, dtype)
+    return base.transpose(1, 2) if _is_torch(base) else base.transpose(0, 2, 1)
+
+
+def error_expansion_(fun, E, y, Z):
+    """Batched error-state expansion along a trajectory: E[k] = [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k], k = 0..N-2, with
+    [A_k B_k] = jacobian!(sig, ForwardAD(), DiscretizedDynamics{Q}(model), ., ., Z[k]) and G = errstate_jacobian!.  This is what
+    TrajectoryOptimization.jl's `error_expansion!` assembles per knot point from this path's outputs; for RigidBody models it is
+    fused into the Jacobian kernel.  E from alloc_error_expansions; y (N-1, n) or None receives f(z_k)."""
+    model, rule = _model_rule(fun)
+    if rule == L.CONTINUOUS:
+        raise TypeError("error_expansion! needs a DiscreteDynamics model")
+    n, m = _check_traj(fun, Z)
+    e = errstate_dim(fun)
+    N = len(Z)
+    P = max(N - 1, 0)
+    _dense(E, (P, e, e + m), "E", transposed_last2=True)
+    if y is not None:
+        _dense(y, (P, n), "y")
+    if N < 2:
+        return None
+    az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+    ae, ay = _Arg(E, "E", az.dtype), _Arg(y, "y", az.dtype)
+    ctx, space = _resolve_ctx([az, at, adt, ae, ay])
+    L.check(L.lib().rdhip_error_expansion(ctx.handle, model._handle, rule, az.dtype, N, az.ptr, at.ptr, adt.ptr, ae.ptr, ay.ptr, space), ctx.handle)
+    return None
+
+
 def _states_of(model, x):
     """(array, ld, N, single): states from a PackedTrajectory / KnotPoint / (N, >=n) array / single vector."""
     n = state_dim(model)

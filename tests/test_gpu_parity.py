@@ -383,6 +383,39 @@ def test_dynamics_error_and_jacobian(where):
         RD.dynamics_error(RD.Cartpole(), Z)
 
 
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_error_state_expansion_fused_into_the_jacobian_kernel(where):
+    """E[k] = [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k] (TrajectoryOptimization.jl error_expansion! built from this path's operators)
+    against the oracle's explicit product of its own Jacobian and errstate Jacobians; Euclidean models return [A B]."""
+    rng = np.random.default_rng(12)
+    cases = [(RD.Satellite(), O.satellite(), lambda n: H.rand_rigid(rng, n, 6)),
+             (RD.Body(bodyframe=True), O.body(O.FRAME_BODY), lambda n: H.rand_rigid(rng, n, 6)),
+             (RD.Satellite(mass=1.3, J=np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), O.satellite(1.3, np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), lambda n: H.rand_rigid(rng, n, 6)),
+             (RD.Quadrotor(), O.quadrotor(), lambda n: H.rand_rigid(rng, n, 4, 0.6, 1.9)),
+             (RD.Cartpole(), O.cartpole(), lambda n: rng.random((n, 5)))]
+    for model, om, gen in cases:
+        for N in (2, 65, 200):
+            Zn = gen(N)
+            if Zn.shape[1] > 7:
+                Zn[:, 3:7] *= rng.uniform(0.6, 1.6, (N, 1))      # G normalises the quaternion, the dynamics do not
+            n, m, e = RD.state_dim(model), RD.control_dim(model), RD.errstate_dim(model)
+            t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+            for Q, rule in ((RD.RK4, O.RK4), (RD.RK3, O.RK3)):
+                dm = RD.DiscretizedDynamics(model, Q)
+                Z = traj(model, Zn, t, dt, "cuda" if where == "cuda" else None)
+                E = RD.alloc_error_expansions(dm, N, Z.data)
+                y = RD.evaluate(dm, Z)[: N - 1] * 0
+                RD.error_expansion_(dm, E, y, Z)
+                Eo, yo = om.error_expansion(rule, Zn, t, dt)
+                assert host(E).shape == (N - 1, e, e + m)
+                np.testing.assert_allclose(host(E), Eo, rtol=0, atol=TOL * max(1.0, np.abs(Eo).max()))
+                np.testing.assert_allclose(host(y), yo, rtol=0, atol=TOL)
+    with pytest.raises(NotImplementedError):
+        mdl = RD.SatellitePair()
+        Zp = traj(mdl, rng.random((4, 20)), np.zeros(4), np.full(4, 0.1), None)
+        RD.error_expansion_(RD.DiscretizedDynamics(mdl, RD.RK4), RD.alloc_error_expansions(mdl, 4, Zp.data), None, Zp)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21

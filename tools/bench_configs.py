@@ -70,6 +70,20 @@ def jac_case(name, model, Zn, rule, diff, dtype, reps, with_y=True):
     emit(name, N, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb})
 
 
+def errexp_case(name, model, Zn, rule, dtype, reps):
+    N = Zn.shape[0]
+    n, m, e = RD.state_dim(model), RD.control_dim(model), RD.errstate_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    fun = RD.DiscretizedDynamics(model, rule)
+    Z = RD.PackedTrajectory(n, m, Zn.astype(dtype), np.arange(N) * 0.1, np.full(N, 0.1)).to(DEV)
+    nb = nbuf_for(N * e * (e + m) * T)
+    Es = [RD.alloc_error_expansions(fun, N, Z.data) for _ in range(nb)]
+    Ys = [torch.empty((N - 1, n), dtype=Z.data.dtype, device=DEV) for _ in range(nb)]
+    us = timed(lambda i: RD.error_expansion_(fun, Es[i % nb], Ys[i % nb], Z), reps)
+    alg = (N - 1) * ((n + m) * T + 16 + e * (e + m) * T + n * T)
+    emit(name, N - 1, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb})
+
+
 def eval_case(name, model, Zn, rule, dtype, reps):
     N = Zn.shape[0]
     n, m = RD.state_dim(model), RD.control_dim(model)
@@ -123,6 +137,7 @@ def main():
     eval_case("C3 satellite RK4 discrete_dynamics", sat, Zs, RD.RK4, f64, a.reps)
     eval_case("C3 satellite continuous dynamics", sat, Zs, None, f64, a.reps)
     jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
+    errexp_case("satellite RK4 error-state expansion [G2'AG1 | G2'B] fused (+x_next)", sat, rigid_inputs(65537, 6, rng), RD.RK4, f64, a.reps)
     jac_case("C3 satellite RK4 jacobian ForwardAD (J only)", sat, Zs, RD.RK4, AD, f64, a.reps, with_y=False)
     jac_case("C3 satellite RK4 jacobian UserDefined (chain rule)", sat, Zs, RD.RK4, UD, f64, a.reps)
     jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
