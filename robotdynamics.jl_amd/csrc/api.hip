@@ -383,7 +383,6 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     rc = check_rotation(c, M); if (rc) return rc;
     const ModelDesc& d = M->d;
     const bool rigid = d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR;
-    if (d.lie_nP > 0 && !rigid) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: fused error-state expansion is built for RigidBody models only", what);
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = d.n + d.m;
     Stage s(c);
     LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = Z; a.t = t; a.dt = dt; a.J = Ebar; a.Y = Y;
@@ -393,8 +392,16 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
         if (s.rc) return s.rc;
     }
     int k;
-    if (!rigid) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);          // EuclideanState: G = I
-    else {
+    if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
+    else if (!rigid) {
+        // other LieGroupModels: Jacobians into a context workspace, then the generic projection kernel
+        void* Jw = s.reserve((size_t)P * d.n * nz * ts);
+        if (s.rc) return s.rc;
+        void* Eout = a.J;
+        a.J = Jw;
+        k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);
+        if (k == RDHIP_OK) k = launch_project_errexp(M->lie, dtype, c->stream, P, d.m, a.Z, Jw, Eout);
+    } else {
         if ((reinterpret_cast<uintptr_t>(a.J) & 15) || (reinterpret_cast<uintptr_t>(a.Y) & 15))
             return fail(c, RDHIP_ERR_INVALID_ARG, "%s: Ebar and Y must be 16-byte aligned", what);
         k = d.kind == RDHIP_MODEL_SATELLITE ? fam_satellite_errexp(d, rule, dtype, a) : fam_quadrotor_errexp(d, rule, dtype, a);

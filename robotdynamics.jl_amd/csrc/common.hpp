@@ -77,6 +77,8 @@ int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, c
 // dynamics-error helpers (errstate.hip): E[:,k] -= Z[0:n, k+1] ; J2[k] = [-I 0]
 int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E);
 int launch_fill_neg_identity(int dtype, hipStream_t s, long long pairs, int n, int nz, void* J2);
+// generic (any LieState) error-state projection of a stack of Jacobians: E[k] = G(x_{k+1})' [A_k G(x_k) | B_k]
+int launch_project_errexp(const LieDesc& d, int dtype, hipStream_t s, long long pairs, int m, const void* Z, const void* J, void* E);
 int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H);
 
 }  // namespace rd

@@ -201,6 +201,45 @@ __global__ void __launch_bounds__(256) fill_neg_identity_kernel(long long pairs,
     J2[idx] = ((rc / n) == (rc % n)) ? T(-1) : T(0);
 }
 
+// E[k] = G(x_{k+1})' [A_k G(x_k) | B_k] from a stack of n x (n+m) Jacobians, any LieState{QuatRotation,P}: one thread per output element.
+// (RigidBody models use the fused kernel of kernels.hpp instead; this is the general composite for the other LieGroupModels.)
+template <class T> __device__ __forceinline__ T lh_entry(const T* q, T inv, int i, int j) {
+    const int s = LH_IDX[i][j];
+    return T(LH_SGN[i][j]) * (q[s] * inv);
+}
+template <class T>
+__global__ void __launch_bounds__(256) project_errexp_kernel(LieDesc d, long long pairs, int m, const T* __restrict__ Z, const T* __restrict__ J, T* __restrict__ E) {
+    const int nz = d.n + m, ec = d.e + m;
+    const long long per = (long long)d.e * ec;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pairs * per) return;
+    const long long k = idx / per;
+    const int rc = (int)(idx - k * per);
+    const int c = rc / d.e, r = rc - c * d.e;             // output (row r, column c), column-major e x (e+m)
+    const T* Jk = J + k * d.n * nz;
+    const T* x1 = Z + k * nz; const T* x2 = Z + (k + 1) * nz;
+    // row side: error row r <- state rows
+    int rs[4]; T rw[4]; int nr = 1;
+    if (d.err_src[r] >= 0) { rs[0] = d.err_src[r]; rw[0] = T(1); }
+    else {
+        const int rot = -1 - d.err_src[r], s0 = d.rot_row0[rot], j = r - d.rot_col0[rot];
+        const T* q = x2 + s0; const T inv = rsqrt_<T>(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        nr = 4; for (int i = 0; i < 4; ++i) { rs[i] = s0 + i; rw[i] = lh_entry<T>(q, inv, i, j); }
+    }
+    // column side: error column c (< e) <- state columns ; control columns map one to one
+    int cs[4]; T cw[4]; int nc = 1;
+    if (c >= d.e) { cs[0] = d.n + (c - d.e); cw[0] = T(1); }
+    else if (d.err_src[c] >= 0) { cs[0] = d.err_src[c]; cw[0] = T(1); }
+    else {
+        const int rot = -1 - d.err_src[c], s0 = d.rot_row0[rot], j = c - d.rot_col0[rot];
+        const T* q = x1 + s0; const T inv = rsqrt_<T>(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        nc = 4; for (int i = 0; i < 4; ++i) { cs[i] = s0 + i; cw[i] = lh_entry<T>(q, inv, i, j); }
+    }
+    T acc = T(0);
+    for (int a = 0; a < nr; ++a) for (int b = 0; b < nc; ++b) acc += rw[a] * cw[b] * Jk[rs[a] + cs[b] * d.n];
+    E[idx] = acc;
+}
+
 static inline int st(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_ERR_HIP; }
 static inline unsigned nblk(long long work) { return (unsigned)((work + 255) / 256); }
 
@@ -257,6 +296,13 @@ int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long 
     return dtype == RDHIP_F64 ? nabla_T<double>(d, s, N, X, ldx, Xb, ldxb, clear, H) : nabla_T<float>(d, s, N, X, ldx, Xb, ldxb, clear, H);
 }
 
+int launch_project_errexp(const LieDesc& d, int dtype, hipStream_t s, long long pairs, int m, const void* Z, const void* J, void* E) {
+    if (pairs <= 0) return RDHIP_OK;
+    const long long work = pairs * d.e * (d.e + m);
+    if (dtype == RDHIP_F64) hipLaunchKernelGGL((project_errexp_kernel<double>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const double*)Z, (const double*)J, (double*)E);
+    else hipLaunchKernelGGL((project_errexp_kernel<float>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const float*)Z, (const float*)J, (float*)E);
+    return st(hipGetLastError());
+}
 int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E) {
     if (pairs <= 0) return RDHIP_OK;
     if (dtype == RDHIP_F64) hipLaunchKernelGGL((sub_next_state_kernel<double>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const double*)Z, (double*)E);

@@ -392,11 +392,13 @@ def test_error_state_expansion_fused_into_the_jacobian_kernel(where):
              (RD.Body(bodyframe=True), O.body(O.FRAME_BODY), lambda n: H.rand_rigid(rng, n, 6)),
              (RD.Satellite(mass=1.3, J=np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), O.satellite(1.3, np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), lambda n: H.rand_rigid(rng, n, 6)),
              (RD.Quadrotor(), O.quadrotor(), lambda n: H.rand_rigid(rng, n, 4, 0.6, 1.9)),
-             (RD.Cartpole(), O.cartpole(), lambda n: rng.random((n, 5)))]
+             (RD.Cartpole(), O.cartpole(), lambda n: rng.random((n, 5))),
+             (RD.SatellitePair(), O.satellite_pair(), lambda n: rng.random((n, 20)) + 0.1),      # two quaternions: generic projection kernel
+             (RD.LieSatellite(), O.lie_satellite(), lambda n: rng.random((n, 10)) + 0.1)]
     for model, om, gen in cases:
         for N in (2, 65, 200):
             Zn = gen(N)
-            if Zn.shape[1] > 7:
+            if Zn.shape[1] in (17, 19):
                 Zn[:, 3:7] *= rng.uniform(0.6, 1.6, (N, 1))      # G normalises the quaternion, the dynamics do not
             n, m, e = RD.state_dim(model), RD.control_dim(model), RD.errstate_dim(model)
             t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
@@ -410,10 +412,6 @@ def test_error_state_expansion_fused_into_the_jacobian_kernel(where):
                 assert host(E).shape == (N - 1, e, e + m)
                 np.testing.assert_allclose(host(E), Eo, rtol=0, atol=TOL * max(1.0, np.abs(Eo).max()))
                 np.testing.assert_allclose(host(y), yo, rtol=0, atol=TOL)
-    with pytest.raises(NotImplementedError):
-        mdl = RD.SatellitePair()
-        Zp = traj(mdl, rng.random((4, 20)), np.zeros(4), np.full(4, 0.1), None)
-        RD.error_expansion_(RD.DiscretizedDynamics(mdl, RD.RK4), RD.alloc_error_expansions(mdl, 4, Zp.data), None, Zp)
 
 
 def test_rollout_matches_oracle_and_is_idempotent():

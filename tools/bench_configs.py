@@ -107,6 +107,19 @@ def errstate_case(name, model, Zn, reps, clear):
     emit(name, N, "f64", us, alg, {"output_buffers": nb, "clear": clear})
 
 
+def statediff_case(name, model, Zn, reps, rng):
+    N = Zn.shape[0]
+    n, e = RD.state_dim(model), RD.errstate_dim(model)
+    X = torch.from_numpy(np.ascontiguousarray(Zn[:, :n])).to(DEV)
+    X0 = torch.from_numpy(np.ascontiguousarray(Zn[::-1, :n].copy())).to(DEV)
+    dX = torch.empty((N, e), dtype=torch.float64, device=DEV)
+    us = timed(lambda i: RD.state_diff_(model, dX, X, X0), reps)
+    emit(name, N, "f64", us, N * (2 * n * 8 + e * 8))
+    dG = torch.empty((N, e, e), dtype=torch.float64, device=DEV).transpose(1, 2)
+    us = timed(lambda i: RD.nabla_errstate_jacobian_(model, dG, X, X0, clear=True), reps)
+    emit(name.replace("state_diff", "nabla_errstate_jacobian clear=True"), N, "f64", us, N * (2 * n * 8 + e * e * 8))
+
+
 def rollout_case(name, model, M, K, rule, dtype, reps, rng):
     n, m = RD.state_dim(model), RD.control_dim(model)
     T = 8 if dtype == np.float64 else 4
@@ -157,6 +170,11 @@ def main():
     rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("C5 cartpole RK4 rollout fp32 512 traj x 256 knots", cart, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+    Zb = rigid_inputs(1 << 20, 6, rng)
+    eval_case("large-N satellite RK4 discrete_dynamics", sat, Zb, RD.RK4, f64, 20)
+    eval_case("large-N satellite continuous dynamics", sat, Zb, None, f64, 20)
+    eval_case("large-N cartpole RK4 discrete_dynamics", cart, rng.random((1 << 22, 5)), RD.RK4, f64, 20)
+    statediff_case("quadrotor state_diff N=262144", quad, rigid_inputs(262144, 4, rng, 0.6, 1.9), 30, rng)
     if a.sweep:
         for p in range(12, 23):
             N = 1 << p
