@@ -55,7 +55,8 @@ typedef enum {
     RDHIP_MODEL_QUADROTOR = 4,         /* RigidBody{R}: test/quadrotor.jl:21-137
                                           params = {mass, J[9], gravity[3], motor_dist, kf, km}                               */
     RDHIP_MODEL_SATELLITE_PAIR = 5,    /* LieGroupModel, LieState(R,(0,3,3)): examples/satellite_pair.jl:8-40  params = {J1[9], J2[9]} */
-    RDHIP_MODEL_LIE_SATELLITE = 6      /* LieGroupModel, LieState(R,(3,0)), x = [w; q]: test/liemodel.jl:1-22  params = {Jdiag[3]}     */
+    RDHIP_MODEL_LIE_SATELLITE = 6,     /* LieGroupModel, LieState(R,(3,0)), x = [w; q]: test/liemodel.jl:1-22  params = {Jdiag[3]}     */
+    RDHIP_MODEL_CUSTOM = 7             /* user-written dynamics, JIT-compiled with hipRTC: rdhip_model_create_custom                  */
 } rdhip_model_kind;
 
 typedef enum { RDHIP_ROT_QUAT = 0, RDHIP_ROT_MRP = 1, RDHIP_ROT_RP = 2 } rdhip_rotation;   /* src/liestate.jl:42-46 */
@@ -95,6 +96,21 @@ int rdhip_memcpy_d2h(rdhip_ctx* ctx, void* dst, const void* src, unsigned long l
 /* host-only object (no GPU needed) */
 int rdhip_model_create(int kind, int rotation, int velocity_frame, const double* params, int nparams, rdhip_model** out);
 int rdhip_model_destroy(rdhip_model* model);
+/* A user-defined ContinuousDynamics model (the reference's `dynamics(model, x, u)` method, src/dynamics.jl:23-45), given as HIP source:
+ * `dynamics_body` is the BODY of
+ *       template <class S> __device__ void f(const S* x, const S* u, S* xdot) const
+ * written on a generic scalar S (the library instantiates it with T = float/double and with forward duals), with the model parameters
+ * available as `p[i]` (type T) and the dual-aware functions sin_, cos_, sqrt_, max0_ plus + - * / (scalar.hpp); `preamble` (may be NULL)
+ * is pasted at namespace scope in front of the model (helper device functions).  Kernels are JIT-compiled with hipRTC for gfx950 on
+ * first use per (operation, rule, dtype) and cached in the model; every rule, diff method and dtype of the compiled-in models works.
+ * LieState models: pass rotation = RDHIP_ROT_QUAT and the partition P (as LieState{R,P}, src/liestate.jl:75-83), nP = 0 for Euclidean.
+ * n <= 16, m <= 8, nparams <= 64.  Compilation errors come back as RDHIP_ERR_INVALID_ARG with the compiler log in rdhip_last_error(NULL)
+ * (creation does not compile; the first use or rdhip_model_precompile does). */
+int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const char* preamble, const double* params, int nparams,
+                              int rotation, const int* P, int nP, rdhip_model** out);
+/* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
+ * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian; custom models only */
+int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
 /* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
 int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);
 /* statevectortype: 0 = EuclideanState, 1 = RotationState (src/statevectortype.jl:63,73; src/liestate.jl:22) */

@@ -166,7 +166,38 @@ int rdhip_model_create(int kind, int rot, int frame, const double* params, int n
     build_lie(M);
     *out = M; return RDHIP_OK;
 }
-int rdhip_model_destroy(rdhip_model* M) { delete M; return RDHIP_OK; }
+int rdhip_model_destroy(rdhip_model* M) { if (M && M->d.jit) jit_model_destroy(M->d.jit); delete M; return RDHIP_OK; }
+
+int rdhip_model_create_custom(int n, int m, const char* body, const char* preamble, const double* params, int nparams, int rot, const int* P, int nP, rdhip_model** out) {
+    if (!out) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!body || !*body) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "dynamics_body is empty");
+    if (n <= 0 || m <= 0 || n > 16 || m > 8) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "unsupported dimensions n=%d m=%d (n <= 16, m <= 8)", n, m);
+    if (nparams < 0 || nparams > 64 || (nparams > 0 && !params)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad params (nparams=%d)", nparams);
+    if (nP < 0 || nP > 8 || (nP > 0 && !P)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad LieState partition (nP=%d)", nP);
+    if (nP > 0 && (rot < RDHIP_ROT_QUAT || rot > RDHIP_ROT_RP)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad rotation %d", rot);
+    rdhip_model* M = new (std::nothrow) rdhip_model();
+    if (!M) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
+    ModelDesc& d = M->d; std::memset(&d, 0, sizeof d);
+    d.kind = RDHIP_MODEL_CUSTOM; d.rot = nP > 0 ? rot : RDHIP_ROT_QUAT; d.frame = RDHIP_FRAME_WORLD; d.n = n; d.m = m; d.nparams = nparams;
+    for (int i = 0; i < nparams; ++i) d.params[i] = params[i];
+    d.lie_nP = nP;
+    int sp = 0; for (int i = 0; i < nP; ++i) { if (P[i] < 0) { delete M; return fail(nullptr, RDHIP_ERR_INVALID_ARG, "negative LieState block"); } d.lie_P[i] = P[i]; sp += P[i]; }
+    if (nP > 0) {
+        const int len = rot_params(d.rot) * (nP - 1) + sp;                  // length(LieState{R,P}), src/liestate.jl:121-123
+        if (len != n) { delete M; return fail(nullptr, RDHIP_ERR_DIM_MISMATCH, "LieState partition has length %d but n = %d", len, n); }
+        d.e = 3 * (nP - 1) + sp;
+    } else d.e = n;
+    d.jit = jit_model_create(n, m, body, preamble, d.params, nparams);
+    build_lie(M);
+    *out = M; return RDHIP_OK;
+}
+int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
+    if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
+    if (op < 0 || op > 4 || rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4 || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    const int rc = jit_precompile(M->d.jit, op, rule, dtype);
+    return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
+}
 int rdhip_model_dims(const rdhip_model* M, int* n, int* m, int* p, int* e) {
     if (!M) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "model is NULL");
     if (n) *n = M->d.n; if (m) *m = M->d.m; if (p) *p = M->d.n; if (e) *e = M->d.e; return RDHIP_OK;
@@ -259,8 +290,10 @@ static int check_rotation(rdhip_ctx* c, const rdhip_model* M) {
         return fail(c, RDHIP_ERR_UNSUPPORTED, "only QuatRotation models have kernels (MRP / RodriguesParam: index queries only)");
     return RDHIP_OK;
 }
+static thread_local const ModelDesc* g_jit_model = nullptr;     // set by family_* for custom models so that kernel_status can report the JIT error
 static int kernel_status(rdhip_ctx* c, int rc, const char* what) {
     if (rc == RDHIP_OK) return rc;
+    if (g_jit_model && g_jit_model->jit) { const ModelDesc* d = g_jit_model; g_jit_model = nullptr; return fail(c, rc, "%s: %s", what, jit_last_error(d->jit)); }
     if (rc == RDHIP_ERR_HIP) return fail(c, rc, "%s: kernel launch failed: %s", what, hipGetErrorString(hipGetLastError()));
     if (rc == RDHIP_ERR_NOT_IMPLEMENTED) return fail(c, rc, "%s: User-defined Jacobian not implemented for this model", what);
     if (rc == RDHIP_ERR_UNSUPPORTED) return fail(c, rc, "%s: model dimensions / kind not compiled in", what);
@@ -268,6 +301,8 @@ static int kernel_status(rdhip_ctx* c, int rc, const char* what) {
 }
 
 static int family_eval(const ModelDesc& d, int rule, int dtype, const LaunchArgs& a) {
+    g_jit_model = nullptr;
+    if (d.kind == RDHIP_MODEL_CUSTOM) { const int rc = jit_eval(d.jit, rule, dtype, a); if (rc) g_jit_model = &d; return rc; }
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_eval(d, rule, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_eval(d, rule, dtype, a);
@@ -277,6 +312,8 @@ static int family_eval(const ModelDesc& d, int rule, int dtype, const LaunchArgs
     }
 }
 static int family_jacobian(const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& a) {
+    g_jit_model = nullptr;
+    if (d.kind == RDHIP_MODEL_CUSTOM) { const int rc = jit_jacobian(d.jit, rule, diff, dtype, a); if (rc) g_jit_model = &d; return rc; }
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_jacobian(d, rule, diff, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_jacobian(d, rule, diff, dtype, a);
@@ -286,6 +323,8 @@ static int family_jacobian(const ModelDesc& d, int rule, int diff, int dtype, co
     }
 }
 static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchArgs& a) {
+    g_jit_model = nullptr;
+    if (d.kind == RDHIP_MODEL_CUSTOM) { const int rc = jit_rollout(d.jit, rule, dtype, a); if (rc) g_jit_model = &d; return rc; }
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_rollout(d, rule, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_rollout(d, rule, dtype, a);

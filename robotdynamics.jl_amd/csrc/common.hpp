@@ -34,6 +34,7 @@ struct ModelDesc {
     double params[64];
     int lie_nP;        // 0 => EuclideanState
     int lie_P[8];
+    void* jit;         // RDHIP_MODEL_CUSTOM: the hipRTC plug-in object (jit.hip)
 };
 
 struct LaunchArgs {
@@ -60,6 +61,15 @@ RD_DECLARE_FAMILY(fam_quadrotor)
 RD_DECLARE_FAMILY(fam_lie)
 int fam_satellite_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
 int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);         // satellite pair, lie satellite
+
+// hipRTC model plug-in (jit.hip)
+void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np);
+void jit_model_destroy(void* h);
+const char* jit_last_error(void* h);
+int jit_precompile(void* h, int op, int rule, int dtype);
+int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a);
+int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a);
+int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a);
 
 // error-state kernels (errstate.hip)
 struct LieDesc {

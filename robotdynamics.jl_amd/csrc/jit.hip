@@ -1,0 +1,194 @@
+// jit.hip -- hipRTC model plug-in: user-defined continuous dynamics on the GPU.
+//
+// The reference is built around user-written `dynamics(model, x, u)` methods (src/dynamics.jl:23-45; RigidBody users write
+// `forces` / `moments`, src/rigidbody.jl:244-258).  Julia cannot be compiled for the GPU here, so a custom model is given as the
+// BODY of a HIP device function, written once on a generic scalar type S:
+//
+//     template <class S> __device__ void f(const S* x, const S* u, S* xdot) const   // p[] = the model's parameters (type T)
+//     { <body> }
+//
+// and the library JIT-compiles the same kernel templates the compiled-in models use (kernels.hpp, embedded at build time) for
+// that model with hipRTC: `S` becomes T for evaluation and Dual<T,K> for ForwardAD / the chain rule, so every rule (Euler, RK2,
+// RK3, RK4), diff method (ForwardAD, FiniteDifference, UserDefined) and dtype is available.  Kernels are compiled lazily per
+// (operation, rule, dtype) on first use (a few seconds each) and cached in the model object.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "common.hpp"
+#include "embedded_headers.inc"
+
+namespace rd {
+
+struct JitKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; size_t lds = 0; int block = 0; bool persistent = false; bool small = false; };
+struct JitModel {
+    int n = 0, m = 0, np = 0;
+    std::string name, body, preamble;
+    std::vector<double> params;
+    std::mutex mu;
+    std::map<std::string, std::vector<char>> code;        // key -> code object (device independent)
+    std::map<std::string, std::string> lowered;
+    std::map<std::string, JitKernel> loaded;              // key@device -> loaded function
+    std::string err;
+};
+
+enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4 };
+
+static std::string program_source(const JitModel& M) {
+    std::ostringstream s;
+    s << "#include \"kernels.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
+      << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
+      << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
+      << "    template <class S> RD_DEV void f(const S* x, const S* u, S* xdot) const {\n" << M.body << "\n    }\n};\n}\n";
+    return s.str();
+}
+static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
+    const char* T = dtype == RDHIP_F64 ? "double" : "float";
+    const int nz = M.n + M.m;
+    std::ostringstream fn, s;
+    fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
+    const int ng = nz >= 4 ? 4 : nz;
+    std::ostringstream plan; plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
+    switch (op) {
+        case JOP_EVAL: s << "rd::eval_kernel<" << fn.str() << ", " << T << ">"; break;
+        case JOP_ROLLOUT: s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">"; break;
+        case JOP_JAC_AD:
+            if (nz <= 10) s << "rd::jac_ad_small_kernel<" << fn.str() << ", " << T << ">";
+            else s << "rd::jac_ad_loop_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">";
+            break;
+        case JOP_JAC_FD: s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
+        default: s << "rd::jac_chain_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
+    }
+    return s.str();
+}
+
+// compile (no GPU needed): code object + lowered kernel name for (op, rule, dtype)
+static int jit_compile(JitModel& M, int op, int rule, int dtype, const std::string& key) {
+    if (M.code.count(key)) return RDHIP_OK;
+    const std::string src = program_source(M), expr = kernel_expr(M, op, rule, dtype);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "rdhip_user_model.hip", rdhip_embedded_count, rdhip_embedded_sources, rdhip_embedded_names) != HIPRTC_SUCCESS) {
+        M.err = "hiprtcCreateProgram failed"; return RDHIP_ERR_HIP;
+    }
+    hiprtcAddNameExpression(prog, expr.c_str());
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize", "-DRDHIP_RTC=1"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, ' '); if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        M.err = "hipRTC compilation of the user model failed:\n" + log.substr(0, 3000);
+        hiprtcDestroyProgram(&prog);
+        return RDHIP_ERR_INVALID_ARG;
+    }
+    const char* low = nullptr;
+    if (hiprtcGetLoweredName(prog, expr.c_str(), &low) != HIPRTC_SUCCESS || !low) { M.err = "hiprtcGetLoweredName failed for " + expr; hiprtcDestroyProgram(&prog); return RDHIP_ERR_HIP; }
+    M.lowered[key] = low;
+    size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    M.code[key] = std::move(code);
+    return RDHIP_OK;
+}
+
+static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
+    std::lock_guard<std::mutex> g(M.mu);
+    std::ostringstream k; k << op << ":" << rule << ":" << dtype;
+    const std::string key = k.str();
+    int rc = jit_compile(M, op, rule, dtype, key); if (rc) return rc;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { M.err = "hipGetDevice failed"; return RDHIP_ERR_NO_DEVICE; }
+    std::ostringstream kd; kd << key << "@" << dev;
+    auto it = M.loaded.find(kd.str());
+    if (it == M.loaded.end()) {
+        JitKernel jk;
+        if (hipModuleLoadData(&jk.mod, M.code[key].data()) != hipSuccess) { M.err = "hipModuleLoadData failed"; return RDHIP_ERR_HIP; }
+        if (hipModuleGetFunction(&jk.fn, jk.mod, M.lowered[key].c_str()) != hipSuccess) { M.err = "hipModuleGetFunction failed for " + M.lowered[key]; return RDHIP_ERR_HIP; }
+        const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = M.n + M.m, ny = M.n;
+        jk.small = (op == JOP_JAC_AD && nz <= 10);
+        if (op == JOP_EVAL) jk.block = 256;
+        else if (op == JOP_ROLLOUT) jk.block = 64;
+        else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
+        else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
+        if (jk.lds > 64 * 1024) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(jk.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jk.lds) != hipSuccess) {
+                (void)hipGetLastError(); M.err = "model too large for the JIT tile kernels (LDS tile > 64 KB and the attribute call failed)"; return RDHIP_ERR_UNSUPPORTED;
+            }
+        }
+        it = M.loaded.emplace(kd.str(), jk).first;
+    }
+    *out = &it->second;
+    return RDHIP_OK;
+}
+
+// ---- entry points used by api.hip ------------------------------------------------------------------------------------
+void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np) {
+    JitModel* M = new JitModel();
+    M->n = n; M->m = m; M->np = np; M->body = body ? body : ""; M->preamble = preamble ? preamble : "";
+    M->params.assign(params, params + np);
+    return M;
+}
+void jit_model_destroy(void* h) {
+    JitModel* M = static_cast<JitModel*>(h);
+    if (!M) return;
+    for (auto& kv : M->loaded) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    delete M;
+}
+const char* jit_last_error(void* h) { return static_cast<JitModel*>(h)->err.c_str(); }
+int jit_precompile(void* h, int op, int rule, int dtype) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    std::lock_guard<std::mutex> g(M.mu);
+    std::ostringstream k; k << op << ":" << rule << ":" << dtype;
+    return jit_compile(M, op, rule, dtype, k.str());
+}
+
+static void pack_params(const JitModel& M, int dtype, std::vector<unsigned char>& buf) {
+    const int np = M.np > 0 ? M.np : 1;
+    if (dtype == RDHIP_F64) { buf.resize(np * 8); std::vector<double> p(np, 0.0); for (int i = 0; i < M.np; ++i) p[i] = M.params[i]; std::memcpy(buf.data(), p.data(), np * 8); }
+    else { buf.resize(np * 4); std::vector<float> p(np, 0.0f); for (int i = 0; i < M.np; ++i) p[i] = (float)M.params[i]; std::memcpy(buf.data(), p.data(), np * 4); }
+}
+static int launch(JitModel& M, JitKernel* k, unsigned grid, hipStream_t s, void** args) {
+    if (hipModuleLaunchKernel(k->fn, grid, 1, 1, k->block, 1, 1, (unsigned)k->lds, s, args, nullptr) != hipSuccess) { M.err = "hipModuleLaunchKernel failed"; return RDHIP_ERR_HIP; }
+    return RDHIP_OK;
+}
+int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    if (a.N == 0) return RDHIP_OK;
+    JitKernel* k; int rc = jit_get(M, JOP_EVAL, rule, dtype, &k); if (rc) return rc;
+    std::vector<unsigned char> fn; pack_params(M, dtype, fn);
+    long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* Y = a.Y;
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y};
+    return launch(M, k, (unsigned)((N + 255) / 256), a.stream, args);
+}
+int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    if (a.N == 0 || a.K == 0) return RDHIP_OK;
+    JitKernel* k; int rc = jit_get(M, JOP_ROLLOUT, rule, dtype, &k); if (rc) return rc;
+    std::vector<unsigned char> fn; pack_params(M, dtype, fn);
+    long long K = a.K, Mt = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; const void* X0 = a.X0;
+    void* args[] = {fn.data(), &K, &Mt, &Z, &t, &dt, &X0};
+    return launch(M, k, (unsigned)((Mt + 63) / 64), a.stream, args);
+}
+int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    if (a.N == 0) return RDHIP_OK;
+    const int op = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
+    JitKernel* k; int rc = jit_get(M, op, rule, dtype, &k); if (rc) return rc;
+    std::vector<unsigned char> fn; pack_params(M, dtype, fn);
+    long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* J = a.J; void* Y = a.Y;
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &J, &Y};
+    const long long ntiles = (N + 63) / 64;
+    unsigned grid;
+    if (k->small) grid = (unsigned)((ntiles + 3) / 4);
+    else {   // persistent tile loop: as many workgroups as fit at once, never more than tiles (dispatch.hpp tile_grid)
+        int per_cu = (int)(160 * 1024 / (k->lds ? k->lds : 1)); const int by_waves = 2048 / k->block;
+        if (per_cu > by_waves) per_cu = by_waves; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+        const long long g = 256LL * per_cu; grid = (unsigned)(ntiles < g ? ntiles : g);
+    }
+    return launch(M, k, grid, a.stream, args);
+}
+
+}  // namespace rd

@@ -6,7 +6,9 @@
 // that (built with -fno-signed-zeros -ffinite-math-only) the structural zeros of the stage Jacobians fold
 // away at compile time and only the ~145/247 structurally non-zero entries cost arithmetic.
 #pragma once
+#ifndef __HIPCC_RTC__      // hipRTC pre-includes the HIP runtime header
 #include <hip/hip_runtime.h>
+#endif
 
 #define RD_DEV __device__ __forceinline__
 #define RD_HD __host__ __device__ __forceinline__

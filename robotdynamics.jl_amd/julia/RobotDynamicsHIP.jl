@@ -66,6 +66,7 @@ end
 # every per-knot method of the reference keeps working on the CPU; only the batched methods below go to the GPU.
 mutable struct Handle
     ptr::Ptr{Cvoid}
+    Handle(ptr::Ptr{Cvoid}) = new(ptr)
     function Handle(kind, rot, frame, params::Vector{Float64})
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:rdhip_model_create, librdhip), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Cint, Ref{Ptr{Cvoid}}),
@@ -111,6 +112,19 @@ function RD.dynamics(m::Cartpole, x, u)        # examples/cartpole.jl:15-34
     B = @SVector [1, 0]
     qdd = -H \ (C * qd + G - B * u[1])
     return [qd; qdd]
+end
+
+# A user-defined model: the Julia `dynamics` method runs on the CPU (per-knot calls), `hip_source` is the same function written as a
+# HIP device-function body for the batched GPU path (include/rdhip.h, rdhip_model_create_custom)
+function custom_handle(n::Integer, m::Integer, hip_source::String; params=Float64[], preamble="", rotation=ROT_QUAT, P=Int[])
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    p = collect(Float64, params); Pc = collect(Cint, P)
+    rc = ccall((:rdhip_model_create_custom, librdhip), Cint,
+               (Cint, Cint, Cstring, Cstring, Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}),
+               n, m, hip_source, preamble, p, length(p), rotation, Pc, length(Pc), out)
+    rc == 0 || throw(ArgumentError(unsafe_string(ccall((:rdhip_last_error, librdhip), Cstring, (Ptr{Cvoid},), C_NULL))))
+    h = Handle(out[])
+    finalizer(x -> ccall((:rdhip_model_destroy, librdhip), Cint, (Ptr{Cvoid},), x.ptr), h)
 end
 
 handle(m) = m.handle.ptr

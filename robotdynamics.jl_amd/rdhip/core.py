@@ -559,6 +559,53 @@ def integration(model):
     return model.integrator
 
 
+class CustomModel(ContinuousDynamics):
+    """A user-defined ContinuousDynamics model -- the reference's `dynamics(model, x, u)` method (src/dynamics.jl:23-45) -- given as
+    the body of a HIP device function written on a generic scalar type S:
+
+        pendulum = RD.CustomModel(2, 1, params=(9.81, 1.0, 0.1), dynamics=
+            "xdot[0] = x[1];"
+            "xdot[1] = (u[0] - x[1] * p[2]) / (p[1] * p[1]) - sin_(x[0]) * (p[0] / p[1]);")
+
+    `x`, `u`, `xdot` are arrays of S, `p[i]` are the parameters (type T = float/double); use sin_, cos_, sqrt_, max0_ and the
+    arithmetic operators (they are defined for T and for forward duals, csrc/scalar.hpp).  The library JIT-compiles its kernel
+    templates for this model with hipRTC on first use (a few seconds per (operation, rule, dtype)), after which every operator
+    of the compiled-in models works: dynamics, discrete_dynamics, jacobian! with ForwardAD / FiniteDifference / UserDefined,
+    rollout!, dynamics_error, and -- with `liestate=(R, P)` as in LieState{R,P} -- the error-state operators."""
+    _kind = L.MODEL_CUSTOM
+    _OPS = {"evaluate": 0, "rollout": 1, "ForwardAD": 2, "FiniteDifference": 3, "UserDefined": 4}
+
+    def __init__(self, n, m, dynamics, params=(), preamble="", liestate=None):
+        self.n, self.m = int(n), int(m)
+        self.dynamics_source, self.preamble = str(dynamics), str(preamble)
+        self.params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).ravel())
+        if liestate is not None:
+            R, P = liestate
+            self.rotation, self._P = R, tuple(int(v) for v in P)
+        else:
+            self._P = ()
+
+    def _params(self):
+        return self.params
+
+    @property
+    def _handle(self):
+        h = getattr(self, "_h", None)
+        if h is None:
+            h = C.c_void_p()
+            P = (C.c_int * max(len(self._P), 1))(*self._P)
+            p = self.params
+            L.check(L.lib().rdhip_model_create_custom(self.n, self.m, self.dynamics_source.encode(), self.preamble.encode(),
+                                                      p.ctypes.data_as(C.POINTER(C.c_double)), p.size, self.rotation.code, P, len(self._P), C.byref(h)))
+            self._h = h
+        return h
+
+    def precompile(self, what="ForwardAD", rule=RK4, dtype=np.float64):
+        """JIT-compile one kernel now (works without a GPU); raises ValueError with the compiler log if the source does not compile."""
+        code = L.CONTINUOUS if rule is None else _rule_code(rule() if isinstance(rule, type) else rule)
+        L.check(L.lib().rdhip_model_precompile(self._handle, self._OPS[what], code, L.F64 if np.dtype(dtype) == np.float64 else L.F32))
+
+
 class LieGroupModel(ContinuousDynamics):
     pass
 

@@ -414,6 +414,64 @@ def test_error_state_expansion_fused_into_the_jacobian_kernel(where):
                 np.testing.assert_allclose(host(y), yo, rtol=0, atol=TOL)
 
 
+SATELLITE_SRC = """
+    // src/rigidbody.jl:213-236 with the satellite wrench (examples/single_satellite.jl:18-27), world-frame velocity; p = {mass, Jxx, Jyy, Jzz}
+    const S* q = x + 3; const S* v = x + 7; const S* w = x + 10;
+    S F[3]; quat_rotate(q, u, F);
+    quat_kinematics(q, w, xdot + 3);
+    const T im = T(1) / p[0];
+    for (int i = 0; i < 3; ++i) { xdot[i] = v[i]; xdot[7 + i] = F[i] * im; }
+    const S Jw[3] = {w[0] * p[1], w[1] * p[2], w[2] * p[3]};
+    S c[3]; cross3(w, Jw, c);
+    xdot[10] = (u[3] - c[0]) / p[1]; xdot[11] = (u[4] - c[1]) / p[2]; xdot[12] = (u[5] - c[2]) / p[3];
+"""
+
+
+def test_custom_models_jit_match_the_compiled_in_ones():
+    """User-defined dynamics through the hipRTC plug-in: the cartpole and the satellite re-written as source strings must reproduce
+    the oracle for every operator (dynamics, RK3/RK4 steps, all three diff methods, rollout, error-state operators, fp32)."""
+    rng = np.random.default_rng(31)
+    cart = RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81))
+    sat = RD.CustomModel(13, 6, SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
+    for model, om, Zn in ((cart, O.cartpole(), rng.random((150, 5))), (sat, O.body(), H.rand_rigid(rng, 150, 6))):
+        N = Zn.shape[0]
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        t, dt = np.arange(N) * 0.05, np.full(N, 0.05); dt[-1] = 0.0
+        Z = traj(model, Zn, t, dt, "cuda")
+        np.testing.assert_allclose(host(RD.dynamics(model, Z)), om.dynamics(Zn, t, dt), rtol=0, atol=TOL)
+        for Q, rule in ((RD.RK4, O.RK4), (RD.RK3, O.RK3)):
+            dm = RD.DiscretizedDynamics(model, Q)
+            np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), om.discrete_dynamics(rule, Zn, t, dt), rtol=0, atol=TOL)
+            J = RD.alloc_jacobians(dm, N, Z.data)
+            Y = torch.empty((N, n), dtype=torch.float64, device="cuda")
+            Jo, Yo = om.jacobian(rule, O.FORWARD_AD, Zn, t, dt)
+            for diff, tol in ((RD.ForwardAD(), TOL), (RD.UserDefined(), TOL), (RD.FiniteDifference(), 1e-6)):
+                J.fill_(3.0)
+                RD.jacobian_(RD.StaticReturn(), diff, dm, J, Y, Z)
+                np.testing.assert_allclose(host(J), Jo, rtol=0, atol=tol * max(1.0, np.abs(Jo).max()))
+                np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), om.dynamics_error(O.RK4, Zn, t, dt), rtol=0, atol=TOL)
+        E = RD.alloc_error_expansions(dm, N, Z.data)
+        RD.error_expansion_(dm, E, None, Z)
+        np.testing.assert_allclose(host(E), om.error_expansion(O.RK4, Zn, t, dt)[0], rtol=0, atol=TOL * 10)
+        G = RD.alloc_errstate_jacobians(model, N, Z.data)
+        RD.errstate_jacobian_(model, G, Z, clear=True)
+        np.testing.assert_allclose(host(G), om.errstate_jacobian(Zn[:, :n]), rtol=0, atol=TOL)
+        # fp32 instantiation of the same source
+        Zf = traj(model, Zn, t, dt, "cuda", dtype=np.float32)
+        Jf = RD.alloc_jacobians(dm, N, Zf.data)
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, Jf, None, Zf)
+        Jo32, _ = om.jacobian(O.RK4, O.FORWARD_AD, Zn.astype(np.float32).astype(np.float64), t, dt)
+        np.testing.assert_allclose(host(Jf), Jo32, rtol=1e-4, atol=1e-4)
+    # rollout of the custom cartpole
+    M, K = 9, 30
+    data = rng.random((M, K, 5)); tt = np.tile(np.arange(K) * 0.02, (M, 1)); dd = np.full((M, K), 0.02)
+    stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+    RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(cart, RD.RK4), stack)
+    np.testing.assert_allclose(host(stack["data"]), O.cartpole().rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21

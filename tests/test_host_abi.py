@@ -11,6 +11,7 @@ import pytest
 
 import rdhip as RD
 from oracle import rd_oracle as O
+from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -223,3 +224,22 @@ def test_shard_ranges_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == N
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert sum(P.shard_sizes(N, world)) == N
+
+
+
+
+
+def test_custom_model_jit_compiles_without_a_gpu():
+    """hipRTC plug-in (user-defined dynamics): creation, integer queries and JIT compilation need no GPU; a body that
+    does not compile raises ValueError carrying the compiler log."""
+    m = RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81))
+    assert RD.dims(m) == (4, 1, 4) and RD.errstate_dim(m) == 4 and isinstance(RD.statevectortype(m), RD.EuclideanState)
+    m.precompile("ForwardAD", RD.RK4, np.float64)
+    m.precompile("evaluate", None, np.float32)
+    bad = RD.CustomModel(2, 1, "xdot[0] = x[1]; xdot[1] = undefined_symbol;")
+    with pytest.raises(ValueError, match="undefined_symbol"):
+        bad.precompile("evaluate", RD.RK4)
+    lie = RD.CustomModel(7, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0)))
+    assert RD.errstate_dim(lie) == 6 and isinstance(RD.statevectortype(lie), RD.RotationState)
+    with pytest.raises(ValueError):
+        RD.dims(RD.CustomModel(8, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0))))     # LieState length 7 != n
