@@ -194,7 +194,7 @@ int rdhip_model_create_custom(int n, int m, const char* body, const char* preamb
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 4 || rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4 || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || op > 6 || rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4 || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }

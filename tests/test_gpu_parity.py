@@ -464,6 +464,14 @@ def test_custom_models_jit_match_the_compiled_in_ones():
         RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, Jf, None, Zf)
         Jo32, _ = om.jacobian(O.RK4, O.FORWARD_AD, Zn.astype(np.float32).astype(np.float64), t, dt)
         np.testing.assert_allclose(host(Jf), Jo32, rtol=1e-4, atol=1e-4)
+    # 8-byte aligned slab: custom models with n+m > 10 fall back from the split-role kernel to the element-wise one
+    N = 100
+    Zn = H.rand_rigid(rng, N, 6); t, dt = np.zeros(N), np.full(N, 0.05)
+    Z = traj(sat, Zn, t, dt, "cuda")
+    buf = torch.zeros(N * 247 + 1, dtype=torch.float64, device="cuda")
+    Ju = buf[1:].view(N, 19, 13).transpose(1, 2)
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(sat, RD.RK4), Ju, None, Z)
+    np.testing.assert_allclose(host(Ju), O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)[0], rtol=0, atol=TOL)
     # rollout of the custom cartpole
     M, K = 9, 30
     data = rng.random((M, K, 5)); tt = np.tile(np.arange(K) * 0.02, (M, 1)); dd = np.full((M, K), 0.02)

@@ -1,0 +1,13 @@
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "robotdynamics.jl_amd")
+import numpy as np, torch, rdhip as RD
+from tests.test_gpu_parity import SATELLITE_SRC
+sys.path.insert(0, "tools")
+import bench_configs as B
+rng = np.random.default_rng(1)
+Zs = B.rigid_inputs(65536, 6, rng)
+sat = RD.CustomModel(13, 6, SATELLITE_SRC, params=(1.0, 1.0, 1.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
+B.jac_case("JIT satellite RK4 jacobian ForwardAD (split-role kernel, contiguous plan)", sat, Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
+B.jac_case("JIT satellite RK4 jacobian UserDefined", sat, Zs, RD.RK4, RD.UserDefined(), np.float64, 30)
+B.jac_case("built-in satellite RK4 jacobian ForwardAD", RD.Satellite(), Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
+B.eval_case("JIT satellite RK4 discrete_dynamics", sat, Zs, RD.RK4, np.float64, 30)
