@@ -247,6 +247,35 @@ def errstate_case(P, X, Xbar, X0):
     return {"G": G, "dG": dG, "dX": dX}
 
 
+def expansion_case(f, n, m, P, Z, dt):
+    """Error-state expansion of consecutive knot points from the DEFINITIONS (no L(q)H closed form, no chain through A):
+         E_k = G(x_{k+1})' * d/d(delta, u) [ f_d(x_k (+) delta, u_k) ]  at delta = 0,
+    with G(x) = d/d(delta) [x (+) delta] at 0 (unit quaternions, so x (+) 0 = x).  Euclidean models (P = None): E_k = d f_d / d z.
+    Also the dynamics error f_d(z_k) - x_{k+1} (reference src/discrete_dynamics.jl:134-135)."""
+    Zt, dtt = torch.as_tensor(Z), torch.as_tensor(dt)
+    N = Zt.shape[0]
+    out = {}
+    if P is not None:
+        comp, _ = compose(P)
+        e = sum(P) + 3 * (len(P) - 1)
+    for rule in ("rk3", "rk4"):
+        step = rk_step(f, rule)
+        Es, errs = [], []
+        for k in range(N - 1):
+            x, u, h = Zt[k, :n], Zt[k, n:], dtt[k]
+            errs.append(step(x, u, h) - Zt[k + 1, :n])
+            if P is None:
+                Es.append(jacfwd(lambda z: step(z[:n], z[n:], h))(Zt[k]))
+                continue
+            z0 = torch.zeros(e)
+            G2 = jacfwd(lambda d: comp(Zt[k + 1, :n], d))(z0)
+            Jdu = jacfwd(lambda du: step(comp(x, du[:e]), u + du[e:], h))(torch.zeros(e + m))
+            Es.append(G2.T @ Jdu)
+        out["E_" + rule] = torch.stack(Es).numpy()
+        out["err_" + rule] = torch.stack(errs).numpy()
+    return out
+
+
 # ---------------------------------------------------------------- input generators (rand(model))
 def rand_rigid(rng, N, m, ulo=0.0, uhi=1.0):
     q = rng.standard_normal((N, 4))
@@ -303,6 +332,16 @@ def main():
     for name, res in cases.items():
         np.savez_compressed(os.path.join(HERE, f"dyn_{name}.npz"), **res)
 
+    # error-state expansion / dynamics error along the same knot sequences (unit quaternions), from the definitions
+    specs = {"cartpole": (cartpole((1.0, 0.2, 0.5, 9.81)), None), "satellite_world": (rigid_body(1.0, Jsat, satellite_wrench, 6, 0), (3, 6)),
+             "body_body": (rigid_body(2.0, Jbody, satellite_wrench, 6, 1), (3, 6)), "satfull_world": (rigid_body(1.7, Jfull, satellite_wrench, 6, 0), (3, 6)),
+             "quadrotor_world": (rigid_body(0.5, np.diag([0.0023, 0.0023, 0.004]), quadrotor_wrench(0.5, [0, 0, -9.81], 0.1750, 1.0, 0.0245), 4, 0), (3, 6)),
+             "satpair": (satellite_pair(np.eye(3), 2 * np.eye(3)), (0, 3, 3)), "liesat": (lie_satellite([1.0, 1.0, 1.0]), (3, 0))}
+    for name, (fnm, P) in specs.items():
+        f, n, m = fnm
+        res = expansion_case(f, n, m, P, cases[name]["Z"], cases[name]["dt"])
+        np.savez_compressed(os.path.join(HERE, f"exp_{name}.npz"), **res)
+
     # error-state fixtures: rigid body (3,6), satellite pair (0,3,3), test/liestate.jl's (3,2,3) with NON-unit
     # quaternions (x = rand(n), test/liestate.jl:50-51), lie satellite (3,0)
     for tag, P in (("rigid", (3, 6)), ("satpair", (0, 3, 3)), ("p323", (3, 2, 3)), ("liesat", (3, 0))):
@@ -317,7 +356,7 @@ def main():
         res = errstate_case(P, X, Xb, X0)
         res.update({"X": X, "Xbar": Xb, "X0": X0, "P": np.asarray(P)})
         np.savez_compressed(os.path.join(HERE, f"err_{tag}.npz"), **res)
-    print("wrote", len(cases) + 4, "fixtures to", HERE)
+    print("wrote", len(cases) + 4 + len(specs), "fixtures to", HERE)
 
 
 if __name__ == "__main__":

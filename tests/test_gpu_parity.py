@@ -480,6 +480,22 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     np.testing.assert_allclose(host(stack["data"]), O.cartpole().rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("name", ["cartpole", "satellite_world", "body_body", "satfull_world", "quadrotor_world", "satpair", "liesat"])
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_golden_error_expansion_and_dynamics_error(name, where):
+    """HIP path against the definition-derived fixtures exp_*.npz (torch, independent of both the oracle and the L(q)H closed form)."""
+    d, g = H.load("dyn_" + name), H.load("exp_" + name)
+    model = rd_model(name, d)
+    N = d["Z"].shape[0]
+    Z = traj(model, d["Z"], d["t"], d["dt"], "cuda" if where == "cuda" else None)
+    for rn, Q in (("rk3", RD.RK3), ("rk4", RD.RK4)):
+        dm = RD.DiscretizedDynamics(model, Q)
+        np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), g["err_" + rn], rtol=0, atol=TOL)
+        E = RD.alloc_error_expansions(dm, N, Z.data)
+        RD.error_expansion_(dm, E, None, Z)
+        np.testing.assert_allclose(host(E), g["E_" + rn], rtol=0, atol=TOL * max(1.0, np.abs(g["E_" + rn]).max()))
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21

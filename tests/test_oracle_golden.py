@@ -73,3 +73,22 @@ def test_errstate(tag, mk):
     np.testing.assert_allclose(M.errstate_jacobian(d["X"]), d["G"], rtol=0, atol=TOL)
     np.testing.assert_allclose(M.nabla_errstate_jacobian(d["X"], d["Xbar"]), d["dG"], rtol=0, atol=TOL)
     np.testing.assert_allclose(M.state_diff(d["X"], d["X0"]), d["dX"], rtol=0, atol=1e-9)
+
+
+EXP_CASES = ["cartpole", "satellite_world", "body_body", "satfull_world", "quadrotor_world", "satpair", "liesat"]
+
+
+@pytest.mark.parametrize("name", EXP_CASES)
+def test_dynamics_error_and_error_expansion_against_the_definition(name):
+    """exp_*.npz: E_k = G(x_{k+1})' d f_d(x_k (+) delta, u)/d(delta, u) and e_k = f_d(z_k) - x_{k+1}, differentiated by torch from the
+    composition map itself (tests/golden/make_golden.py) -- independent of the oracle's G2' [A G1 | B] product."""
+    d, g = H.load("dyn_" + name), H.load("exp_" + name)
+    M = H.oracle_model(name, d)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    for rn, rule in (("rk3", O.RK3), ("rk4", O.RK4)):
+        np.testing.assert_allclose(M.dynamics_error(rule, Z, t, dt), g["err_" + rn], rtol=0, atol=TOL)
+        E, _ = M.error_expansion(rule, Z, t, dt)
+        np.testing.assert_allclose(E, g["E_" + rn], rtol=0, atol=TOL * max(1.0, np.abs(g["E_" + rn]).max()))
+        J2, J1, e = M.dynamics_error_jacobian(rule, O.FORWARD_AD, Z, t, dt)
+        np.testing.assert_allclose(J1, d["Jd_" + rn][:-1], rtol=0, atol=TOL * max(1.0, np.abs(d["Jd_" + rn]).max()))
+        np.testing.assert_allclose(e, g["err_" + rn], rtol=0, atol=TOL)
