@@ -243,3 +243,18 @@ def test_custom_model_jit_compiles_without_a_gpu():
     assert RD.errstate_dim(lie) == 6 and isinstance(RD.statevectortype(lie), RD.RotationState)
     with pytest.raises(ValueError):
         RD.dims(RD.CustomModel(8, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0))))     # LieState length 7 != n
+
+
+def test_header_is_plain_c_and_the_c_demo_links_and_runs():
+    """include/rdhip.h must be consumable by a C compiler (the boundary is a C ABI): compile examples/c_abi_demo.c as C99 with
+    -Wall -Wextra -Werror, link it against librdhip.so and run it (on a box without a GPU it exercises the model queries and exits 0)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_build", "c_abi_demo")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.dirname(RD.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-L", libdir, "-lrdhip", "-lm", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "n=13 m=6 p=13 errstate_dim=12" in out.stdout
