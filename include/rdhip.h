@@ -62,7 +62,9 @@ typedef enum {
 typedef enum { RDHIP_ROT_QUAT = 0, RDHIP_ROT_MRP = 1, RDHIP_ROT_RP = 2 } rdhip_rotation;   /* src/liestate.jl:42-46 */
 typedef enum { RDHIP_FRAME_WORLD = 0, RDHIP_FRAME_BODY = 1 } rdhip_velocity_frame;          /* src/rigidbody.jl:258 */
 /* QuadratureRule (src/integration.jl:69,109,258; RK2 = v0.3 explicit midpoint); RDHIP_CONTINUOUS = no discretisation */
-typedef enum { RDHIP_CONTINUOUS = -1, RDHIP_EULER = 0, RDHIP_RK2 = 1, RDHIP_RK3 = 2, RDHIP_RK4 = 3 } rdhip_rule;
+/* RDHIP_IMPLICIT_MIDPOINT (src/integration.jl:620-729): x1 + h f((x1+x2)/2, u1) - x2 = 0 solved by Newton's method (src/integration.jl:422-463);
+ * accepted by rdhip_discrete_dynamics, rdhip_jacobian (implicit function theorem, src/integration.jl:517-538), rdhip_dynamics_error[_jacobian] */
+typedef enum { RDHIP_CONTINUOUS = -1, RDHIP_EULER = 0, RDHIP_RK2 = 1, RDHIP_RK3 = 2, RDHIP_RK4 = 3, RDHIP_IMPLICIT_MIDPOINT = 4 } rdhip_rule;
 typedef enum { RDHIP_FORWARD_AD = 0, RDHIP_FINITE_DIFF = 1, RDHIP_USER_DEFINED = 2 } rdhip_diffmethod; /* src/functionbase.jl:109-120 */
 typedef enum { RDHIP_F64 = 0, RDHIP_F32 = 1 } rdhip_dtype;
 typedef enum { RDHIP_DEVICE = 0, RDHIP_HOST = 1 } rdhip_memspace;
@@ -108,6 +110,9 @@ int rdhip_model_destroy(rdhip_model* model);
  * (creation does not compile; the first use or rdhip_model_precompile does). */
 int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const char* preamble, const double* params, int nparams,
                               int rotation, const int* P, int nP, rdhip_model** out);
+/* setnewtoniters / setnewtontolerance of an ImplicitDynamicsModel (src/discretized_dynamics.jl:225-228); defaults 10 and 1e-12
+ * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol. */
+int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_tol);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian; custom models only */
 int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
@@ -139,7 +144,9 @@ int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, 
  * continuous model (rule = RDHIP_CONTINUOUS; generated methods src/jacobian_gen.jl:485-529, :643-685) or
  * DiscretizedDynamics{rule}(model) (src/discretized_dynamics.jl:169,208-219; chain rule src/integration.jl:85-93,
  * :149-177,:302-337).  v0.3 spellings: jacobian!(D, model, z) / discrete_jacobian!(rule, D, model, z).
- * J: n x (n+m) x N, fully overwritten.  Y: n x N or NULL; receives f(z) (what InPlace leaves in `y`). */
+ * J: n x (n+m) x N, fully overwritten.  Y: n x N or NULL; receives f(z) (what InPlace leaves in `y`).
+ * rule = RDHIP_IMPLICIT_MIDPOINT: diff = RDHIP_FORWARD_AD stands for ImplicitFunctionTheorem(ForwardAD()) (the only DiffMethod the reference
+ * accepts for implicit models, src/discretized_dynamics.jl:243-249): the next state is solved for, then J = -J2[:,1:n] \ J1. */
 int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                    const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);
 

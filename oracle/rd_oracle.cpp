@@ -692,6 +692,96 @@ int oracle_rollout(const OModel* M, int rule, int sig, int K, int ntraj, double*
     }
     return 0;
 }
+// ---- ImplicitMidpoint (src/integration.jl:620-729) with the Newton solve of src/integration.jl:422-463 --------------------
+//   e(x2; z1) = x1 + h f((x1 + x2)/2, u1, t + h/2) - x2 = 0      J2 = de/dz2 = [(h/2) A - I, 0]      J1 = de/dz1 = [I + (h/2) A, h B]
+// with [A B] the continuous Jacobian at (xmid, u1) (src/integration.jl:664-690).  Newton from x2 = x1 (StaticReturn flavour):
+// residual, Jacobians, convergence test, step -- so on exit J2/J1 belong to the last iterate that was TESTED; the discrete Jacobian
+// is the implicit-function-theorem solve  J = -J2[:, 1:n] \ J1  (src/integration.jl:517-538).  LU with partial pivoting as `lu`.
+static int lu_factor(double* A, int n, int* piv) {        // A column-major n x n, in place
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = std::fabs(A[k + k * n]);
+        for (int i = k + 1; i < n; ++i) if (std::fabs(A[i + k * n]) > best) { best = std::fabs(A[i + k * n]); p = i; }
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < n; ++j) std::swap(A[k + j * n], A[p + j * n]);
+        if (A[k + k * n] == 0.0) return -1;
+        for (int i = k + 1; i < n; ++i) {
+            A[i + k * n] /= A[k + k * n];
+            for (int j = k + 1; j < n; ++j) A[i + j * n] -= A[i + k * n] * A[k + j * n];
+        }
+    }
+    return 0;
+}
+static void lu_solve(const double* LU, const int* piv, int n, double* b) {
+    for (int k = 0; k < n; ++k) if (piv[k] != k) std::swap(b[k], b[piv[k]]);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) b[i] -= LU[i + j * n] * b[j];
+    for (int i = n - 1; i >= 0; --i) { for (int j = i + 1; j < n; ++j) b[i] -= LU[i + j * n] * b[j]; b[i] /= LU[i + i * n]; }
+}
+// residual and Jacobians of the implicit midpoint dynamics error for one pair; Jc: n x nz continuous Jacobian scratch
+static void implicit_midpoint_parts(const OModel& M, const double* x1, const double* u1, const double* x2, double t, double h,
+                                    double* e, double* J2, double* J1) {
+    const int n = M.n, nz = M.n + M.m;
+    double zm[MAXZ], Jc[MAXN * MAXZ], f[MAXN];
+    for (int i = 0; i < n; ++i) zm[i] = (x1[i] + x2[i]) / 2;
+    for (int i = 0; i < M.m; ++i) zm[n + i] = u1[i];
+    jac_table()[nz](M, -1, 0, zm, t + h / 2, h, Jc, f);
+    for (int i = 0; i < n; ++i) e[i] = x1[i] + h * f[i] - x2[i];
+    for (int j = 0; j < nz; ++j) for (int i = 0; i < n; ++i) {
+        const double a = Jc[i + j * n] * h;
+        if (j < n) { J1[i + j * n] = a / 2 + (i == j ? 1.0 : 0.0); J2[i + j * n] = a / 2 - (i == j ? 1.0 : 0.0); }
+        else { J1[i + j * n] = a; J2[i + j * n] = 0.0; }
+    }
+}
+// Xn: n x N ; J: n x nz x N or NULL ; iters_used: N or NULL
+int oracle_implicit_midpoint(const OModel* M, int N, const double* Z, const double* t, const double* dt, int newton_iters, double tol,
+                             double* Xn, double* J, int* iters_used) {
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    const int n = M->n, nz = M->n + M->m;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < N; ++k) {
+        const double* z = Z + (size_t)k * nz; const double h = dt[k];
+        double u[MAXM]; for (int i = 0; i < M->m; ++i) u[i] = (h == 0.0) ? 0.0 : z[n + i];       // terminal knot point: control reads as zeros
+        double xn[MAXN], e[MAXN], J2[MAXN * MAXZ], J1[MAXN * MAXZ], A[MAXN * MAXN]; int piv[MAXN];
+        for (int i = 0; i < n; ++i) xn[i] = z[i];
+        int it = 0;
+        for (; it < newton_iters; ++it) {
+            implicit_midpoint_parts(*M, z, u, xn, t[k], h, e, J2, J1);
+            double nr = 0; for (int i = 0; i < n; ++i) nr += e[i] * e[i];
+            if (std::sqrt(nr) < tol) break;
+            for (int i = 0; i < n * n; ++i) A[i] = J2[i];
+            lu_factor(A, n, piv); lu_solve(A, piv, n, e);
+            for (int i = 0; i < n; ++i) xn[i] -= e[i];
+        }
+        for (int i = 0; i < n; ++i) Xn[(size_t)k * n + i] = xn[i];
+        if (iters_used) iters_used[k] = it;
+        if (J) {
+            for (int i = 0; i < n * n; ++i) A[i] = J2[i];
+            lu_factor(A, n, piv);
+            for (int j = 0; j < nz; ++j) {
+                double col[MAXN]; for (int i = 0; i < n; ++i) col[i] = J1[i + j * n];
+                lu_solve(A, piv, n, col);
+                const bool zero = (j >= n && h == 0.0);
+                for (int i = 0; i < n; ++i) J[(size_t)k * n * nz + i + j * n] = zero ? 0.0 : -col[i];
+            }
+        }
+    }
+    return 0;
+}
+// dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for the N-1 consecutive pairs: E n x (N-1), J2, J1: n x nz x (N-1) (any may be NULL)
+int oracle_implicit_midpoint_error(const OModel* M, int N, const double* Z, const double* t, const double* dt, double* E, double* J2, double* J1) {
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    const int n = M->n, nz = M->n + M->m;
+    for (int k = 0; k + 1 < N; ++k) {
+        const double* z1 = Z + (size_t)k * nz; const double* z2 = Z + (size_t)(k + 1) * nz;
+        double u[MAXM]; for (int i = 0; i < M->m; ++i) u[i] = (dt[k] == 0.0) ? 0.0 : z1[n + i];
+        double e[MAXN], j2[MAXN * MAXZ], j1[MAXN * MAXZ];
+        implicit_midpoint_parts(*M, z1, u, z2, t[k], dt[k], e, j2, j1);
+        if (E) for (int i = 0; i < n; ++i) E[(size_t)k * n + i] = e[i];
+        if (J2) for (int i = 0; i < n * nz; ++i) J2[(size_t)k * n * nz + i] = j2[i];
+        if (J1) for (int i = 0; i < n * nz; ++i) J1[(size_t)k * n * nz + i] = j1[i];
+    }
+    return 0;
+}
+
 int oracle_num_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();

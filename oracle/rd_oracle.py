@@ -186,6 +186,28 @@ class Model:
         Bb = np.einsum("kia,kij->kaj", G2, B)
         return np.concatenate([Ab, Bb], axis=2), y
 
+    def implicit_midpoint(self, Z, t, dt, newton_iters=10, tol=1e-12, want_jacobian=True):
+        """DiscretizedDynamics{ImplicitMidpoint}: Newton solve for x_{k+1} (reference src/integration.jl:422-463) and the
+        implicit-function-theorem Jacobian -J2[:,1:n] \\ J1 (src/integration.jl:517-538).  Returns (Xn (N,n), J (N,n,n+m) or None, iterations (N,))."""
+        Z, t, dt, N = self._prep(Z, t, dt)
+        Xn = np.empty((N, self.n))
+        J = np.empty((N, self.n + self.m, self.n)) if want_jacobian else None
+        its = np.zeros(N, dtype=np.int32)
+        rc = lib().oracle_implicit_midpoint(self._buf, N, _dp(Z), _dp(t), _dp(dt), int(newton_iters), C.c_double(tol), _dp(Xn), _dp(J), _ip(its))
+        if rc:
+            raise RuntimeError(f"rc={rc}")
+        return Xn, (None if J is None else J.transpose(0, 2, 1)), its
+
+    def implicit_midpoint_error(self, Z, t, dt):
+        """dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for consecutive pairs (src/integration.jl:631-690): (e, J2, J1)."""
+        Z, t, dt, N = self._prep(Z, t, dt)
+        nz = self.n + self.m
+        E = np.empty((N - 1, self.n)); J2 = np.empty((N - 1, nz, self.n)); J1 = np.empty((N - 1, nz, self.n))
+        rc = lib().oracle_implicit_midpoint_error(self._buf, N, _dp(Z), _dp(t), _dp(dt), _dp(E), _dp(J2), _dp(J1))
+        if rc:
+            raise RuntimeError(f"rc={rc}")
+        return E, J2.transpose(0, 2, 1), J1.transpose(0, 2, 1)
+
     def errstate_jacobian(self, X, clear=True, G0=None):
         """G0: optional (N, n, e) initial content (the reference does not clear G)."""
         X = np.ascontiguousarray(X, dtype=np.float64)

@@ -163,6 +163,7 @@ int rdhip_model_create(int kind, int rot, int frame, const double* params, int n
     if (d.n <= 0 || d.m <= 0 || d.n > 16 || d.m > 8) { delete M; return fail(nullptr, RDHIP_ERR_INVALID_ARG, "unsupported dimensions n=%d m=%d", d.n, d.m); }
     // errstate_dim: 3 per rotation + vector parts (src/liestate.jl:124) ; Euclidean: n (src/statevectortype.jl:144)
     if (d.lie_nP) { int sp = 0; for (int i = 0; i < d.lie_nP; ++i) sp += d.lie_P[i]; d.e = 3 * (d.lie_nP - 1) + sp; } else d.e = d.n;
+    d.newton_iters = 10; d.newton_tol = 1e-12;
     build_lie(M);
     *out = M; return RDHIP_OK;
 }
@@ -189,8 +190,14 @@ int rdhip_model_create_custom(int n, int m, const char* body, const char* preamb
         d.e = 3 * (nP - 1) + sp;
     } else d.e = n;
     d.jit = jit_model_create(n, m, body, preamble, d.params, nparams);
+    d.newton_iters = 10; d.newton_tol = 1e-12;
     build_lie(M);
     *out = M; return RDHIP_OK;
+}
+int rdhip_model_set_newton(rdhip_model* M, int iters, double tol) {
+    if (!M) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "model is NULL");
+    if (iters < 1 || !(tol > 0)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "newton_iters must be >= 1 and newton_tol > 0");
+    M->d.newton_iters = iters; M->d.newton_tol = tol; return RDHIP_OK;
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
@@ -334,20 +341,34 @@ static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchA
     }
 }
 
+static int family_implicit(const ModelDesc& d, int mode, int dtype, LaunchArgs a) {
+    g_jit_model = nullptr;
+    a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
+    switch (d.kind) {
+        case RDHIP_MODEL_CARTPOLE: return fam_cartpole_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return fam_satellite_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_CUSTOM: return RDHIP_ERR_UNSUPPORTED;      // implicit rules are not JIT-compiled yet
+        default: return fam_lie_implicit(d, mode, dtype, a);
+    }
+}
+
 static int eval_common(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt,
                        void* Y, int memspace, const char* what) {
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (N > 0 && (!Z || !t || !dt || !Y)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
     LaunchArgs a{}; a.stream = c->stream; a.N = N;
-    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.Y = Y; return kernel_status(c, family_eval(d, rule, dtype, a), what); }
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.Y = Y; return kernel_status(c, implicit ? family_implicit(d, 0, dtype, a) : family_eval(d, rule, dtype, a), what); }
     Stage s(c);
     a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
     a.Y = s.out(Y, (size_t)N * d.n * ts);
     if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, family_eval(d, rule, dtype, a), what));
+    return s.finish(kernel_status(c, implicit ? family_implicit(d, 0, dtype, a) : family_eval(d, rule, dtype, a), what));
 }
 
 int rdhip_dynamics(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, const double* t, const double* dt, void* Xdot, int memspace) {
@@ -362,25 +383,31 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     if (N > 0 && (!Z || !t || !dt || !J)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
+    if (implicit && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take ImplicitFunctionTheorem(ForwardAD()) only", what);
     LaunchArgs a{}; a.stream = c->stream; a.N = N;
-    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.J = J; a.Y = Y; return kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what); }
     Stage s(c);
-    a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
-    a.J = s.out(J, (size_t)N * d.n * (d.n + d.m) * ts); a.Y = s.out(Y, (size_t)N * d.n * ts);
-    if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what));
+    a.Z = Z; a.t = t; a.dt = dt; a.J = J; a.Y = Y;
+    if (memspace == RDHIP_HOST) {
+        a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
+        a.J = s.out(J, (size_t)N * d.n * (d.n + d.m) * ts); a.Y = s.out(Y, (size_t)N * d.n * ts);
+        if (s.rc) return s.rc;
+    }
+    if (implicit && !a.Y && N > 0) { a.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }     // the Newton solution has to land somewhere
+    const int k = kernel_status(c, implicit ? family_implicit(d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
+    return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
 
 // dynamics_error / dynamics_error_jacobian!: the discrete dynamics (Jacobian) of the first N-1 knot points, minus the next state
 static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                          void* J2, void* J1, void* E, bool want_jac, int memspace, const char* what) {
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: an explicit quadrature rule is required (got %d)", what, rule);
+    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: a quadrature rule is required (got %d)", what, rule);
     if (want_jac && (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
@@ -396,6 +423,12 @@ static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     }
     LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = dZ; a.t = dtm; a.dt = ddt;
     int k = RDHIP_OK;
+    if (rule == RDHIP_IMPLICIT_MIDPOINT) {          // e = x1 + h f((x1+x2)/2, u1) - x2 ; J1 = [I + (h/2)A, hB] ; J2 = [(h/2)A - I, 0]  (src/integration.jl:631-690)
+        if (want_jac && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: ForwardAD only for implicit rules", what);
+        a.Y = dE; a.J = want_jac ? dJ1 : nullptr; a.J2 = want_jac ? dJ2 : nullptr;
+        k = kernel_status(c, family_implicit(d, 2, dtype, a), what);
+        return memspace == RDHIP_HOST ? s.finish(k) : k;
+    }
     if (want_jac && dJ1) { a.J = dJ1; a.Y = dE; k = family_jacobian(d, rule, diff, dtype, a); }       // f(z_k) lands in E
     else if (dE) { a.Y = dE; k = family_eval(d, rule, dtype, a); }
     if (k == RDHIP_OK && dE) k = launch_sub_next_state(dtype, c->stream, P, d.n, nz, dZ, dE);

@@ -35,6 +35,8 @@ struct ModelDesc {
     int lie_nP;        // 0 => EuclideanState
     int lie_P[8];
     void* jit;         // RDHIP_MODEL_CUSTOM: the hipRTC plug-in object (jit.hip)
+    int newton_iters;  // ImplicitNewtonCache defaults (src/integration.jl:599-600): 10 iterations, tolerance 1e-12
+    double newton_tol;
 };
 
 struct LaunchArgs {
@@ -47,13 +49,17 @@ struct LaunchArgs {
     void* J;
     void* Y;            // eval: output; jacobian: optional f(z)
     const void* X0;     // rollout
+    void* J2;           // implicit dynamics_error_jacobian: d e / d z2 (J holds d e / d z1)
+    int newton_iters;   // implicit rules
+    double newton_tol;
 };
 
 // per-family entry points (one translation unit each so they compile in parallel)
 #define RD_DECLARE_FAMILY(name)                                                                      \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                  \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);    \
-    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);       \
+    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs */
 RD_DECLARE_FAMILY(fam_cartpole)
 RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)

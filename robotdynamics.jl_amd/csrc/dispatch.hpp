@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include <cstdint>
 #include "kernels.hpp"
+#include "implicit.hpp"
 
 namespace rd {
 
@@ -158,6 +159,34 @@ template <class Mdl> int dispatch_jacobian_rule(const Mdl& m, int rule, int diff
         case RDHIP_RK3: return launch_jacobian<Mdl, RULE_RK3>(m, diff, a);
         case RDHIP_RK4: return launch_jacobian<Mdl, RULE_RK4>(m, diff, a);
     }
+    return RDHIP_ERR_INVALID_ARG;
+}
+
+// DiscretizedDynamics{ImplicitMidpoint}: mode 0 = Newton solve, 1 = Newton solve + implicit-function-theorem Jacobian, 2 = dynamics error of pairs
+template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArgs& a) {
+    using T = typename Mdl::T;
+    if (a.N == 0) return RDHIP_OK;
+    const unsigned grid = (unsigned)((a.N + TILE - 1) / TILE);
+    if (mode == 2) {
+        hipLaunchKernelGGL((implicit_midpoint_error_kernel<Mdl, T>), dim3(grid), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.dt, (T*)a.Y, (T*)a.J2, (T*)a.J);
+        return hip_status(hipGetLastError());
+    }
+    constexpr size_t lds = ImplicitLds<Mdl, T>::BYTES;
+    static_assert(lds <= 160 * 1024, "Newton matrices do not fit the LDS of a CU");
+    if (mode == 1) {
+        auto kern = implicit_midpoint_kernel<Mdl, T, true>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol);
+    } else {
+        auto kern = implicit_midpoint_kernel<Mdl, T, false>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol);
+    }
+    return hip_status(hipGetLastError());
+}
+template <template <class> class MT> int dispatch_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) {
+    if (dtype == RDHIP_F64) return launch_implicit(MT<double>::make(md.params), mode, a);
+    if (dtype == RDHIP_F32) return launch_implicit(MT<float>::make(md.params), mode, a);
     return RDHIP_ERR_INVALID_ARG;
 }
 

@@ -11,4 +11,7 @@ int fam_lie_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const L
 int fam_lie_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
     return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_rollout<SatellitePair>(md, rule, dtype, a) : dispatch_rollout<LieSatellite>(md, rule, dtype, a);
 }
+int fam_lie_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) {
+    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_implicit<SatellitePair>(md, mode, dtype, a) : dispatch_implicit<LieSatellite>(md, mode, dtype, a);
+}
 }  // namespace rd

@@ -22,6 +22,7 @@ template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENC
 
 #define RD_RIGID_VARIANT_DECL(name)                                                                       \
     int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                     \
+    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);                   \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                       \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);         \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
@@ -30,7 +31,8 @@ template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENC
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_eval<name##_M>(md, rule, dtype, a); } \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_jacobian<name##_M>(md, rule, diff, dtype, a); } \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); } \
-    int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_errexp<name##_M>(md, rule, dtype, a); }
+    int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_errexp<name##_M>(md, rule, dtype, a); } \
+    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) { return dispatch_implicit<name##_M>(md, mode, dtype, a); }
 RD_RIGID_VARIANT_DECL(sat_wd) RD_RIGID_VARIANT_DECL(sat_wf) RD_RIGID_VARIANT_DECL(sat_bd) RD_RIGID_VARIANT_DECL(sat_bf)
 RD_RIGID_VARIANT_DECL(quad_wd) RD_RIGID_VARIANT_DECL(quad_wf) RD_RIGID_VARIANT_DECL(quad_bd) RD_RIGID_VARIANT_DECL(quad_bf)
 inline bool diag_inertia(const ModelDesc& md) { return host_is_diag3(md.params + 1); }

@@ -30,4 +30,9 @@ int fam_simple_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArg
     RD_SIMPLE_SWITCH(CALL)
 #undef CALL
 }
+int fam_simple_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) {
+#define CALL(M) dispatch_implicit<M>(md, mode, dtype, a)
+    RD_SIMPLE_SWITCH(CALL)
+#undef CALL
+}
 }  // namespace rd

@@ -1,0 +1,200 @@
+// implicit.hpp -- DiscretizedDynamics{ImplicitMidpoint}: batched Newton solve and implicit-function-theorem Jacobian.
+//   reference: src/integration.jl:620-729 (the scheme, its dynamics_error and Jacobians), :422-463 (Newton solve, StaticReturn flavour),
+//              :517-538 (jacobian! by the implicit function theorem), :585-605 (defaults: 10 iterations, tolerance 1e-12)
+//   e(x2; z1) = x1 + h f((x1 + x2)/2, u1) - x2        J2 = [(h/2) A - I, 0]        J1 = [I + (h/2) A, h B]        x_next: e = 0
+//   discrete Jacobian = -J2[:, 1:n] \ J1,  [A B] = continuous Jacobian at (xmid, u1)
+// One lane owns one knot point; its n x n Newton matrix lives in LDS (lane-private, odd stride -> conflict-free), because n*n
+// doubles do not fit a lane's registers.  LU with partial pivoting like `lu`; right-hand sides stay in registers (compile-time
+// indices, row swaps by select).  Continuous Jacobian columns are matrix-free forward-dual JVPs of the model.  This kernel is
+// compute- and LDS-latency-bound (one wave per CU for n = 13 in fp64), not a streaming kernel.
+#pragma once
+#include "kernels.hpp"
+
+namespace rd {
+
+template <class Mdl, class T> struct ImplicitLds {
+    static constexpr int NX = Mdl::NX;
+    static constexpr int RSA = (NX * NX + NX) | 1;                  // per-lane stride (elements): the matrix + one right-hand side
+    static constexpr size_t BYTES = (size_t)TILE * RSA * sizeof(T) + (size_t)TILE * 16 * sizeof(int);   // + pivots
+};
+
+template <class Mdl, class T> struct ImplicitOps {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    using D = Dual<T, 1>;
+    // f(xm, u) and one column of the continuous Jacobian (direction e_c of z = [x; u])
+    template <int C> static RD_DEV void jcol(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T (&col)[NX], T (&f)[NX]) {
+        D xd[NX], ud[NU], fd[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xd[i].v = xm[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
+        m.f(xd, ud, fd);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { col[i] = fd[i].d[0]; f[i] = fd[i].v; }
+    }
+    // A2 = (h/2) A - I into the lane's LDS matrix (column-major), residual e = x1 + h f - x2
+    template <int C> static RD_DEV void fill_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T* A, T (&f)[NX]) {
+        if constexpr (C < NX) {
+            T col[NX];
+            jcol<C>(m, xm, u, col, f);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) A[i + C * NX] = col[i] * (h * T(0.5)) - ((i == C) ? T(1) : T(0));
+            fill_cols<C + 1>(m, xm, u, h, A, f);
+        }
+    }
+    // in-place LU with partial pivoting of the lane's matrix; pivots into piv[0..NX)
+    static RD_DEV void lu(T* A, int* piv) {
+        for (int i = 0; i < NX; ++i) piv[i] = i;
+#pragma unroll 1
+        for (int k = 0; k < NX; ++k) {
+            int p = k; T best = A[k + k * NX]; best = best < T(0) ? -best : best;
+            for (int i = k + 1; i < NX; ++i) { T v = A[i + k * NX]; v = v < T(0) ? -v : v; if (v > best) { best = v; p = i; } }
+            { const int tmp = piv[k]; piv[k] = piv[p]; piv[p] = tmp; }   // piv[] holds the row permutation: row i of P*A is row piv[i] of A
+            if (p != k) for (int j = 0; j < NX; ++j) { const T a = A[k + j * NX], b = A[p + j * NX]; A[k + j * NX] = b; A[p + j * NX] = a; }
+            const T inv = T(1) / A[k + k * NX];
+            for (int i = k + 1; i < NX; ++i) {
+                const T l = A[i + k * NX] * inv;
+                A[i + k * NX] = l;
+                for (int j = k + 1; j < NX; ++j) A[i + j * NX] -= l * A[k + j * NX];
+            }
+        }
+    }
+    // b <- A^{-1} b with the factors above; b in registers (compile-time indices).  The row permutation is applied through the
+    // lane's LDS staging vector: a select chain on registers is turned into a dynamically indexed private array (scratch memory).
+    static RD_DEV void solve(T* A, const int* piv, T (&b)[NX]) {
+        T* sb = A + NX * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sb[i] = b[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) b[i] = sb[piv[i]];
+#pragma unroll
+        for (int i = 1; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < i; ++j) b[i] -= A[i + j * NX] * b[j];
+        }
+#pragma unroll
+        for (int i = NX - 1; i >= 0; --i) {
+#pragma unroll
+            for (int j = i + 1; j < NX; ++j) b[i] -= A[i + j * NX] * b[j];
+            b[i] = b[i] / A[i + i * NX];
+        }
+    }
+    // IFT columns: J[:, C] = -A2^{-1} J1[:, C],  J1 = [I + (h/2) A, h B]
+    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, T* A, const int* piv, T* Jk, bool store) {
+        if constexpr (C < NX + NU) {
+            T col[NX], f[NX];
+            jcol<C>(m, xm, u, col, f);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
+            solve(A, piv, col);
+            const T sc = (C >= NX && term) ? T(0) : T(-1);           // control columns of a terminal knot point are zero
+            if (store) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Jk[C * NX + i] = col[i] * sc;
+            }
+            ift_cols<C + 1>(m, xm, u, h, term, A, piv, Jk, store);
+        }
+    }
+};
+
+template <class Mdl, class T, bool WANT_J>
+__global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    using L = ImplicitLds<Mdl, T>;
+    using Ops = ImplicitOps<Mdl, T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
+    int* piv = reinterpret_cast<int*>(smem + (size_t)TILE * L::RSA * sizeof(T)) + lane * 16;
+    const long long k = (long long)blockIdx.x * TILE + lane;
+    const bool active = k < N;
+    const long long kc = active ? k : N - 1;
+    const double hd = dtt[kc];
+    const T h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    T x1[NX], u[NU], xn[NX], xl[NX], xm[NX], f[NX], r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x1[i] = Z[kc * NZ + i]; xn[i] = x1[i]; xl[i] = x1[i]; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[kc * NZ + NX + i];
+    bool done = false;
+    for (int it = 0; it < newton_iters; ++it) {
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xl[i] = xn[i]; xm[i] = (x1[i] + xn[i]) * T(0.5); }
+        }
+        // residual and Newton matrix at the last tested iterate xl (recomputed, unchanged, for lanes that are already done)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
+        Ops::template fill_cols<0>(m, xm, u, h, A, f);
+        T nr = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
+        if ((double)sqrt_(nr) < tol) done = true;
+        if (__all(done)) break;
+        Ops::lu(A, piv);
+        Ops::solve(A, piv, r);
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xn[i] = xl[i] - r[i];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xn[k * NX + i] = xn[i];
+    }
+    if constexpr (WANT_J) {
+        // Jacobians at the last TESTED iterate (what the reference's cache holds when the loop exits)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
+        Ops::template fill_cols<0>(m, xm, u, h, A, f);
+        Ops::lu(A, piv);
+        Ops::template ift_cols<0>(m, xm, u, h, term, A, piv, J + kc * NX * NZ, active);
+    }
+}
+
+template <class Mdl, class T, int C>
+RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&u)[Mdl::NU], const T (&x1)[Mdl::NX], const T (&x2)[Mdl::NX], T h, T* e, T* j2, T* j1) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    if constexpr (C < NX + NU) {
+        T col[NX], f[NX];
+        ImplicitOps<Mdl, T>::template jcol<C>(m, xm, u, col, f);
+        if (C == 0 && e) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) e[i] = x1[i] + h * f[i] - x2[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const T a = col[i] * h;
+            if (C < NX) { if (j1) j1[C * NX + i] = a * T(0.5) + ((i == C) ? T(1) : T(0)); if (j2) j2[C * NX + i] = a * T(0.5) - ((i == C) ? T(1) : T(0)); }
+            else { if (j1) j1[C * NX + i] = a; if (j2) j2[C * NX + i] = T(0); }
+        }
+        implicit_error_cols<Mdl, T, C + 1>(m, xm, u, x1, x2, h, e, j2, j1);
+    }
+}
+
+// dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for the pairs (Z[k], Z[k+1]) (src/integration.jl:631-690)
+template <class Mdl, class T>
+__global__ void __launch_bounds__(TILE) implicit_midpoint_error_kernel(Mdl m, long long P, const T* __restrict__ Z, const double* __restrict__ dtt,
+                                                                       T* __restrict__ E, T* __restrict__ J2, T* __restrict__ J1) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    const long long k = (long long)blockIdx.x * TILE + threadIdx.x;
+    if (k >= P) return;
+    const double hd = dtt[k];
+    const T h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    T x1[NX], x2[NX], u[NU], xm[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x1[i] = Z[k * NZ + i]; x2[i] = Z[(k + 1) * NZ + i]; xm[i] = (x1[i] + x2[i]) * T(0.5); }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[k * NZ + NX + i];
+    if (E && !J1 && !J2) {
+        T f[NX]; m.f(xm, u, f);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) E[k * NX + i] = x1[i] + h * f[i] - x2[i];
+        return;
+    }
+    implicit_error_cols<Mdl, T, 0>(m, xm, u, x1, x2, h, E ? E + k * NX : nullptr, J2 ? J2 + k * NX * NZ : nullptr, J1 ? J1 + k * NX * NZ : nullptr);
+}
+}  // namespace rd

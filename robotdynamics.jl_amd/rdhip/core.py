@@ -71,7 +71,8 @@ class UserDefined(DiffMethod):
 
 
 class ImplicitFunctionTheorem(DiffMethod):
-    """Exists for API completeness; implicit integrators are outside the accelerated path."""
+    """ImplicitFunctionTheorem(diff): the DiffMethod of implicit models (src/functionbase.jl:109-120, src/discretized_dynamics.jl:230-251):
+    solve for the next state, then J = -J2[:,1:n] \\ J1 with the continuous Jacobians from `diff` (ForwardAD is built)."""
 
     def __init__(self, diff):
         if isinstance(diff, ImplicitFunctionTheorem):   # src/functionbase.jl:113-116
@@ -134,10 +135,18 @@ class RK4(Explicit):
     code = L.RK4
 
 
+class Implicit(QuadratureRule):
+    pass
+
+
+class ImplicitMidpoint(Implicit):   # src/integration.jl:620-629: x1 + h f((x1+x2)/2, u1, t + h/2) - x2 = 0, Newton solve
+    code = L.IMPLICIT_MIDPOINT
+
+
 def _rule_code(Q):
     if isinstance(Q, type) and issubclass(Q, QuadratureRule) or isinstance(Q, QuadratureRule):
         if Q.code is None:
-            raise NotImplementedError(f"{Q} has no batched kernel (implicit integrators are out of scope)")
+            raise NotImplementedError(f"{Q} has no batched kernel")
         return Q.code
     raise ValueError(f"not a QuadratureRule: {Q!r}")
 
@@ -756,8 +765,24 @@ def input_dim(fun):
     return state_dim(fun) + control_dim(fun)
 
 
-def default_diffmethod(fun):                   # src/functionbase.jl:121 ; src/discretized_dynamics.jl:190
-    return ForwardAD() if isinstance(fun, DiscretizedDynamics) else UserDefined()
+def default_diffmethod(fun):                   # src/functionbase.jl:121 ; src/discretized_dynamics.jl:190,250-251
+    if isinstance(fun, DiscretizedDynamics):
+        if isinstance(fun.integrator, Implicit):
+            return ImplicitFunctionTheorem(default_diffmethod(fun.continuous_dynamics) if False else ForwardAD())
+        return ForwardAD()
+    return UserDefined()
+
+
+def setnewtoniters(model, iters):              # src/discretized_dynamics.jl:227-228
+    cm = _cm(model)
+    cm._newton = (int(iters), getattr(cm, "_newton", (10, 1e-12))[1])
+    L.check(L.lib().rdhip_model_set_newton(cm._handle, cm._newton[0], cm._newton[1]))
+
+
+def setnewtontolerance(model, tol):            # src/discretized_dynamics.jl:225-226
+    cm = _cm(model)
+    cm._newton = (getattr(cm, "_newton", (10, 1e-12))[0], float(tol))
+    L.check(L.lib().rdhip_model_set_newton(cm._handle, cm._newton[0], cm._newton[1]))
 
 
 def default_signature(fun):
@@ -1062,9 +1087,16 @@ def jacobian_(*args):
         raise TypeError("jacobian_(sig, diff, fun, J, y, z)  or  jacobian_(J, model, z)")
     if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
         raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
-    if isinstance(diff, ImplicitFunctionTheorem):
-        raise ValueError("ImplicitFunctionTheorem needs an implicit integrator (not part of the batched path)")
     model, rule = _model_rule(fun)
+    if rule == L.IMPLICIT_MIDPOINT:
+        # src/discretized_dynamics.jl:243-249: "Must call jacobian! on an ImplicitDynamicsModel with the ImplicitFunctionTheorem diff method"
+        if not isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError(f"Must call jacobian! on an implicit model with the ImplicitFunctionTheorem diff method. Got {type(diff).__name__}.")
+        if not isinstance(diff.diff, ForwardAD):
+            raise NotImplementedError("ImplicitFunctionTheorem is built over ForwardAD continuous Jacobians only")
+        diff = diff.diff
+    elif isinstance(diff, ImplicitFunctionTheorem):
+        raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
     Z, single = _as_traj(fun, z)
     n, m = _check_traj(fun, Z)
     N = len(Z)
@@ -1172,6 +1204,8 @@ def dynamics_error_jacobian_(sig, diff, fun, J2, J1, y2, y1, *args):
     model, rule = _model_rule(fun)
     if rule == L.CONTINUOUS:
         raise TypeError("dynamics_error_jacobian! needs a DiscreteDynamics model")
+    if isinstance(diff, ImplicitFunctionTheorem):      # the implicit model's diff method wraps the one used for the continuous Jacobians
+        diff = diff.diff
     if len(args) == 2:
         Z = _pair_traj(fun, *args)
         n, m = _check_traj(fun, Z)

@@ -496,6 +496,57 @@ def test_golden_error_expansion_and_dynamics_error(name, where):
         np.testing.assert_allclose(host(E), g["E_" + rn], rtol=0, atol=TOL * max(1.0, np.abs(g["E_" + rn]).max()))
 
 
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_implicit_midpoint_newton_solve_and_ift_jacobian(where):
+    """DiscretizedDynamics{ImplicitMidpoint} (src/integration.jl:620-729; Newton :422-463; IFT Jacobian :517-538; test/implicit_dynamics_test.jl):
+    next state, IFT Jacobian, dynamics error and its Jacobians against the oracle; the solution satisfies the implicit equation, and
+    the dynamics error of (z1, [x_next; u]) vanishes (test/implicit_dynamics_test.jl:46-60)."""
+    rng = np.random.default_rng(41)
+    cases = [(RD.Cartpole(), O.cartpole(), lambda n: rng.random((n, 5))), (RD.Satellite(), O.satellite(), lambda n: H.rand_rigid(rng, n, 6)),
+             (RD.Quadrotor(), O.quadrotor(), lambda n: H.rand_rigid(rng, n, 4, 0.6, 1.9)), (RD.DoubleIntegrator(2), O.double_integrator(2), lambda n: rng.random((n, 6))),
+             (RD.SatellitePair(), O.satellite_pair(), lambda n: rng.random((n, 20)) + 0.1)]
+    for model, om, gen in cases:
+        for N in (1, 70):
+            Zn = gen(N)
+            n, m = RD.state_dim(model), RD.control_dim(model)
+            t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+            if N > 2:
+                dt[-1] = 0.0
+            dm = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+            assert isinstance(RD.default_diffmethod(dm), RD.ImplicitFunctionTheorem)
+            Z = traj(model, Zn, t, dt, "cuda" if where == "cuda" else None)
+            Xo, Jo, its = om.implicit_midpoint(Zn, t, dt)
+            assert its.max() <= 6
+            Xn = RD.discrete_dynamics(dm, Z)
+            np.testing.assert_allclose(host(Xn), Xo, rtol=0, atol=TOL)
+            J = RD.alloc_jacobians(dm, N, Z.data)
+            Y = RD.evaluate(dm, Z) * 0
+            RD.jacobian_(RD.StaticReturn(), RD.default_diffmethod(dm), dm, J, Y, Z)
+            np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL * max(1.0, np.abs(Jo).max()))
+            np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
+            with pytest.raises(ValueError):                    # ArgumentError in the reference (src/discretized_dynamics.jl:243-249)
+                RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+            # the solution satisfies x1 + h f((x1 + x2)/2, u) - x2 = 0
+            xm = np.concatenate([(Zn[:, :n] + host(Xn)) / 2, np.where(dt[:, None] == 0, 0.0, Zn[:, n:])], axis=1)
+            res = Zn[:, :n] + dt[:, None] * om.dynamics(xm, t, np.full(N, 0.1)) - host(Xn)
+            assert np.abs(res).max() < 1e-11
+            if N > 1:
+                Eo, J2o, J1o = om.implicit_midpoint_error(Zn, t, dt)
+                np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), Eo, rtol=0, atol=TOL)
+                J2, J1 = RD.alloc_jacobians(dm, N - 1, Z.data), RD.alloc_jacobians(dm, N - 1, Z.data)
+                y2 = RD.evaluate(dm, Z)[: N - 1] * 0
+                RD.dynamics_error_jacobian_(RD.StaticReturn(), RD.default_diffmethod(dm), dm, J2, J1, y2, None, Z)
+                np.testing.assert_allclose(host(J2), J2o, rtol=0, atol=TOL * max(1.0, np.abs(J2o).max()))
+                np.testing.assert_allclose(host(J1), J1o, rtol=0, atol=TOL * max(1.0, np.abs(J1o).max()))
+                np.testing.assert_allclose(host(y2), Eo, rtol=0, atol=TOL)
+    # fewer Newton iterations than needed: the iterate after 1 step, as the oracle with newton_iters = 1
+    model, om = RD.Cartpole(), O.cartpole()
+    RD.setnewtoniters(model, 1)
+    Zn = rng.random((9, 5)); t, dt = np.zeros(9), np.full(9, 0.1)
+    dm = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    np.testing.assert_allclose(host(RD.discrete_dynamics(dm, traj(model, Zn, t, dt, "cuda" if where == "cuda" else None))), om.implicit_midpoint(Zn, t, dt, newton_iters=1)[0], rtol=0, atol=TOL)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21

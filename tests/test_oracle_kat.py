@@ -213,3 +213,35 @@ def test_rollout_matches_repeated_steps():
         np.testing.assert_allclose(R[:, k, :4], x, atol=1e-14)
     np.testing.assert_array_equal(R[:, :, 4:], Z[:, :, 4:])
     np.testing.assert_allclose(M.rollout(O.RK4, Z, t, dt, sig=O.INPLACE), R, atol=1e-12)
+
+
+def test_implicit_midpoint_linear_closed_form_and_properties():
+    """ImplicitMidpoint (src/integration.jl:620-729).  Known answers independent of any implementation:
+    * linear system xdot = A x + B u:  x2 = (I - hA/2)^-1 ((I + hA/2) x1 + h B u),  d x2/d x1 = (I - hA/2)^-1 (I + hA/2),  d x2/d u = h (I - hA/2)^-1 B,
+      Newton converges in one step;
+    * any model: the solution satisfies x1 + h f((x1+x2)/2, u) - x2 = 0 (test/implicit_dynamics_test.jl:46-60) and the IFT Jacobian agrees with
+      central differences of the solve."""
+    rng = np.random.default_rng(17)
+    A, B = rng.standard_normal((4, 4)), rng.standard_normal((4, 2))
+    m = O.linear(A, B)
+    Z = rng.random((6, 6)); h = 0.1
+    Xn, J, its = m.implicit_midpoint(Z, 0.0, h)
+    I = np.eye(4)
+    Minv = np.linalg.inv(I - h * A / 2)
+    np.testing.assert_allclose(Xn, (Minv @ ((I + h * A / 2) @ Z[:, :4].T + h * B @ Z[:, 4:].T)).T, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(J[:, :, :4], np.broadcast_to(Minv @ (I + h * A / 2), (6, 4, 4)), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(J[:, :, 4:], np.broadcast_to(h * Minv @ B, (6, 4, 2)), rtol=0, atol=1e-13)
+    assert its.max() <= 1
+    for om, Zn in ((O.cartpole(), rng.random((5, 5))), (O.satellite(), H.rand_rigid(rng, 5, 6))):
+        n = om.n
+        Xn, J, its = om.implicit_midpoint(Zn, 0.0, h)
+        xm = np.concatenate([(Zn[:, :n] + Xn) / 2, Zn[:, n:]], axis=1)
+        assert np.abs(Zn[:, :n] + h * om.dynamics(xm, 0.0, h) - Xn).max() < 1e-13
+        eps = 1e-6
+        for j in range(Zn.shape[1]):
+            Zp, Zm = Zn.copy(), Zn.copy(); Zp[:, j] += eps; Zm[:, j] -= eps
+            fd = (om.implicit_midpoint(Zp, 0.0, h)[0] - om.implicit_midpoint(Zm, 0.0, h)[0]) / (2 * eps)
+            np.testing.assert_allclose(J[:, :, j], fd, rtol=0, atol=2e-8)
+        E, J2, J1 = om.implicit_midpoint_error(np.concatenate([Zn[:1], np.concatenate([Xn[:1], Zn[:1, n:]], axis=1)]), 0.0, h)
+        assert np.abs(E).max() < 1e-13                       # dynamics_error(z2 = [x_next; u], z1) = 0
+        np.testing.assert_allclose(-np.linalg.solve(J2[0][:, :n], J1[0]), J[0], rtol=0, atol=1e-12)    # J = -J2[:,1:n] \\ J1

@@ -170,6 +170,21 @@ def main():
     rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("C5 cartpole RK4 rollout fp32 512 traj x 256 knots", cart, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+    # ImplicitMidpoint: Newton solve and IFT Jacobian (compute / LDS-latency bound)
+    dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
+    Zi = RD.PackedTrajectory(13, 6, Zs, np.arange(65536) * 0.1, np.full(65536, 0.1)).to(DEV)
+    Xi = torch.empty((65536, 13), dtype=torch.float64, device=DEV)
+    us = timed(lambda i: RD.evaluate_(dmi, Xi, Zi), 10, warm=2)
+    emit("satellite ImplicitMidpoint discrete_dynamics (Newton)", 65536, "f64", us, 65536 * (19 * 8 + 16 + 13 * 8))
+    Ji = RD.alloc_jacobians(dmi, 65536, Zi.data)
+    ift = RD.ImplicitFunctionTheorem(RD.ForwardAD())
+    us = timed(lambda i: RD.jacobian_(RD.StaticReturn(), ift, dmi, Ji, Xi, Zi), 10, warm=2)
+    emit("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", 65536, "f64", us, 65536 * 2248)
+    dci = RD.DiscretizedDynamics(cart, RD.ImplicitMidpoint)
+    Zc = RD.PackedTrajectory(4, 1, rng.random((1 << 20, 5)), np.zeros(1 << 20), np.full(1 << 20, 0.1)).to(DEV)
+    Jc = RD.alloc_jacobians(dci, 1 << 20, Zc.data); Xc = torch.empty((1 << 20, 4), dtype=torch.float64, device=DEV)
+    us = timed(lambda i: RD.jacobian_(RD.StaticReturn(), ift, dci, Jc, Xc, Zc), 10, warm=2)
+    emit("cartpole ImplicitMidpoint jacobian (Newton + IFT), 1M knots", 1 << 20, "f64", us, (1 << 20) * 248)
     Zb = rigid_inputs(1 << 20, 6, rng)
     eval_case("large-N satellite RK4 discrete_dynamics", sat, Zb, RD.RK4, f64, 20)
     eval_case("large-N satellite continuous dynamics", sat, Zb, None, f64, 20)
