@@ -98,19 +98,17 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Jacobians.  One WORKGROUP (NG waves) owns a tile of 64 knot points at a time and walks tiles persistently;
-// one LANE owns one knot point; the NZ = n+m Jacobian columns are split into NCHUNK contiguous column chunks that
-// are processed one after the other, and inside a chunk every wave owns a compile-time list of columns (Plan).
+// Jacobians -- the generic tile loop (jac_tile_loop: FiniteDifference, run-time-column ForwardAD / chain rule for models without
+// a column plan).  One WORKGROUP (NG waves) owns a tile of 64 knot points at a time and walks tiles persistently; one LANE owns one
+// knot point; the NZ = n+m Jacobian columns are split over the waves (Plan), optionally in NCHUNK column chunks processed in turn.
 //
 // LDS per workgroup:  out[64][RS]  one row per knot point holding the chunk's columns (and, in one chunk, f(z)),
 //                                  RS odd so that the lane stride hits distinct banks;
 //                     z tile 64 x NZ, t[64], dt[64].
-// After a chunk is computed the whole workgroup copies it out: thread u handles element u of the chunk, so one store
-// instruction writes 64 consecutive elements of rows that are (ncol*NY*sizeof(T))-byte contiguous runs of global
-// memory.  Measured on MI355X (profiles/): storing single columns from single waves (104-B runs) ran 2x
-// slower than a streaming fill; whole-workgroup chunk copies run within 15 % of it.  With NCHUNK = 2 the LDS
-// footprint (77 KB for the 13x19 fp64 case) lets two workgroups share a CU, so one computes while the other's
-// stores drain.  The next tile's z/t/dt are prefetched into registers before the last copy-out.
+// After a chunk is computed the whole workgroup copies it out row by row (row_copy): a row is a (ncol*NY*sizeof(T))-byte
+// contiguous run of global memory.  Measured on MI355X: storing single columns from single waves (104-B runs)
+// ran 2x slower than a streaming fill.  The next tile's z/t/dt are prefetched into registers before the last copy-out.
+// The flagship path (ForwardAD / chain rule with compile-time columns) uses the split-role loop further down instead.
 // No inter-workgroup data reuse exists, so no XCD-aware remap is needed: each tile is touched by exactly one workgroup.
 // ------------------------------------------------------------------------------------------------------------
 

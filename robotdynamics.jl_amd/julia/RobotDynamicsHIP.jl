@@ -138,7 +138,7 @@ rulecode(::RD.ImplicitMidpoint) = 4          # RDHIP_IMPLICIT_MIDPOINT
 diffcode(::RD.ForwardAD) = FORWARD_AD
 diffcode(::RD.FiniteDifference) = FINITE_DIFF
 diffcode(::RD.UserDefined) = USER_DEFINED
-diffcode(d::RD.ImplicitFunctionTheorem) = diffcode(d.diff)     # the C ABI takes the inner method for implicit rules
+diffcode(::RD.ImplicitFunctionTheorem{D}) where {D} = diffcode(D())     # the C ABI takes the inner method for implicit rules
 dtypecode(::Type{Float64}) = F64
 dtypecode(::Type{Float32}) = F32
 
