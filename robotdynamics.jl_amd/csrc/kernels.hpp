@@ -482,7 +482,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
     }
 }
 template <class Fn, class T, class Plan, int NC>
-__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
