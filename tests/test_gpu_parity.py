@@ -213,6 +213,32 @@ def test_prepared_jacobian_matches_the_checked_call():
         RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dm, J2[:, :, :5], Y2, Z)
 
 
+def test_degenerate_batch_sizes_of_the_pair_operators():
+    """N = 0, 1 (no consecutive pair): dynamics_error, dynamics_error_jacobian!, error expansion are no-ops with empty outputs;
+    N = 2 is the smallest real case."""
+    model, om = RD.Satellite(), O.satellite()
+    rng = np.random.default_rng(23)
+    for Q in (RD.RK4, RD.ImplicitMidpoint):
+        dm = RD.DiscretizedDynamics(model, Q)
+        for N in (0, 1, 2):
+            Zn = H.rand_rigid(rng, N, 6) if N else np.zeros((0, 19))
+            Z = traj(model, Zn, np.zeros(N), np.full(N, 0.1), "cuda")
+            E = RD.dynamics_error(dm, Z)
+            assert tuple(E.shape) == (max(N - 1, 0), 13)
+            J2, J1 = RD.alloc_jacobians(dm, max(N - 1, 0), Z.data), RD.alloc_jacobians(dm, max(N - 1, 0), Z.data)
+            RD.dynamics_error_jacobian_(RD.StaticReturn(), RD.default_diffmethod(dm), dm, J2, J1, None, None, Z)
+            if Q is RD.RK4:
+                Eb = RD.alloc_error_expansions(dm, N, Z.data)
+                RD.error_expansion_(dm, Eb, None, Z)
+                if N == 2:
+                    np.testing.assert_allclose(host(Eb), om.error_expansion(O.RK4, Zn, np.zeros(N), np.full(N, 0.1))[0], rtol=0, atol=TOL)
+            if N == 2 and Q is RD.RK4:
+                np.testing.assert_allclose(host(E), om.dynamics_error(O.RK4, Zn, np.zeros(N), np.full(N, 0.1)), rtol=0, atol=TOL)
+    with pytest.raises(ValueError):
+        RD.error_expansion_(RD.DiscretizedDynamics(model, RD.ImplicitMidpoint), RD.alloc_error_expansions(model, 3, None), None,
+                            traj(model, H.rand_rigid(rng, 3, 6), np.zeros(3), np.full(3, 0.1), None))
+
+
 def test_empty_batch_is_a_noop():
     model = RD.Satellite()
     dm = RD.DiscretizedDynamics(model, RD.RK4)
