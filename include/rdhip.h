@@ -114,7 +114,8 @@ int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const cha
  * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol. */
 int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_tol);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
- * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian; custom models only */
+ * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
+ * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT); custom models only */
 int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
 /* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
 int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);
@@ -198,7 +199,8 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
 /* rollout!(sig, DiscretizedDynamics{rule}(model), Z, x0) for M independent trajectories of K knot points:
  * src/trajectories.jl:436-441, src/discrete_dynamics.jl:217-235.  Z: (n+m) x K x M (trajectory j at
  * Z + j*K*(n+m)), states of knots 2..K are overwritten in place, controls are read; t, dt: K x M.
- * X0: n x M initial states or NULL (keep state(Z[1])).  Sequential in k, parallel over trajectories. */
+ * X0: n x M initial states or NULL (keep state(Z[1])).  Sequential in k, parallel over trajectories.  rule may be
+ * RDHIP_IMPLICIT_MIDPOINT (a Newton solve per step). */
 int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M,
                   void* Z, const double* t, const double* dt, const void* X0, int memspace);
 

@@ -201,7 +201,7 @@ int rdhip_model_set_newton(rdhip_model* M, int iters, double tol) {
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 6 || rule < RDHIP_CONTINUOUS || rule > RDHIP_RK4 || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || op > 10 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
@@ -349,7 +349,7 @@ static int family_implicit(const ModelDesc& d, int mode, int dtype, LaunchArgs a
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_implicit(d, mode, dtype, a);
         case RDHIP_MODEL_SATELLITE: return fam_satellite_implicit(d, mode, dtype, a);
         case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_implicit(d, mode, dtype, a);
-        case RDHIP_MODEL_CUSTOM: return RDHIP_ERR_UNSUPPORTED;      // implicit rules are not JIT-compiled yet
+        case RDHIP_MODEL_CUSTOM: { const int rc = jit_implicit(d.jit, mode, dtype, a); if (rc) g_jit_model = &d; return rc; }
         default: return fam_lie_implicit(d, mode, dtype, a);
     }
 }
@@ -533,18 +533,19 @@ int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long 
     const char* what = "rdhip_rollout";
     int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
     if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
-    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (K * Mt > 0 && (!Z || !t || !dt)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K;
-    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, family_rollout(d, rule, dtype, a), what); }
+    const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, implicit ? family_implicit(d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what); }
     Stage s(c);
     a.Z = s.out(Z, (size_t)K * Mt * (d.n + d.m) * ts, /*preload=*/true);
     a.t = (const double*)s.in(t, (size_t)K * Mt * 8); a.dt = (const double*)s.in(dt, (size_t)K * Mt * 8);
     a.X0 = s.in(X0, (size_t)Mt * d.n * ts);
     if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, family_rollout(d, rule, dtype, a), what));
+    return s.finish(kernel_status(c, implicit ? family_implicit(d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
 }
 
 }  // extern "C"

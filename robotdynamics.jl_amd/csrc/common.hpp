@@ -59,7 +59,7 @@ struct LaunchArgs {
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                  \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);    \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);       \
-    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs */
+    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs, 3: rollout */
 RD_DECLARE_FAMILY(fam_cartpole)
 RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)
@@ -76,6 +76,7 @@ int jit_precompile(void* h, int op, int rule, int dtype);
 int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a);
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a);
 int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a);
+int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a);
 
 // error-state kernels (errstate.hip)
 struct LieDesc {

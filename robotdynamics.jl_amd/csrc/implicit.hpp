@@ -174,6 +174,62 @@ RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&
     }
 }
 
+// rollout!(sig, DiscretizedDynamics{ImplicitMidpoint}(model), Z, x0): one lane per trajectory, a Newton solve per step
+// (src/trajectories.jl:436-441 over src/integration.jl:422-463).  Z: (n+m) x K x M, states of knots 2..K overwritten in place.
+template <class Mdl, class T>
+__global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ dtt,
+                                                                const T* __restrict__ X0, int newton_iters, double tol) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    using L = ImplicitLds<Mdl, T>;
+    using Ops = ImplicitOps<Mdl, T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
+    int* piv = reinterpret_cast<int*>(smem + (size_t)TILE * L::RSA * sizeof(T)) + lane * 16;
+    const long long j = (long long)blockIdx.x * TILE + lane;
+    const bool active = j < M;
+    const long long jc = active ? j : M - 1;
+    T* Zj = Z + jc * K * NZ;
+    T x1[NX], u[NU], xn[NX], xl[NX], xm[NX], f[NX], r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x1[i] = X0 ? X0[jc * NX + i] : Zj[i];
+    if (X0 && active) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Zj[i] = x1[i];
+    }
+    for (long long k = 1; k < K; ++k) {
+        const double hd = dtt[jc * K + k - 1];
+        const T h = (T)hd;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(hd) ? T(0) : Zj[(k - 1) * NZ + NX + i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xn[i] = x1[i]; xl[i] = x1[i]; }
+        bool done = false;
+        for (int it = 0; it < newton_iters; ++it) {
+            if (!done) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xl[i] = xn[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
+            Ops::template fill_cols<0>(m, xm, u, h, A, f);
+            T nr = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
+            if ((double)sqrt_(nr) < tol) done = true;
+            if (__all(done)) break;
+            Ops::lu(A, piv);
+            Ops::solve(A, piv, r);
+            if (!done) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xn[i] = xl[i] - r[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x1[i] = xn[i]; if (active) Zj[k * NZ + i] = xn[i]; }
+    }
+}
+
 // dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for the pairs (Z[k], Z[k+1]) (src/integration.jl:631-690)
 template <class Mdl, class T>
 __global__ void __launch_bounds__(TILE) implicit_midpoint_error_kernel(Mdl m, long long P, const T* __restrict__ Z, const double* __restrict__ dtt,

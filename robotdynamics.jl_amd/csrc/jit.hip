@@ -37,11 +37,12 @@ struct JitModel {
     std::string err;
 };
 
-enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6 };   // 5, 6: element-wise fallbacks for unaligned outputs
+enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
+       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10 };   // 5, 6: element-wise fallbacks for unaligned outputs
 
 static std::string program_source(const JitModel& M) {
     std::ostringstream s;
-    s << "#include \"kernels.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
+    s << "#include \"implicit.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
       << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
       << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
       << "    template <class S> RD_DEV void f(const S* x, const S* u, S* xdot) const {\n" << M.body << "\n    }\n};\n}\n";
@@ -51,6 +52,13 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const char* T = dtype == RDHIP_F64 ? "double" : "float";
     const int nz = M.n + M.m;
     std::ostringstream fn, s;
+    if (op >= JOP_IMPLICIT_X) {      // ImplicitMidpoint kernels are templated on the model itself
+        const char* k = op == JOP_IMPLICIT_ERR ? "implicit_midpoint_error_kernel" : op == JOP_IMPLICIT_ROLLOUT ? "implicit_rollout_kernel" : "implicit_midpoint_kernel";
+        s << "rd::" << k << "<rd::UserModel<" << T << ">, " << T;
+        if (op == JOP_IMPLICIT_X) s << ", false"; else if (op == JOP_IMPLICIT_J) s << ", true";
+        s << ">";
+        return s.str();
+    }
     fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
     const int ng = nz >= 4 ? 4 : nz;
     std::ostringstream plan; plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
@@ -118,7 +126,8 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT) jk.block = 64;
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR) jk.block = 64;
+        else if (op >= JOP_IMPLICIT_X) { jk.block = 64; jk.lds = (size_t)64 * ((ny * ny + ny) | 1) * ts + (size_t)64 * 16 * 4; }     // ImplicitLds<Mdl,T>::BYTES
         else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
@@ -199,6 +208,22 @@ int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
         if (per_cu > by_waves) per_cu = by_waves; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
         const long long g = 256LL * per_cu; grid = (unsigned)(ntiles < g ? ntiles : g);
     }
+    return launch(M, k, grid, a.stream, args);
+}
+
+// DiscretizedDynamics{ImplicitMidpoint}(custom model): mode as in dispatch.hpp launch_implicit
+int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    if (a.N == 0) return RDHIP_OK;
+    const int op = mode == 0 ? JOP_IMPLICIT_X : mode == 1 ? JOP_IMPLICIT_J : mode == 2 ? JOP_IMPLICIT_ERR : JOP_IMPLICIT_ROLLOUT;
+    JitKernel* k; int rc = jit_get(M, op, RDHIP_IMPLICIT_MIDPOINT, dtype, &k); if (rc) return rc;
+    std::vector<unsigned char> fn; pack_params(M, dtype, fn);
+    long long N = a.N, K = a.K; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* Y = a.Y; void* J = a.J; void* J2 = a.J2; const void* X0 = a.X0;
+    int iters = a.newton_iters; double tol = a.newton_tol; void* nul = nullptr;
+    const unsigned grid = (unsigned)((N + 63) / 64);
+    if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
+    if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol}; return launch(M, k, grid, a.stream, args); }
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol};
     return launch(M, k, grid, a.stream, args);
 }
 

@@ -565,6 +565,31 @@ def test_implicit_midpoint_newton_solve_and_ift_jacobian(where):
                 np.testing.assert_allclose(host(J2), J2o, rtol=0, atol=TOL * max(1.0, np.abs(J2o).max()))
                 np.testing.assert_allclose(host(J1), J1o, rtol=0, atol=TOL * max(1.0, np.abs(J1o).max()))
                 np.testing.assert_allclose(host(y2), Eo, rtol=0, atol=TOL)
+    # rollout!(sig, DiscretizedDynamics{ImplicitMidpoint}(model), Z, x0): repeated Newton solves along each trajectory
+    for model, om, nz in ((RD.Cartpole(), O.cartpole(), 5), (RD.Satellite(), O.satellite(), 19)):
+        n = RD.state_dim(model)
+        M, K = 70, 12
+        data = (H.rand_rigid(rng, M * K, 6) if nz == 19 else rng.random((M * K, nz))).reshape(M, K, nz)
+        tt, dd = np.tile(np.arange(K) * 0.05, (M, 1)), np.full((M, K), 0.05)
+        ref = data.copy()
+        for k in range(1, K):
+            ref[:, k, :n] = om.implicit_midpoint(ref[:, k - 1], tt[:, k - 1], dd[:, k - 1], want_jacobian=False)[0]
+        stack = {"data": data.copy(), "t": tt, "dt": dd}
+        if where == "cuda":
+            stack = {k_: torch.as_tensor(v).cuda() for k_, v in stack.items()}
+        RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(model, RD.ImplicitMidpoint), stack)
+        np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
+    # a JIT-compiled custom model under the implicit rule
+    cm = RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81))
+    Zc = rng.random((40, 5)); tc, dc = np.zeros(40), np.full(40, 0.1)
+    dmc = RD.DiscretizedDynamics(cm, RD.ImplicitMidpoint)
+    Zt = traj(cm, Zc, tc, dc, "cuda" if where == "cuda" else None)
+    Xo, Jo, _ = O.cartpole().implicit_midpoint(Zc, tc, dc)
+    Jc = RD.alloc_jacobians(dmc, 40, Zt.data)
+    RD.jacobian_(RD.StaticReturn(), RD.default_diffmethod(dmc), dmc, Jc, None, Zt)
+    np.testing.assert_allclose(host(Jc), Jo, rtol=0, atol=TOL * max(1.0, np.abs(Jo).max()))
+    np.testing.assert_allclose(host(RD.discrete_dynamics(dmc, Zt)), Xo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(RD.dynamics_error(dmc, Zt)), O.cartpole().implicit_midpoint_error(Zc, tc, dc)[0], rtol=0, atol=TOL)
     # fewer Newton iterations than needed: the iterate after 1 step, as the oracle with newton_iters = 1
     model, om = RD.Cartpole(), O.cartpole()
     RD.setnewtoniters(model, 1)
