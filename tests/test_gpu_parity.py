@@ -239,6 +239,46 @@ def test_degenerate_batch_sizes_of_the_pair_operators():
                             traj(model, H.rand_rigid(rng, 3, 6), np.zeros(3), np.full(3, 0.1), None))
 
 
+def test_two_streams_two_contexts_run_concurrently():
+    """One context per HIP stream (rdhip borrows torch's current stream): interleaved launches on two streams give the same results
+    as sequential ones, and from two host threads (one context each, as the header prescribes) as well."""
+    import threading
+    rng = np.random.default_rng(24)
+    model, om = RD.Satellite(), O.satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    N = 3000
+    Zs = [H.rand_rigid(rng, N, 6) for _ in range(2)]
+    t, dt = np.zeros(N), np.full(N, 0.1)
+    refs = [om.jacobian(O.RK4, O.FORWARD_AD, Z, t, dt)[0] for Z in Zs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    Zd = [traj(model, Z, t, dt, "cuda") for Z in Zs]
+    Js = [RD.alloc_jacobians(dm, N, Zd[0].data) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, Js[i], None, Zd[i])
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        np.testing.assert_allclose(host(Js[i]), refs[i], rtol=0, atol=TOL)
+        Js[i].zero_()
+    errs = []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(20):
+                    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, Js[i], None, Zd[i])
+            streams[i].synchronize()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in (0, 1)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errs
+    for i in (0, 1):
+        np.testing.assert_allclose(host(Js[i]), refs[i], rtol=0, atol=TOL)
+
+
 def test_empty_batch_is_a_noop():
     model = RD.Satellite()
     dm = RD.DiscretizedDynamics(model, RD.RK4)
