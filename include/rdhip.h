@@ -187,7 +187,8 @@ int rdhip_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype,
                             const void* X, int ldx, int clear, void* G, int memspace);
 
 /* state_diff(model, x, x0) with the default CayleyMap: src/statevectortype.jl:102-104,145-146, src/liestate.jl:210-260.
- * dX: e x N. */
+ * dX: e x N.  Served for QuatRotation, MRP and RodriguesParam LieStates (test/liestate.jl:33-68): the rotation part is the vector of
+ * Rodrigues parameters of q0^-1 q whatever the parameterisation. */
 int rdhip_state_diff(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
                      const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace);
 

@@ -50,15 +50,17 @@ static void build_lie(rdhip_model* M) {
         for (int i = 0; i < d.n && i < 16; ++i) { L.row_kind[i] = 0; L.row_col[i] = (signed char)i; L.err_src[i] = (signed char)i; }
         return;
     }
-    if (d.rot != RDHIP_ROT_QUAT) return;   // kernels refuse non-quaternion rotations; the table is unused
+    L.rot = d.rot;
+    const int rp = rot_params(d.rot);
     int r = 0, c = 0;
     for (int v = 0; v < d.lie_nP; ++v) {
         for (int j = 0; j < d.lie_P[v]; ++j) { L.row_kind[r] = 0; L.row_col[r] = (signed char)c; L.err_src[c] = (signed char)r; ++r; ++c; }
         if (v < d.lie_nP - 1) {
             L.rot_row0[v] = (signed char)r; L.rot_col0[v] = (signed char)c;
-            for (int i = 0; i < 4; ++i) { L.row_kind[r + i] = 1; L.row_col[r + i] = (signed char)c; L.row_sub[r + i] = (signed char)i; L.row_q0[r + i] = (signed char)r; }
+            // G tables (errstate_jacobian!, nabla): quaternion blocks only; MRP / RodriguesParam models are served by state_diff alone
+            if (rp == 4) for (int i = 0; i < 4; ++i) { L.row_kind[r + i] = 1; L.row_col[r + i] = (signed char)c; L.row_sub[r + i] = (signed char)i; L.row_q0[r + i] = (signed char)r; }
             for (int j = 0; j < 3; ++j) L.err_src[c + j] = (signed char)(-1 - v);
-            r += 4; c += 3;
+            r += rp; c += 3;
         }
     }
 }
@@ -502,8 +504,7 @@ int rdhip_state_diff(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N,
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (N > 0 && (!X || !X0 || !dX)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     if (ldx < M->d.n || ldx0 < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
-    rc = check_rotation(c, M); if (rc) return rc;
-    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;      // state_diff serves QuatRotation, MRP and RodriguesParam
     if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, X, ldx, X0, ldx0, dX), what);
     Stage s(c);
     const void* a = s.in(X, (size_t)N * ldx * ts); const void* b = s.in(X0, (size_t)N * ldx0 * ts);

@@ -81,6 +81,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a);
 // error-state kernels (errstate.hip)
 struct LieDesc {
     int n, e, nrot;
+    int rot;                    // rdhip_rotation of the rotation blocks (QUAT: 4 parameters, MRP / RP: 3); only state_diff serves MRP / RP
     signed char row_kind[16];   // 0: vector row, 1: quaternion row
     signed char row_col[16];    // vector row: its column in G ; quaternion row: first column of the 3-wide block
     signed char row_sub[16];    // quaternion row: component index 0..3

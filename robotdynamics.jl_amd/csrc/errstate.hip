@@ -136,12 +136,27 @@ __global__ void __launch_bounds__(256) state_diff_kernel(LieDesc d, long long N,
     if (src >= 0) { dX[idx] = x[src] - x0[src]; return; }
     const int rot = -1 - src;
     const int j = c - d.rot_col0[rot];   // 0..2
-    const T* q = x + d.rot_row0[rot]; const T* p = x0 + d.rot_row0[rot];
-    const T iq = rsqrt_<T>(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    const T ip = rsqrt_<T>(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
-    const T a0 = q[0] * iq, a1 = q[1] * iq, a2 = q[2] * iq, a3 = q[3] * iq;     // q
-    const T b0 = p[0] * ip, b1 = -p[1] * ip, b2 = -p[2] * ip, b3 = -p[3] * ip;  // conj(q0)
-    // dq = conj(q0) (x) q
+    // both rotations as unit quaternions [w x y z]: QuatRotation(w,x,y,z) normalises; RodriguesParam g = v/w -> [1; g]/|.|;
+    // MRP p = v/(1+w) -> [1 - p.p; 2p]/(1 + p.p)   (Rotations.jl conversions)
+    T qa[4], qb[4];
+    const T* ra = x + d.rot_row0[rot]; const T* rb = x0 + d.rot_row0[rot];
+    if (d.rot == RDHIP_ROT_QUAT) {
+        const T iq = rsqrt_<T>(ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2] + ra[3] * ra[3]);
+        const T ip = rsqrt_<T>(rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2] + rb[3] * rb[3]);
+        for (int i = 0; i < 4; ++i) { qa[i] = ra[i] * iq; qb[i] = rb[i] * ip; }
+    } else if (d.rot == RDHIP_ROT_RP) {
+        const T ia = rsqrt_<T>(T(1) + ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2]), ib = rsqrt_<T>(T(1) + rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2]);
+        qa[0] = ia; qb[0] = ib;
+        for (int i = 0; i < 3; ++i) { qa[1 + i] = ra[i] * ia; qb[1 + i] = rb[i] * ib; }
+    } else {
+        const T na = ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2], nb = rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2];
+        const T ia = T(1) / (T(1) + na), ib = T(1) / (T(1) + nb);
+        qa[0] = (T(1) - na) * ia; qb[0] = (T(1) - nb) * ib;
+        for (int i = 0; i < 3; ++i) { qa[1 + i] = T(2) * ra[i] * ia; qb[1 + i] = T(2) * rb[i] * ib; }
+    }
+    const T a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];                      // q
+    const T b0 = qb[0], b1 = -qb[1], b2 = -qb[2], b3 = -qb[3];                   // conj(q0)
+    // dq = conj(q0) (x) q ; Cayley error = vec(dq) / scalar(dq)  (rotation_error(q, q0, CayleyMap), test/rbstate.jl:157)
     const T w = b0 * a0 - b1 * a1 - b2 * a2 - b3 * a3;
     const T v = (j == 0) ? (b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2)
               : (j == 1) ? (b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1)

@@ -713,6 +713,8 @@ class LieSatellite(LieGroupModel):           # `Satellite` of test/liemodel.jl:1
 
 # ---- trait queries ------------------------------------------------------------------------------------------------
 def _cm(fun):
+    if isinstance(fun, LieState):
+        return fun._model()
     return fun.continuous_dynamics if isinstance(fun, DiscretizedDynamics) else fun
 
 
@@ -841,6 +843,13 @@ class LieState:
 
     def errstate_dim(self):
         return self._query()[1]
+
+    def _model(self):
+        """A state-only native model carrying this partition: lets state_diff(s::LieState, x, x0) (src/liestate.jl:210-260) run batched."""
+        m = getattr(self, "_m", None)
+        if m is None:
+            m = self._m = CustomModel(len(self), 1, "/* state-only LieState carrier */ xdot[0] = x[0];", liestate=(self.R, self.P))
+        return m
 
     def __eq__(self, other):
         return isinstance(other, LieState) and self.R is other.R and self.P == other.P

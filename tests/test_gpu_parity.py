@@ -279,6 +279,44 @@ def test_two_streams_two_contexts_run_concurrently():
         np.testing.assert_allclose(host(Js[i]), refs[i], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
+    """state_diff(s::LieState, x, x0) on raw rand(n) vectors, as test/liestate.jl:33-51 (QuatRotation, P = (3,2,3)) and :56-68
+    (RodriguesParam): vector parts subtract, every rotation part is q (-) q0 = the Cayley (Rodrigues) parameters of q0^-1 q.
+    Expected values from scipy's Rotation algebra (independent of the library and of the oracle)."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(33)
+    N = 257
+
+    def to_scipy(kind, p):
+        if kind == "quat":
+            return R.from_quat(np.roll(p / np.linalg.norm(p, axis=1, keepdims=True), -1, axis=1))     # scipy is scalar-last
+        if kind == "rp":
+            q = np.concatenate([np.ones((len(p), 1)), p], axis=1)
+            return R.from_quat(np.roll(q / np.linalg.norm(q, axis=1, keepdims=True), -1, axis=1))
+        return R.from_mrp(p)
+
+    for Rtype, kind, rp in ((RD.QuatRotation, "quat", 4), (RD.RodriguesParam, "rp", 3), (RD.MRP, "mrp", 3)):
+        P = (3, 2, 3)
+        s = RD.LieState(Rtype, P)
+        n = len(s)
+        assert n == sum(P) + 2 * rp and RD.errstate_dim(s) == 14
+        X, X0 = rng.random((N, n)), rng.random((N, n))
+        exp = np.zeros((N, 14))
+        r = c = 0
+        for i, p in enumerate(P):
+            exp[:, c:c + p] = X[:, r:r + p] - X0[:, r:r + p]; r += p; c += p
+            if i < len(P) - 1:
+                rel = (to_scipy(kind, X0[:, r:r + rp]).inv() * to_scipy(kind, X[:, r:r + rp])).as_quat()
+                exp[:, c:c + 3] = rel[:, :3] / rel[:, 3:4]
+                r += rp; c += 3
+        a, b = (torch.as_tensor(X).cuda(), torch.as_tensor(X0).cuda()) if where == "cuda" else (X, X0)
+        np.testing.assert_allclose(host(RD.state_diff(s, a, b)), exp, rtol=0, atol=1e-12)
+        if kind != "quat":      # the error-state Jacobians of MRP / RodriguesParam states are not built (formulas unpinned, SURVEY App. A)
+            with pytest.raises(NotImplementedError):
+                RD.errstate_jacobian_(s, np.zeros((N, 14, n)).transpose(0, 2, 1), X, clear=True)
+
+
 def test_empty_batch_is_a_noop():
     model = RD.Satellite()
     dm = RD.DiscretizedDynamics(model, RD.RK4)
