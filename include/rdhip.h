@@ -113,6 +113,10 @@ int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const cha
 /* setnewtoniters / setnewtontolerance of an ImplicitDynamicsModel (src/discretized_dynamics.jl:225-228); defaults 10 and 1e-12
  * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol. */
 int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_tol);
+/* Custom models with n+m > 10: measure the cost of every Jacobian column (each is JIT-compiled alone, ~0.5 s per column, no GPU needed)
+ * and assign the columns to the compute waves of the Jacobian kernel by cost instead of in contiguous ranges.  Optional; call it before
+ * the first Jacobian (kernels compiled earlier are discarded). */
+int rdhip_model_balance_columns(rdhip_model* model);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
  * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT); custom models only */

@@ -201,6 +201,11 @@ int rdhip_model_set_newton(rdhip_model* M, int iters, double tol) {
     if (iters < 1 || !(tol > 0)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "newton_iters must be >= 1 and newton_tol > 0");
     M->d.newton_iters = iters; M->d.newton_tol = tol; return RDHIP_OK;
 }
+int rdhip_model_balance_columns(rdhip_model* M) {
+    if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_balance_columns: not a custom model");
+    const int rc = jit_balance(M->d.jit);
+    return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
+}
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
     if (op < 0 || op > 10 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -35,6 +36,8 @@ struct JitModel {
     std::map<std::string, std::string> lowered;
     std::map<std::string, JitKernel> loaded;              // key@device -> loaded function
     std::string err;
+    std::vector<int> plan_wave;                           // column -> compute wave (after jit_balance); empty: contiguous ranges
+    int plan_value_wave = 0;
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
@@ -61,7 +64,12 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     }
     fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
     const int ng = nz >= 4 ? 4 : nz;
-    std::ostringstream plan; plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
+    std::ostringstream plan;
+    if (!M.plan_wave.empty() && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN) && nz > 10) {     // cost-balanced column -> wave table
+        plan << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
+        for (int c = 0; c < nz; ++c) plan << ", " << M.plan_wave[c];
+        plan << ">";
+    } else plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
     switch (op) {
         case JOP_EVAL: s << "rd::eval_kernel<" << fn.str() << ", " << T << ">"; break;
         case JOP_ROLLOUT: s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">"; break;
@@ -139,6 +147,42 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         it = M.loaded.emplace(kd.str(), jk).first;
     }
     *out = &it->second;
+    return RDHIP_OK;
+}
+
+// Column costs by compiling each column alone (RK4, fp64) and reading the size of the code object, then longest-processing-time-first
+// assignment of the columns to the 4 compute waves of the split-role kernel; f(z) goes to the lightest wave.
+int jit_balance(void* h) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    std::lock_guard<std::mutex> g(M.mu);
+    const int nz = M.n + M.m;
+    if (nz <= 10) return RDHIP_OK;                       // small models use the all-columns-per-lane kernel
+    const std::string src = program_source(M);
+    std::vector<size_t> cost(nz, 0);
+    for (int c = 0; c < nz; ++c) {
+        std::ostringstream e; e << "rd::col_probe_kernel<rd::Fun<rd::UserModel<double>, 3>, double, " << c << ">";
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "rdhip_user_model.hip", rdhip_embedded_count, rdhip_embedded_sources, rdhip_embedded_names) != HIPRTC_SUCCESS) { M.err = "hiprtcCreateProgram failed"; return RDHIP_ERR_HIP; }
+        hiprtcAddNameExpression(prog, e.str().c_str());
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize"};
+        if (hiprtcCompileProgram(prog, 6, opts) != HIPRTC_SUCCESS) {
+            size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls); std::string log(ls, ' '); if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            M.err = "hipRTC compilation of the user model failed:\n" + log.substr(0, 3000); hiprtcDestroyProgram(&prog); return RDHIP_ERR_INVALID_ARG;
+        }
+        hiprtcGetCodeSize(prog, &cost[c]);
+        hiprtcDestroyProgram(&prog);
+    }
+    size_t base = cost[0]; for (size_t v : cost) base = v < base ? v : base;        // fixed code-object overhead ~ the cheapest column
+    std::vector<int> order(nz); for (int c = 0; c < nz; ++c) order[c] = c;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    size_t load[4] = {0, 0, 0, 0};
+    M.plan_wave.assign(nz, 0);
+    for (int c : order) { int w = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[w]) w = i; M.plan_wave[c] = w; load[w] += cost[c] - base + 64; }
+    int vw = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[vw]) vw = i;
+    M.plan_value_wave = vw;
+    // kernels compiled with the old plan are stale
+    for (auto& kv : M.loaded) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    M.loaded.clear(); M.code.clear(); M.lowered.clear();
     return RDHIP_OK;
 }
 

@@ -330,6 +330,22 @@ __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_unrolled_kernel(Fn fn,
     jac_tile_loop<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
 }
 
+// one Jacobian column of one knot point per lane, nothing else: the hipRTC plug-in compiles this per column and uses the code size as
+// the column's cost when it balances a custom model's columns over the compute waves (jit.hip)
+template <class Fn, class T, int C>
+__global__ void col_probe_kernel(Fn fn, const T* __restrict__ Z, T* __restrict__ O) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY;
+    using D = Dual<T, 1>;
+    D xd[NX], ud[NU], yd[NY];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xd[i].v = Z[threadIdx.x * (NX + NU) + i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { ud[i].v = Z[threadIdx.x * (NX + NU) + NX + i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
+    fn.eval(xd, ud, T(0), Z[4096], yd);
+#pragma unroll
+    for (int i = 0; i < NY; ++i) O[threadIdx.x * NY + i] = yd[i].d[0];
+}
+
 // ---- split-role variant of the tile loop --------------------------------------------------------------------------
 // A copy-out that is issued by the same waves that compute cannot overlap with compute: when HBM is the bottleneck the
 // store instructions block AT ISSUE, so a workgroup whose LDS tile fills a whole CU alternates "all compute" / "all

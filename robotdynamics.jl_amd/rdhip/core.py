@@ -609,6 +609,12 @@ class CustomModel(ContinuousDynamics):
             self._h = h
         return h
 
+    def balance_columns(self):
+        """n+m > 10: cost-balance the Jacobian columns over the compute waves (each column is JIT-compiled alone and its code size is
+        the cost; ~0.5 s per column).  Call before the first Jacobian."""
+        L.check(L.lib().rdhip_model_balance_columns(self._handle))
+        return self
+
     def precompile(self, what="ForwardAD", rule=RK4, dtype=np.float64):
         """JIT-compile one kernel now (works without a GPU); raises ValueError with the compiler log if the source does not compile."""
         code = L.CONTINUOUS if rule is None else _rule_code(rule() if isinstance(rule, type) else rule)

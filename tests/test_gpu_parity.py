@@ -576,6 +576,14 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     Ju = buf[1:].view(N, 19, 13).transpose(1, 2)
     RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(sat, RD.RK4), Ju, None, Z)
     np.testing.assert_allclose(host(Ju), O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)[0], rtol=0, atol=TOL)
+    # cost-balanced column plan (columns JIT-compiled one by one, code size = cost): same numbers as the contiguous plan
+    satb = RD.CustomModel(13, 6, SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6))).balance_columns()
+    Jb = RD.alloc_jacobians(RD.DiscretizedDynamics(satb, RD.RK4), N, Z.data)
+    Yb = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(satb, RD.RK4), Jb, Yb, Z)
+    Jo, Yo = O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    np.testing.assert_allclose(host(Jb), Jo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Yb), Yo, rtol=0, atol=TOL)
     # rollout of the custom cartpole
     M, K = 9, 30
     data = rng.random((M, K, 5)); tt = np.tile(np.arange(K) * 0.02, (M, 1)); dd = np.full((M, K), 0.02)

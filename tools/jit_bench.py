@@ -9,5 +9,7 @@ Zs = B.rigid_inputs(65536, 6, rng)
 sat = RD.CustomModel(13, 6, SATELLITE_SRC, params=(1.0, 1.0, 1.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
 B.jac_case("JIT satellite RK4 jacobian ForwardAD (split-role kernel, contiguous plan)", sat, Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
 B.jac_case("JIT satellite RK4 jacobian UserDefined", sat, Zs, RD.RK4, RD.UserDefined(), np.float64, 30)
+satb = RD.CustomModel(13, 6, SATELLITE_SRC, params=(1.0, 1.0, 1.0, 1.0), liestate=(RD.QuatRotation, (3, 6))).balance_columns()
+B.jac_case("JIT satellite RK4 jacobian ForwardAD (cost-balanced columns)", satb, Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
 B.jac_case("built-in satellite RK4 jacobian ForwardAD", RD.Satellite(), Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
 B.eval_case("JIT satellite RK4 discrete_dynamics", sat, Zs, RD.RK4, np.float64, 30)
