@@ -51,16 +51,4 @@ def rand_rigid(rng, N, m, ulo=0.0, uhi=1.0):
     X = np.concatenate([rng.random((N, 3)), q, rng.random((N, 6))], axis=1)
     return np.concatenate([X, ulo + (uhi - ulo) * rng.random((N, m))], axis=1)
 
-
-CARTPOLE_SRC = """
-    // examples/cartpole.jl:15-34 written as a HIP device-function body: p = {mc, mp, l, g}
-    const S s = sin_(x[1]), c = cos_(x[1]);
-    const T H11 = p[0] + p[1], H22 = p[1] * p[2] * p[2];
-    const S H12 = c * (p[1] * p[2]);
-    const S r0 = (x[3] * x[3]) * s * (-(p[1] * p[2])) - u[0];
-    const S r1 = s * (p[1] * p[3] * p[2]);
-    const S det = H12 * H12 * T(-1) + H11 * H22;
-    xdot[0] = x[2]; xdot[1] = x[3];
-    xdot[2] = -((r0 * H22 - H12 * r1) / det);
-    xdot[3] = -((r1 * H11 - H12 * r0) / det);
-"""
+from examples.custom_models import CARTPOLE_SRC, SATELLITE_SRC  # noqa: E402,F401

@@ -518,25 +518,12 @@ def test_error_state_expansion_fused_into_the_jacobian_kernel(where):
                 np.testing.assert_allclose(host(y), yo, rtol=0, atol=TOL)
 
 
-SATELLITE_SRC = """
-    // src/rigidbody.jl:213-236 with the satellite wrench (examples/single_satellite.jl:18-27), world-frame velocity; p = {mass, Jxx, Jyy, Jzz}
-    const S* q = x + 3; const S* v = x + 7; const S* w = x + 10;
-    S F[3]; quat_rotate(q, u, F);
-    quat_kinematics(q, w, xdot + 3);
-    const T im = T(1) / p[0];
-    for (int i = 0; i < 3; ++i) { xdot[i] = v[i]; xdot[7 + i] = F[i] * im; }
-    const S Jw[3] = {w[0] * p[1], w[1] * p[2], w[2] * p[3]};
-    S c[3]; cross3(w, Jw, c);
-    xdot[10] = (u[3] - c[0]) / p[1]; xdot[11] = (u[4] - c[1]) / p[2]; xdot[12] = (u[5] - c[2]) / p[3];
-"""
-
-
 def test_custom_models_jit_match_the_compiled_in_ones():
     """User-defined dynamics through the hipRTC plug-in: the cartpole and the satellite re-written as source strings must reproduce
     the oracle for every operator (dynamics, RK3/RK4 steps, all three diff methods, rollout, error-state operators, fp32)."""
     rng = np.random.default_rng(31)
     cart = RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81))
-    sat = RD.CustomModel(13, 6, SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
+    sat = RD.CustomModel(13, 6, H.SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
     for model, om, Zn in ((cart, O.cartpole(), rng.random((150, 5))), (sat, O.body(), H.rand_rigid(rng, 150, 6))):
         N = Zn.shape[0]
         n, m = RD.state_dim(model), RD.control_dim(model)
@@ -577,7 +564,7 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(sat, RD.RK4), Ju, None, Z)
     np.testing.assert_allclose(host(Ju), O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)[0], rtol=0, atol=TOL)
     # cost-balanced column plan (columns JIT-compiled one by one, code size = cost): same numbers as the contiguous plan
-    satb = RD.CustomModel(13, 6, SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6))).balance_columns()
+    satb = RD.CustomModel(13, 6, H.SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6))).balance_columns()
     Jb = RD.alloc_jacobians(RD.DiscretizedDynamics(satb, RD.RK4), N, Z.data)
     Yb = torch.empty((N, 13), dtype=torch.float64, device="cuda")
     RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(satb, RD.RK4), Jb, Yb, Z)

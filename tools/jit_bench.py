@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "robotdynamics.jl_amd")
 import numpy as np, torch, rdhip as RD
-from tests.test_gpu_parity import SATELLITE_SRC
+from examples.custom_models import SATELLITE_SRC
 sys.path.insert(0, "tools")
 import bench_configs as B
 rng = np.random.default_rng(1)
