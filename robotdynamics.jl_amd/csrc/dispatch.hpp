@@ -65,6 +65,8 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     using T = typename Fn::T;
     constexpr int NZ = Fn::NX + Fn::NU;
     using DefPlan = ContiguousPlan<NZ, (NZ >= 4 ? 4 : NZ)>;     // compact kernels: 4 waves per tile, one chunk
+    // run-time-column bodies also go through the split-role loop when the output tile is big enough to be worth dedicated copy waves
+    constexpr bool split_fits = NZ > 10 && SplitLds<Fn, T, DefPlan, 4>::BYTES <= 160 * 1024;
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
     if (diff == RDHIP_FORWARD_AD) {
@@ -86,9 +88,13 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             }
             return launch_jac_kernel<Fn, T, Plan>(jac_ad_unrolled_kernel<Fn, T, Plan>, fn, a);
         } else {
+            if constexpr (split_fits)
+                if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, fn, a);
             return launch_jac_kernel<Fn, T, DefPlan>(jac_ad_loop_kernel<Fn, T, DefPlan>, fn, a);
         }
     } else if (diff == RDHIP_FINITE_DIFF) {
+        if constexpr (split_fits)
+            if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, fn, a);
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
     } else if (diff == RDHIP_USER_DEFINED) {
         if constexpr (Mdl::HAS_USER_JACOBIAN) {

@@ -41,7 +41,7 @@ struct JitModel {
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
-       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10 };   // 5, 6: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
 
 static std::string program_source(const JitModel& M) {
     std::ostringstream s;
@@ -55,7 +55,7 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const char* T = dtype == RDHIP_F64 ? "double" : "float";
     const int nz = M.n + M.m;
     std::ostringstream fn, s;
-    if (op >= JOP_IMPLICIT_X) {      // ImplicitMidpoint kernels are templated on the model itself
+    if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitMidpoint kernels are templated on the model itself
         const char* k = op == JOP_IMPLICIT_ERR ? "implicit_midpoint_error_kernel" : op == JOP_IMPLICIT_ROLLOUT ? "implicit_rollout_kernel" : "implicit_midpoint_kernel";
         s << "rd::" << k << "<rd::UserModel<" << T << ">, " << T;
         if (op == JOP_IMPLICIT_X) s << ", false"; else if (op == JOP_IMPLICIT_J) s << ", true";
@@ -78,7 +78,11 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
             else s << "rd::jac_ad_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
             break;
         case JOP_JAC_AD_LOOP: s << "rd::jac_ad_loop_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
-        case JOP_JAC_FD: s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
+        case JOP_JAC_FD:
+            if (nz <= 10) s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">";
+            else s << "rd::jac_fd_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
+            break;
+        case JOP_JAC_FD_LOOP: s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
         case JOP_JAC_CHAIN:
             if (nz <= 10) s << "rd::jac_chain_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">";
             else s << "rd::jac_chain_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
@@ -131,11 +135,11 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         if (hipModuleGetFunction(&jk.fn, jk.mod, M.lowered[key].c_str()) != hipSuccess) { M.err = "hipModuleGetFunction failed for " + M.lowered[key]; return RDHIP_ERR_HIP; }
         const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = M.n + M.m, ny = M.n;
         jk.small = (op == JOP_JAC_AD && nz <= 10);
-        const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN);
+        const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
         else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR) jk.block = 64;
-        else if (op >= JOP_IMPLICIT_X) { jk.block = 64; jk.lds = (size_t)64 * ((ny * ny + ny) | 1) * ts + (size_t)64 * 16 * 4; }     // ImplicitLds<Mdl,T>::BYTES
+        else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) { jk.block = 64; jk.lds = (size_t)64 * ((ny * ny + ny) | 1) * ts + (size_t)64 * 16 * 4; }     // ImplicitLds<Mdl,T>::BYTES
         else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
@@ -239,7 +243,7 @@ int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
     if (a.N == 0) return RDHIP_OK;
     int op = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.J) | reinterpret_cast<uintptr_t>(a.Y)) & 15) == 0;
-    if (M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : op);   // the split-role kernels copy 16-B units
+    if (M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);   // the split-role kernels copy 16-B units
     JitKernel* k; int rc = jit_get(M, op, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* J = a.J; void* Y = a.Y;

@@ -279,6 +279,48 @@ def test_two_streams_two_contexts_run_concurrently():
         np.testing.assert_allclose(host(Js[i]), refs[i], rtol=0, atol=TOL)
 
 
+def test_device_calls_can_be_captured_in_a_hip_graph():
+    """A solver iteration at small N is launch-bound; with device-resident data the library only enqueues kernels on the context's
+    stream, so a sequence of calls can be captured once into a HIP graph (torch.cuda.graph on ROCm) and replayed.  The replay must give
+    what the eager calls give, also after the inputs changed in place."""
+    rng = np.random.default_rng(27)
+    N = 101
+    model, om = RD.Quadrotor(), O.quadrotor()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Zn = H.rand_rigid(rng, N, 4)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    Z = traj(model, Zn, t, dt, "cuda")
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    G = RD.alloc_errstate_jacobians(model, N, Z.data)
+    E = RD.alloc_error_expansions(dm, N, Z.data)
+    s = torch.cuda.Stream()
+
+    def iteration():
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+        RD.errstate_jacobian_(model, G, Z.data[:, :13], clear=True)
+        RD.error_expansion_(dm, E, None, Z)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        iteration()                                   # warm-up: creates the context of this stream, sets the kernels' LDS attributes
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        iteration()
+    for scale in (1.0, 0.5):
+        Z.data[:, 7:].mul_(scale)                     # velocities and controls change in place between replays
+        Zh = host(Z.data)
+        J.zero_(); Y.zero_(); G.zero_(); E.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        Jr, Yr = om.jacobian(O.RK4, O.FORWARD_AD, Zh, t, dt)
+        np.testing.assert_allclose(host(J), Jr, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(Y), Yr, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(G), om.errstate_jacobian(Zh[:, :13]), rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(E), om.error_expansion(O.RK4, Zh, t, dt)[0], rtol=0, atol=TOL)
+
+
 @pytest.mark.parametrize("where", ["host", "cuda"])
 def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
     """state_diff(s::LieState, x, x0) on raw rand(n) vectors, as test/liestate.jl:33-51 (QuatRotation, P = (3,2,3)) and :56-68
