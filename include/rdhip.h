@@ -209,6 +209,17 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
 int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M,
                   void* Z, const double* t, const double* dt, const void* X0, int memspace);
 
+/* layouts of a batch of M trajectories x K knot points (Z, t, dt and the Jacobians share the knot indexing) */
+#define RDHIP_TRAJECTORY_MAJOR 0   /* knot k of trajectory j at index j*K + k: M consecutive trajectories, what rdhip_rollout takes */
+#define RDHIP_TIME_MAJOR 1         /* knot k of trajectory j at index k*M + j: knot k of all trajectories contiguous */
+
+/* rollout!(sig, dmodel, Z, x0) followed by jacobian!(sig, diff, dmodel, J[k], y, Z[k]) at every knot point of the simulated trajectories
+ * (the forward pass + linearisation of a shooting method; rollout!: src/trajectories.jl:436-441, jacobian!: src/functionbase.jl:242-257).
+ * Same result as rdhip_rollout + rdhip_jacobian on the K*M knot points.  Z: (n+m) x (K*M), J: n x (n+m) x (K*M), t, dt: K*M, X0: n x M or NULL.
+ * Implicit rules take RDHIP_TRAJECTORY_MAJOR data only. */
+int rdhip_rollout_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long K, long long M, int layout,
+                           void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace);
+
 #ifdef __cplusplus
 }
 #endif

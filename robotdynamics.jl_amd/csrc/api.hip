@@ -554,4 +554,39 @@ int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long 
     return s.finish(kernel_status(c, implicit ? family_implicit(d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
 }
 
+// rollout!, then the Jacobians along the rollout: what a shooting / iLQR forward pass + linearisation needs, in one call.
+// Two launches back to back on the context's stream; the Jacobian kernel finds the simulated states in L2 / Infinity Cache.
+// (Issuing the rollout in pieces and computing the Jacobians of finished pieces on a second stream was measured and dropped: the
+// rollout's latency chain slows down by as much as it overlaps once the Jacobian kernel saturates the memory system)
+int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long K, long long Mt, int layout,
+                           void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace) {
+    const char* what = "rdhip_rollout_jacobian";
+    int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
+    if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
+    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
+    if (layout != RDHIP_TRAJECTORY_MAJOR && layout != RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad layout %d", what, layout);
+    const long long N = K * Mt;
+    if (N == 0) return RDHIP_OK;
+    if (!Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M); if (rc) return rc;
+    const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
+    if (implicit && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take ImplicitFunctionTheorem(ForwardAD()) only", what);
+    if (implicit && layout == RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take trajectory-major data only", what);
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d; const int nz = d.n + d.m;
+    Stage s(c);
+    LaunchArgs r{}; r.stream = c->stream; r.N = Mt; r.K = K; r.Z = Z; r.t = t; r.dt = dt; r.X0 = X0; r.time_major = (layout == RDHIP_TIME_MAJOR);
+    void* dJ = J;
+    if (memspace == RDHIP_HOST) {
+        r.Z = s.out(Z, (size_t)N * nz * ts, /*preload=*/true); r.t = (const double*)s.in(t, (size_t)N * 8); r.dt = (const double*)s.in(dt, (size_t)N * 8);
+        r.X0 = s.in(X0, (size_t)Mt * d.n * ts); dJ = s.out(J, (size_t)N * d.n * nz * ts);
+        if (s.rc) return s.rc;
+    }
+    LaunchArgs j{}; j.stream = c->stream; j.N = N; j.Z = r.Z; j.t = r.t; j.dt = r.dt; j.J = dJ;
+    if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
+    int k = kernel_status(c, implicit ? family_implicit(d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
+    if (!k) k = kernel_status(c, implicit ? family_implicit(d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
+    return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
+
 }  // extern "C"

@@ -52,6 +52,7 @@ struct LaunchArgs {
     void* J2;           // implicit dynamics_error_jacobian: d e / d z2 (J holds d e / d z1)
     int newton_iters;   // implicit rules
     double newton_tol;
+    int time_major;     // rollout: knot k of trajectory j at k*M + j instead of j*K + k
 };
 
 // per-family entry points (one translation unit each so they compile in parallel)

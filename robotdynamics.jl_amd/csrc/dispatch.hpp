@@ -23,7 +23,8 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
     const unsigned grid = (unsigned)((a.N + 63) / 64);
-    hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+    const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
+    hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }
 // persistent grid for the tile kernels: as many workgroups as fit on the chip at once (LDS-limited), never more than tiles

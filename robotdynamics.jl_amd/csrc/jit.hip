@@ -234,8 +234,9 @@ int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
     JitKernel* k; int rc = jit_get(M, JOP_ROLLOUT, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
-    long long K = a.K, Mt = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; const void* X0 = a.X0;
-    void* args[] = {fn.data(), &K, &Mt, &Z, &t, &dt, &X0};
+    long long K = a.K, Mt = a.N, sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
+    const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; const void* X0 = a.X0;
+    void* args[] = {fn.data(), &K, &Mt, &sj, &sk, &Z, &t, &dt, &X0};
     return launch(M, k, (unsigned)((Mt + 63) / 64), a.stream, args);
 }
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {

@@ -241,6 +241,22 @@ function error_expansion!(fun::RD.DiscretizedDynamics, E::Array{T,3}, Y::Union{N
     check(ctx, rc)
 end
 
+# rollout!(sig, dmodel, Z, x0) of M stacked trajectories followed by jacobian! at every simulated knot point, one call
+# (the forward pass + linearisation of a shooting method).  Zs holds the M trajectories back to back (K knot points each).
+function rollout_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.DiscretizedDynamics, J::Array{T,3}, Zs::PackedTrajectory{n,m,T},
+                           K::Integer, x0::Union{Nothing,Matrix{T}}=nothing; ctx::Context=default_context()) where {n,m,T}
+    N = length(Zs); M = div(N, K)
+    M * K == N || throw(DimensionMismatch("the stack must hold whole trajectories of K knot points"))
+    size(J) == (n, n + m, N) || throw(DimensionMismatch("J must be n x (n+m) x (K*M)"))
+    GC.@preserve J Zs x0 begin
+        rc = ccall((:rdhip_rollout_jacobian, librdhip), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Clonglong, Clonglong, Cint, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   ctx.ptr, handle(fun), rulecode(fun), diffcode(diff), dtypecode(T), K, M, #= RDHIP_TRAJECTORY_MAJOR =# 0,
+                   Zs.data, Zs.t, Zs.dt, x0 === nothing ? C_NULL : pointer(x0), J, HOST)
+    end
+    check(ctx, rc)
+end
+
 # v0.3 spellings (README.md:73-82,128-136; SURVEY.md App. B)
 discrete_jacobian!(::Type{Q}, D::Array{T,3}, model::RD.ContinuousDynamics, Z::PackedTrajectory{n,m,T}) where {Q<:RD.QuadratureRule,n,m,T} =
     RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics{Q}(model), D, nothing, Z)

@@ -77,6 +77,7 @@ _SIGS = {
     "rdhip_state_diff": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "rdhip_nabla_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
+    "rdhip_rollout_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -589,7 +589,7 @@ class CustomModel(ContinuousDynamics):
         self.dynamics_source, self.preamble = str(dynamics), str(preamble)
         self.params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).ravel())
         if liestate is not None:
-            R, P = liestate
+            R, P = (liestate.R, liestate.P) if isinstance(liestate, LieState) else liestate
             self.rotation, self._P = R, tuple(int(v) for v in P)
         else:
             self._P = ()
@@ -1421,6 +1421,43 @@ def rollout_(sig, model, Z, x0=None):
         raise ValueError("x0 dtype does not match the trajectory")
     ctx, space = _resolve_ctx([az, at, adt, a0])
     L.check(L.lib().rdhip_rollout(ctx.handle, cm._handle, rule, az.dtype, K, M, az.ptr, at.ptr, adt.ptr, a0.ptr, space), ctx.handle)
+    return None
+
+
+def rollout_jacobian_(sig, diff, model, J, Z, x0=None, time_major=False):
+    """rollout!(sig, model, Z, x0) followed by jacobian!(sig, diff, model, J[k], y, Z[k]) at every knot point of the simulated
+    trajectories, in ONE call (the forward pass + linearisation of a shooting method).  Z = {"data", "t", "dt"}: a stack of M
+    trajectories of K knot points, (M, K, n+m) / (M, K) or, with time_major=True, (K, M, n+m) / (K, M).  J: (K*M, n, n+m) from
+    alloc_jacobians, in the knot order of Z.  Equivalent to rollout_ + jacobian_ on the flattened stack."""
+    if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+        raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+    cm, rule = _model_rule(model)
+    if rule == L.CONTINUOUS:
+        raise TypeError("rollout! needs a DiscreteDynamics model")
+    if rule == L.IMPLICIT_MIDPOINT:
+        if not isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError(f"Must call jacobian! on an implicit model with the ImplicitFunctionTheorem diff method. Got {type(diff).__name__}.")
+        diff = diff.diff
+    elif isinstance(diff, ImplicitFunctionTheorem):
+        raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
+    data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
+    n, m = state_dim(model), control_dim(model)
+    if len(data3.shape) != 3 or data3.shape[2] != n + m or tuple(t2.shape) != tuple(data3.shape[:2]) or tuple(dt2.shape) != tuple(data3.shape[:2]):
+        raise ValueError("trajectory stack: data (.., .., n+m) with t, dt of the leading two dimensions")
+    K, M = (data3.shape[0], data3.shape[1]) if time_major else (data3.shape[1], data3.shape[0])
+    x0a = x0
+    if x0a is not None and not _is_torch(x0a):
+        x0a = np.ascontiguousarray(np.asarray(x0a, dtype=data3.dtype if isinstance(data3, np.ndarray) else np.float64).reshape(M, -1))
+    if x0a is not None and tuple(x0a.shape) != (M, n):
+        raise ValueError("x0 has the wrong shape")
+    _dense(J, (K * M, n, n + m), "J", transposed_last2=True)
+    az, at, adt, a0 = _Arg(data3, "Z.data"), _Arg(t2, "Z.t"), _Arg(dt2, "Z.dt"), _Arg(x0a, "x0")
+    aj = _Arg(J, "J", az.dtype)
+    if a0.ptr is not None and a0.dtype != az.dtype:
+        raise ValueError("x0 dtype does not match the trajectory")
+    ctx, space = _resolve_ctx([az, at, adt, a0, aj])
+    L.check(L.lib().rdhip_rollout_jacobian(ctx.handle, cm._handle, rule, diff.code, az.dtype, K, M, 1 if time_major else 0,
+                                           az.ptr, at.ptr, adt.ptr, a0.ptr, aj.ptr, space), ctx.handle)
     return None
 
 

@@ -736,6 +736,58 @@ def test_rollout_matches_oracle_and_is_idempotent():
     np.testing.assert_allclose(Zt.data, ref1[0], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("case", ["satellite_tm_large", "satellite_traj_major", "cartpole_tm_large", "quadrotor_tm_host", "custom_tm_large",
+                                  "satellite_implicit_traj_major"])
+def test_rollout_then_jacobians_in_one_call(case):
+    """rdhip_rollout_jacobian = rollout! + jacobian! at every knot of the simulated trajectories, trajectory-major or time-major stacks:
+    the result must be the oracle's rollout followed by the oracle's Jacobians, and later work on the caller's stream must see it."""
+    rng = np.random.default_rng(31)
+    tm = "_tm_" in case
+    if case.startswith("satellite"):
+        model, om, mctl = RD.Satellite(), O.satellite(), 6
+    elif case.startswith("quadrotor"):
+        model, om, mctl = RD.Quadrotor(), O.quadrotor(), 4
+    elif case.startswith("custom"):
+        model, om, mctl = RD.CustomModel(13, 6, dynamics=H.SATELLITE_SRC, params=[1.0, 1.0, 1.0, 1.0], liestate=RD.LieState(RD.QuatRotation, (3, 6))), O.satellite(), 6
+    else:
+        model, om, mctl = RD.Cartpole(), O.cartpole(), 1
+    implicit = "implicit" in case
+    Q, OQ = (RD.ImplicitMidpoint, None) if implicit else (RD.RK4, O.RK4)
+    dm = RD.DiscretizedDynamics(model, Q)
+    M, K = (9000, 11) if "large" in case else (70, 9)
+    n = RD.state_dim(model)
+    data = (H.rand_rigid(rng, M * K, mctl) if n == 13 else rng.random((M * K, 5))).reshape(M, K, n + mctl)
+    t = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy()
+    dt = np.full((M, K), 0.05); dt[:, -1] = 0.0
+    x0 = data[:, 0, :n].copy() * 1.0
+    if n == 13:
+        x0[:, 7:] *= 0.5
+    if implicit:
+        dt[:, -1] = 0.05
+        ref = data.copy(); ref[:, 0, :n] = x0
+        for k in range(1, K):
+            ref[:, k, :n] = om.implicit_midpoint(ref[:, k - 1], t[:, k - 1], dt[:, k - 1], want_jacobian=False)[0]
+        Jref = om.implicit_midpoint(ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1), want_jacobian=True)[1]
+    else:
+        ref = om.rollout(OQ, data, t, dt, X0=x0)
+        Jref = om.jacobian(OQ, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0]
+    order = (1, 0, 2) if tm else (0, 1, 2)
+    dz, tz, dtz = np.ascontiguousarray(data.transpose(order)), np.ascontiguousarray(t.T if tm else t), np.ascontiguousarray(dt.T if tm else dt)
+    on_host = case.endswith("_host")
+    dev = (lambda a: a) if on_host else (lambda a: torch.as_tensor(a).cuda())
+    stack = {"data": dev(dz), "t": dev(tz), "dt": dev(dtz)}
+    J = RD.alloc_jacobians(dm, K * M, stack["data"])
+    diff = RD.ImplicitFunctionTheorem(RD.ForwardAD()) if implicit else RD.ForwardAD()
+    RD.rollout_jacobian_(RD.StaticReturn(), diff, dm, J, stack, dev(x0), time_major=tm)
+    after = None if on_host else J.sum()                  # work queued on the caller's stream right after the call
+    got = host(stack["data"])
+    np.testing.assert_allclose(got.transpose(order) if tm else got, ref, rtol=0, atol=1e-9 if implicit else TOL)
+    Jg = host(J).reshape((K, M) + Jref.shape[1:]).transpose(1, 0, 2, 3) if tm else host(J).reshape((M, K) + Jref.shape[1:])
+    np.testing.assert_allclose(Jg.reshape(Jref.shape), Jref, rtol=0, atol=1e-8 if implicit else TOL)
+    if after is not None:
+        assert abs(float(after) - float(Jref.sum())) <= 1e-6 * max(1.0, abs(float(Jref.sum())))
+
+
 def test_single_knot_point_api_reads_like_the_reference():
     # examples/cartpole.jl:41-57 restated with v0.4 calls (SURVEY App. B)
     model = RD.Cartpole()

@@ -132,16 +132,52 @@ def rollout_case(name, model, M, K, rule, dtype, reps, rng):
     emit(name, M * K, "f64" if T == 8 else "f32", us, M * K * ((n + m) * T + 16 + n * T), {"trajectories": M, "knots": K})
 
 
+def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
+    """forward pass + linearisation: (a) rollout_ then jacobian_ (two calls), (b) rollout_jacobian_ (one call), trajectory- and time-major"""
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    Zn = (rigid_inputs(M * K, m, rng) if n == 13 else rng.random((M * K, n + m))).astype(dtype)
+    fun = RD.DiscretizedDynamics(model, rule)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    alg = M * K * ((n + m) * T + 16 + n * T) + M * K * ((n + m) * T + 16 + n * (n + m) * T)
+    for tm in (False, True):
+        shape = (K, M) if tm else (M, K)
+        data = torch.from_numpy(Zn.reshape(shape + (n + m,))).to(DEV)
+        tk = np.arange(K) * 0.01
+        t = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tk[:, None] if tm else tk[None, :], shape))).to(DEV)
+        dt = torch.full(shape, 0.01, dtype=torch.float64, device=DEV)
+        stack = {"data": data, "t": t, "dt": dt}
+        J = RD.alloc_jacobians(fun, M * K, data)
+        if not tm:
+            flat = RD.PackedTrajectory(n, m, data.reshape(M * K, n + m), t.reshape(-1), dt.reshape(-1))
+
+            def two_calls(i):
+                RD.rollout_(sig, fun, stack)
+                RD.jacobian_(sig, AD, fun, J, None, flat)
+            us = timed(two_calls, reps, warm=2)
+            emit(name + ": rollout_ + jacobian_ (two calls)", M * K, "f64" if T == 8 else "f32", us, alg, {"trajectories": M, "knots": K})
+        us = timed(lambda i: RD.rollout_jacobian_(sig, AD, fun, J, stack, time_major=tm), reps, warm=2)
+        emit(name + (": rollout_jacobian_ time-major" if tm else ": rollout_jacobian_ trajectory-major"), M * K, "f64" if T == 8 else "f32", us, alg,
+             {"trajectories": M, "knots": K})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true", help="also run the N sweep 2^12 .. 2^22 for C2/C3")
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--only", default="", help="run only the rollout+Jacobian cases (value: rolljac)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     rng = np.random.default_rng(7)
     f64, f32 = np.float64, np.float32
     sat, cart, quad = RD.Satellite(), RD.Cartpole(), RD.Quadrotor()
     AD, FD, UD = RD.ForwardAD(), RD.FiniteDifference(), RD.UserDefined()
+    if a.only == "rolljac":
+        rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+        rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
+        rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        rollout_jacobian_case("cartpole RK4 16384 traj x 101 knots", cart, 16384, 101, RD.RK4, f64, 10, rng)
+        return
 
     # C2: Cartpole RK4 discrete Jacobian, N = 4096
     jac_case("C2 cartpole RK4 jacobian ForwardAD", cart, rng.random((4096, 5)), RD.RK4, AD, f64, a.reps)
@@ -170,6 +206,9 @@ def main():
     rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("C5 cartpole RK4 rollout fp32 512 traj x 256 knots", cart, 512, 256, RD.RK4, f32, 10, rng)
     rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+    rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+    rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
+    rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
     # ImplicitMidpoint: Newton solve and IFT Jacobian (compute / LDS-latency bound)
     dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
     Zi = RD.PackedTrajectory(13, 6, Zs, np.arange(65536) * 0.1, np.full(65536, 0.1)).to(DEV)
