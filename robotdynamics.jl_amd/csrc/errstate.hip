@@ -63,20 +63,34 @@ __global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long
     const long long k0 = (long long)blockIdx.x * TK;
     const int nk = (int)((N - k0) < TK ? (N - k0) : TK);
     const int total = nk * per;                              // elements of this tile (TK*per is a multiple of VN: TK = 64)
+    // the lane's quaternions (and nablaG's xbar parts) are requested first: their latency hides under the zero fill
+    T qv[4][4], bv[4][4];
+    const bool owner = threadIdx.x < nk;
+    {
+        const T* x = X + (k0 + (owner ? threadIdx.x : 0)) * ldx;
+        const T* xb = MODE == 1 ? Xb + (k0 + (owner ? threadIdx.x : 0)) * ldxb : nullptr;
+#pragma unroll
+        for (int rot = 0; rot < 4; ++rot) {
+            const int r0 = rot < d.nrot ? d.rot_row0[rot] : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { qv[rot][i] = (owner && rot < d.nrot) ? x[r0 + i] : T(1); bv[rot][i] = (MODE == 1 && owner && rot < d.nrot) ? xb[r0 + i] : T(0); }
+        }
+    }
     V zero;
 #pragma unroll
     for (int q = 0; q < VN; ++q) zero[q] = T(0);
     for (int i = threadIdx.x * VN; i < TK * per; i += 256 * VN) *reinterpret_cast<V*>(tile + i) = zero;
     __syncthreads();
-    if (threadIdx.x < nk) {
+    if (owner) {
         T* g = tile + threadIdx.x * per;
-        const T* x = X + (k0 + threadIdx.x) * ldx;
         if (MODE == 0) {
             for (int r = 0; r < d.n; ++r) if (d.row_kind[r] == 0) g[r + d.row_col[r] * d.n] = T(1);
         }
-        for (int rot = 0; rot < d.nrot; ++rot) {
+#pragma unroll
+        for (int rot = 0; rot < 4; ++rot) {
+            if (rot >= d.nrot) break;
             const int r0 = d.rot_row0[rot], c0 = d.rot_col0[rot];
-            const T q0 = x[r0], q1 = x[r0 + 1], q2 = x[r0 + 2], q3 = x[r0 + 3];
+            const T q0 = qv[rot][0], q1 = qv[rot][1], q2 = qv[rot][2], q3 = qv[rot][3];
             const T inv = rsqrt_<T>(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
             if (MODE == 0) {
                 const T a = q0 * inv, b = q1 * inv, c = q2 * inv, e = q3 * inv;      // L(q) H, q normalised (QuatRotation constructor)
@@ -85,8 +99,7 @@ __global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long
                 g0[0] = -c; g0[1] = -e; g0[2] = a;  g0[3] = b;   g0 += d.n;
                 g0[0] = -e; g0[1] = c;  g0[2] = -b; g0[3] = a;
             } else {
-                const T* bq = Xb + (k0 + threadIdx.x) * ldxb + r0;
-                const T val = -((q0 * bq[0] + q1 * bq[1] + q2 * bq[2] + q3 * bq[3]) * inv);
+                const T val = -((q0 * bv[rot][0] + q1 * bv[rot][1] + q2 * bv[rot][2] + q3 * bv[rot][3]) * inv);
                 for (int j = 0; j < 3; ++j) g[(c0 + j) * (d.e + 1)] = val;
             }
         }
