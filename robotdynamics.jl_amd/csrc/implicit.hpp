@@ -42,22 +42,37 @@ template <class Mdl, class T> struct ImplicitOps {
             fill_cols<C + 1>(m, xm, u, h, A, f);
         }
     }
-    // in-place LU with partial pivoting of the lane's matrix; pivots into piv[0..NX)
-    static RD_DEV void lu(T* A, int* piv) {
-        for (int i = 0; i < NX; ++i) piv[i] = i;
-#pragma unroll 1
-        for (int k = 0; k < NX; ++k) {
-            int p = k; T best = A[k + k * NX]; best = best < T(0) ? -best : best;
-            for (int i = k + 1; i < NX; ++i) { T v = A[i + k * NX]; v = v < T(0) ? -v : v; if (v > best) { best = v; p = i; } }
-            { const int tmp = piv[k]; piv[k] = piv[p]; piv[p] = tmp; }   // piv[] holds the row permutation: row i of P*A is row piv[i] of A
-            if (p != k) for (int j = 0; j < NX; ++j) { const T a = A[k + j * NX], b = A[p + j * NX]; A[k + j * NX] = b; A[p + j * NX] = a; }
-            const T inv = T(1) / A[k + k * NX];
-            for (int i = k + 1; i < NX; ++i) {
-                const T l = A[i + k * NX] * inv;
-                A[i + k * NX] = l;
-                for (int j = k + 1; j < NX; ++j) A[i + j * NX] -= l * A[k + j * NX];
+    // in-place LU with partial pivoting of the lane's matrix; pivots into piv[0..NX).  Fully unrolled over the elimination step K: only
+    // the pivot row index p is a run-time (per-lane) LDS address; the pivot row and column live in registers during the step, so the
+    // update costs two LDS operations per FMA, all independent of each other (the run-time-indexed triple loop was LDS-latency-bound).
+    template <int K> static RD_DEV void lu_step(T* A, int* piv) {
+        if constexpr (K < NX) {
+            T ck[NX];                                            // column K from row K down
+#pragma unroll
+            for (int i = K; i < NX; ++i) ck[i] = A[i + K * NX];
+            int p = K; T best = ck[K] < T(0) ? -ck[K] : ck[K];
+#pragma unroll
+            for (int i = K + 1; i < NX; ++i) { const T v = ck[i] < T(0) ? -ck[i] : ck[i]; if (v > best) { best = v; p = i; } }
+            { const int tmp = piv[K]; piv[K] = piv[p]; piv[p] = tmp; }   // piv[] holds the row permutation: row i of P*A is row piv[i] of A
+            // swap rows K and p (all columns: the stored multipliers move with their rows); the new row K stays in registers
+            T rk[NX];
+#pragma unroll
+            for (int jj = 0; jj < NX; ++jj) { const T a = A[K + jj * NX], b = A[p + jj * NX]; A[K + jj * NX] = b; A[p + jj * NX] = a; rk[jj] = b; }
+            const T inv = T(1) / rk[K];
+#pragma unroll
+            for (int i = K + 1; i < NX; ++i) {
+                const T l = A[i + K * NX] * inv;               // (re-read: row p's entry moved to row K's old place)
+                A[i + K * NX] = l;
+#pragma unroll
+                for (int jj = K + 1; jj < NX; ++jj) A[i + jj * NX] -= l * rk[jj];
             }
+            lu_step<K + 1>(A, piv);
         }
+    }
+    static RD_DEV void lu(T* A, int* piv) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) piv[i] = i;
+        lu_step<0>(A, piv);
     }
     // b <- A^{-1} b with the factors above; b in registers (compile-time indices).  The row permutation is applied through the
     // lane's LDS staging vector: a select chain on registers is turned into a dynamically indexed private array (scratch memory).
