@@ -180,21 +180,22 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     }
     constexpr size_t lds = ImplicitLds<Mdl, T>::BYTES;
     static_assert(lds <= 160 * 1024, "Newton matrices do not fit the LDS of a CU");
+    const unsigned gridn = (unsigned)((a.N + ImplicitLds<Mdl, T>::KP - 1) / ImplicitLds<Mdl, T>::KP);     // Newton kernels: KP knot points per wave
     if (mode == 3) {          // rollout: a.N trajectories of a.K knot points
         if (a.K == 0) return RDHIP_OK;
         auto kern = implicit_rollout_kernel<Mdl, T>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol);
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol);
     } else {
         auto kern = implicit_midpoint_kernel<Mdl, T, false>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol);
     }
     return hip_status(hipGetLastError());
 }

@@ -15,7 +15,17 @@ namespace rd {
 template <class Mdl, class T> struct ImplicitLds {
     static constexpr int NX = Mdl::NX;
     static constexpr int RSA = (NX * NX + NX) | 1;                  // per-lane stride (elements): the matrix + one right-hand side
-    static constexpr size_t BYTES = (size_t)TILE * RSA * sizeof(T) + (size_t)TILE * 16 * sizeof(int);   // + pivots
+    static constexpr size_t LANE_BYTES = (size_t)RSA * sizeof(T) + 16 * sizeof(int);   // + pivots
+    // knot points per wave: a wave runs on one SIMD and is latency-bound, so what counts is how many knot points are resident per
+    // CU.  When 64 lanes' matrices allow only one wave per CU (n = 13 in fp64: 93 KB), waves of KP < 64 knot points that fit TWO per CU
+    // (on two SIMDs) hold 1.6x more knot points in flight; lanes >= KP idle.
+    static constexpr int knots_per_wave() {
+        if (2 * TILE * LANE_BYTES <= 160 * 1024) return TILE;
+        const int kp = (int)((80 * 1024) / LANE_BYTES);
+        return kp < TILE ? (kp < 1 ? 1 : kp) : TILE;
+    }
+    static constexpr int KP = knots_per_wave();
+    static constexpr size_t BYTES = (size_t)KP * LANE_BYTES;
 };
 
 template <class Mdl, class T> struct ImplicitOps {
@@ -119,10 +129,11 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x >= L::KP) return;                                    // lanes without a matrix slot stay idle
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
-    int* piv = reinterpret_cast<int*>(smem + (size_t)TILE * L::RSA * sizeof(T)) + lane * 16;
-    const long long k = (long long)blockIdx.x * TILE + lane;
+    int* piv = reinterpret_cast<int*>(smem + (size_t)L::KP * L::RSA * sizeof(T)) + lane * 16;
+    const long long k = (long long)blockIdx.x * L::KP + lane;
     const bool active = k < N;
     const long long kc = active ? k : N - 1;
     const double hd = dtt[kc];
@@ -198,10 +209,11 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x >= L::KP) return;
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
-    int* piv = reinterpret_cast<int*>(smem + (size_t)TILE * L::RSA * sizeof(T)) + lane * 16;
-    const long long j = (long long)blockIdx.x * TILE + lane;
+    int* piv = reinterpret_cast<int*>(smem + (size_t)L::KP * L::RSA * sizeof(T)) + lane * 16;
+    const long long j = (long long)blockIdx.x * L::KP + lane;
     const bool active = j < M;
     const long long jc = active ? j : M - 1;
     T* Zj = Z + jc * K * NZ;

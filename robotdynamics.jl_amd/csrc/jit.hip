@@ -26,7 +26,7 @@
 
 namespace rd {
 
-struct JitKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; size_t lds = 0; int block = 0; bool persistent = false; bool small = false; };
+struct JitKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; size_t lds = 0; int block = 0; int knots = 64; bool persistent = false; bool small = false; };
 struct JitModel {
     int n = 0, m = 0, np = 0;
     std::string name, body, preamble;
@@ -139,7 +139,12 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
         else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR) jk.block = 64;
-        else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) { jk.block = 64; jk.lds = (size_t)64 * ((ny * ny + ny) | 1) * ts + (size_t)64 * 16 * 4; }     // ImplicitLds<Mdl,T>::BYTES
+        else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
+            const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
+            int kp = 64;
+            if (2 * 64 * lane_bytes > 160 * 1024) { kp = (int)((80 * 1024) / lane_bytes); if (kp > 64) kp = 64; if (kp < 1) kp = 1; }
+            jk.block = 64; jk.knots = kp; jk.lds = (size_t)kp * lane_bytes;
+        }
         else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
@@ -269,7 +274,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N, K = a.K; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* Y = a.Y; void* J = a.J; void* J2 = a.J2; const void* X0 = a.X0;
     int iters = a.newton_iters; double tol = a.newton_tol; void* nul = nullptr;
-    const unsigned grid = (unsigned)((N + 63) / 64);
+    const unsigned grid = (unsigned)(mode == 2 ? (N + 63) / 64 : (N + k->knots - 1) / k->knots);
     if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
     if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol}; return launch(M, k, grid, a.stream, args); }
     void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol};
