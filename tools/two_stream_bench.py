@@ -15,7 +15,7 @@ import rdhip as RD  # noqa: E402
 from tools.bench_configs import rigid_inputs  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-reps = 400
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 rng = np.random.default_rng(0)
 sat = RD.Satellite()
 dm = RD.DiscretizedDynamics(sat, RD.RK4)
