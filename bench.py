@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gather", choices=["none", "all", "root"], default="all", help="also time the RCCL exchange of the stacked Jacobians (N>1 only; reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="N=1 only: also report independent batches issued round-robin on this many streams (extra object, never `value`); 1 = skip")
+    ap.add_argument("--streams", type=int, default=1, help="N=1 only, opt-in: also report independent batches issued round-robin on this many streams (extra object, never `value`)")
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
