@@ -151,24 +151,80 @@ def _rule_code(Q):
     raise ValueError(f"not a QuadratureRule: {Q!r}")
 
 
-# rotation parameterisations (Rotations.jl types, only as tags)
-class QuatRotation:
+# rotation parameterisations (Rotations.jl types): the class is the tag the kernels are selected by; an instance is a host-side
+# value with the conversions the state helpers need (quaternion <-> MRP p = v/(1+w) <-> Rodrigues parameter g = v/w)
+class _Rotation:
+    def params(self):
+        return self._p.copy()
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(repr(float(v)) for v in self._p)})"
+
+
+class QuatRotation(_Rotation):
+    """QuatRotation(w, x, y, z, normalize=True) or QuatRotation(other_rotation)."""
     code, nparams = L.ROT_QUAT, 4
+
+    def __init__(self, *a):
+        if len(a) == 1 and isinstance(a[0], _Rotation):
+            self._p = a[0].quat()
+            return
+        normalize = True
+        if len(a) == 5:
+            a, normalize = a[:4], bool(a[4])
+        elif len(a) == 2 and np.ndim(a[0]) == 1:
+            a, normalize = tuple(a[0]), bool(a[1])
+        elif len(a) == 1:
+            a = tuple(a[0])
+        if len(a) != 4:
+            raise TypeError("QuatRotation(w, x, y, z[, normalize])")
+        q = np.array(a, dtype=np.float64)
+        self._p = q / np.linalg.norm(q) if normalize else q
+
+    def quat(self):
+        return self._p.copy()
 
 
 UnitQuaternion = QuatRotation   # pre-1.0 Rotations.jl name
 
 
-class MRP:
+class MRP(_Rotation):
     code, nparams = L.ROT_MRP, 3
 
+    def __init__(self, *a):
+        if len(a) == 1 and isinstance(a[0], _Rotation):
+            q = a[0].quat(); q = q / np.linalg.norm(q)
+            self._p = q[1:] / (1.0 + q[0])
+            return
+        a = tuple(a[0]) if len(a) == 1 else a
+        if len(a) != 3:
+            raise TypeError("MRP(x, y, z)")
+        self._p = np.array(a, dtype=np.float64)
 
-class RodriguesParam:
+    def quat(self):
+        n2 = float(self._p @ self._p)
+        return np.concatenate([[1.0 - n2], 2.0 * self._p]) / (1.0 + n2)
+
+
+class RodriguesParam(_Rotation):
     code, nparams = L.ROT_RP, 3
 
+    def __init__(self, *a):
+        if len(a) == 1 and isinstance(a[0], _Rotation):
+            q = a[0].quat()
+            self._p = q[1:] / q[0]
+            return
+        a = tuple(a[0]) if len(a) == 1 else a
+        if len(a) != 3:
+            raise TypeError("RodriguesParam(x, y, z)")
+        self._p = np.array(a, dtype=np.float64)
 
-def params(R):   # Rotations.params(::Type) as extended at src/liestate.jl:42-46
-    return R.nparams
+    def quat(self):
+        return np.concatenate([[1.0], self._p]) / np.sqrt(1.0 + float(self._p @ self._p))
+
+
+def params(R):   # Rotations.params(::Type) as extended at src/liestate.jl:42-46; Rotations.params(rotation) for a value
+    return R.params() if isinstance(R, _Rotation) else R.nparams
 
 
 # =============================================================================================================
@@ -817,6 +873,81 @@ def gen_inds(model):
     ln = (C.c_int * 5)()
     L.check(L.lib().rdhip_model_gen_inds(_cm(model)._handle, first, ln))
     return {k: range(first[i], first[i] + ln[i]) for i, k in enumerate(("r", "q", "v", "w", "u"))}
+
+
+def _ix(r):     # 1-based Julia range -> numpy slice
+    return slice(r.start - 1, r.stop - 1)
+
+
+def position(model, x):               # src/rigidbody.jl:97
+    return np.asarray(x)[_ix(gen_inds(model)["r"])]
+
+
+def linear_velocity(model, x):        # src/rigidbody.jl:98
+    return np.asarray(x)[_ix(gen_inds(model)["v"])]
+
+
+def angular_velocity(model, x):       # src/rigidbody.jl:99
+    return np.asarray(x)[_ix(gen_inds(model)["w"])]
+
+
+def orientation(model, x, renorm=False):   # src/rigidbody.jl:101-108
+    R = rotation_type(model)
+    q = np.asarray(x, dtype=np.float64)[_ix(gen_inds(model)["q"])]
+    return R(*q, renorm) if R is QuatRotation else R(*q)
+
+
+def flipquat(model, x):               # src/rigidbody.jl:115-118
+    if rotation_type(model) is not QuatRotation:
+        raise TypeError("flipquat is defined for RigidBody{<:QuatRotation}")
+    y = np.array(x, copy=True)
+    y[3:7] = -y[3:7]
+    return y
+
+
+def parse_state(model, x, renorm=False):   # src/rigidbody.jl:127-133
+    return position(model, x), orientation(model, x, renorm), linear_velocity(model, x), angular_velocity(model, x)
+
+
+def build_state(model, *args):        # src/rigidbody.jl:161-199
+    """build_state(model, r, q, v, w) with q a rotation value (converted to the model's rotation type) or a parameter vector of the
+    model's rotation (taken as is, like the reference: no renormalisation); build_state(model, x) with a 13-vector [r; quat; v; w]."""
+    R = rotation_type(model)
+    if len(args) == 1:
+        x = np.asarray(args[0], dtype=np.float64)
+        if x.shape != (13,):
+            raise ValueError("build_state(model, x): x is [r; q; v; w] with a quaternion (13 entries)")
+        r, q, v, w = x[0:3], QuatRotation(*x[3:7], False), x[7:10], x[10:13]
+    elif len(args) == 4:
+        r, q, v, w = args
+    else:
+        raise TypeError("build_state(model, r, q, v, w) or build_state(model, x)")
+    if isinstance(q, _Rotation):
+        qp = q.params() if type(q) is R else R(q).params()
+    else:
+        qp = np.asarray(q, dtype=np.float64)
+        if qp.shape == (4,) and R is not QuatRotation:      # a quaternion given as a vector (RBState(r, q_, v, w)): convert
+            qp = R(QuatRotation(*qp, False)).params()
+        if qp.shape != (R.nparams,):
+            raise AssertionError(f"length(q) == {R.nparams}")
+    return np.concatenate([np.asarray(r, dtype=np.float64), qp, np.asarray(v, dtype=np.float64), np.asarray(w, dtype=np.float64)])
+
+
+def fill_state(model, x, q, v, w):    # src/rigidbody.jl:201-207
+    nq = rotation_type(model).nparams
+    return np.array([x] * 3 + [q] * nq + [v] * 3 + [w] * 3)
+
+
+def vec_states(s, x):                 # src/liestate.jl:142-151
+    s = s if isinstance(s, LieState) else LieState(s)
+    x = np.asarray(x)
+    return tuple(x[_ix(vec_inds(s, i))] for i in range(1, len(s.P) + 1))
+
+
+def rot_states(s, x):                 # src/liestate.jl:160-173 (quaternions are NOT renormalised)
+    s = s if isinstance(s, LieState) else LieState(s)
+    x = np.asarray(x, dtype=np.float64)
+    return tuple(s.R(*x[_ix(rot_inds(s, i))], False) if s.R is QuatRotation else s.R(*x[_ix(rot_inds(s, i))]) for i in range(1, len(s.P)))
 
 
 class LieState:
