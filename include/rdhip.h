@@ -88,6 +88,17 @@ const char* rdhip_last_error(rdhip_ctx* ctx);
 /* HIP-event stopwatch on the context's stream (for hosts without their own event API) */
 int rdhip_timer_start(rdhip_ctx* ctx);
 int rdhip_timer_stop(rdhip_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+/* HIP graphs.  A batch of a few thousand knot points is launch-bound (an MI355X kernel launch costs more than streaming its output), and a
+ * solver iteration issues the same few calls on the same arrays every time: record them once, replay them with one launch.
+ *   rdhip_graph_begin_capture(ctx); <any RDHIP_DEVICE calls on ctx: they are recorded, not executed>; rdhip_graph_end_capture(ctx, &g);
+ *   rdhip_graph_launch(ctx, g) enqueues the whole sequence on the context's stream (array CONTENTS may change between launches,
+ *   addresses and sizes may not).  Run every call once before capturing (first use sets kernel attributes, JIT-compiles custom models
+ *   and grows workspaces -- none of that can happen inside a capture).  RDHIP_HOST calls are refused while capturing. */
+typedef struct rdhip_graph rdhip_graph;
+int rdhip_graph_begin_capture(rdhip_ctx* ctx);
+int rdhip_graph_end_capture(rdhip_ctx* ctx, rdhip_graph** out);
+int rdhip_graph_launch(rdhip_ctx* ctx, rdhip_graph* graph);
+int rdhip_graph_destroy(rdhip_graph* graph);
 /* device memory helpers for hosts that do not own a device allocator (the Julia wrapper) */
 int rdhip_malloc(rdhip_ctx* ctx, void** ptr, unsigned long long bytes);
 int rdhip_free(rdhip_ctx* ctx, void* ptr);

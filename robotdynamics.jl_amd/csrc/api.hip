@@ -19,6 +19,7 @@ struct rdhip_ctx {
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
+    bool capturing = false;               // between rdhip_graph_begin_capture and rdhip_graph_end_capture
     std::string err;
     // grow-only device workspace slots for RDHIP_HOST staging
     void* ws[8];
@@ -109,6 +110,45 @@ int rdhip_ctx_synchronize(rdhip_ctx* c) {
 }
 void* rdhip_ctx_stream(rdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 const char* rdhip_last_error(rdhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+// ---- HIP graphs: record a sequence of device-memory calls once, replay it with one launch (small batches are launch-bound) ----
+struct rdhip_graph { hipGraph_t graph; hipGraphExec_t exec; int device; };
+int rdhip_graph_begin_capture(rdhip_ctx* c) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_begin_capture: the context is already capturing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return RDHIP_OK;
+}
+int rdhip_graph_end_capture(rdhip_ctx* c, rdhip_graph** out) {
+    if (!c || !out) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (!c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_end_capture: the context is not capturing");
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (e != hipSuccess || !g) { (void)hipGetLastError(); return fail(c, RDHIP_ERR_HIP, "hipStreamEndCapture failed: %s (a call inside the capture was not capturable)", hipGetErrorString(e)); }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail(c, RDHIP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    rdhip_graph* G = new (std::nothrow) rdhip_graph{g, x, c->device};
+    if (!G) { (void)hipGraphExecDestroy(x); (void)hipGraphDestroy(g); return fail(c, RDHIP_ERR_HIP, "out of host memory"); }
+    *out = G; return RDHIP_OK;
+}
+int rdhip_graph_launch(rdhip_ctx* c, rdhip_graph* g) {
+    if (!c || !g) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_launch: the context is capturing");
+    if (g->device != c->device) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_launch: the graph was captured on device %d, the context is on device %d", g->device, c->device);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipGraphLaunch(g->exec, c->stream));
+    return RDHIP_OK;
+}
+int rdhip_graph_destroy(rdhip_graph* g) {
+    if (!g) return RDHIP_OK;
+    (void)hipGraphExecDestroy(g->exec); (void)hipGraphDestroy(g->graph);
+    delete g; return RDHIP_OK;
+}
+
 int rdhip_timer_start(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream)); return RDHIP_OK;
@@ -295,6 +335,7 @@ static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long
     if (dtype != RDHIP_F64 && dtype != RDHIP_F32) return fail(c, RDHIP_ERR_INVALID_ARG, "bad dtype %d", dtype);
     if (N < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "negative N");
     if (memspace != RDHIP_DEVICE && memspace != RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "bad memspace %d", memspace);
+    if (c->capturing && memspace == RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "host-memory calls copy and synchronise: they cannot be captured into a graph");
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
     return RDHIP_OK;

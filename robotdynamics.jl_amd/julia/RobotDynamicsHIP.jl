@@ -257,6 +257,26 @@ function rollout_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.
     check(ctx, rc)
 end
 
+# HIP graphs: record the device-memory calls of one solver iteration once, replay them with one launch (small batches are launch-bound).
+#   g = capture(ctx) do ... batched calls on device arrays ... end ;  launch(ctx, g)
+mutable struct Graph
+    ptr::Ptr{Cvoid}
+end
+function capture(f::Function, ctx::Context)
+    check(ctx, ccall((:rdhip_graph_begin_capture, librdhip), Cint, (Ptr{Cvoid},), ctx.ptr))
+    try
+        f()
+    finally
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:rdhip_graph_end_capture, librdhip), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.ptr, out)
+        check(ctx, rc)
+        g = Graph(out[])
+        finalizer(x -> ccall((:rdhip_graph_destroy, librdhip), Cint, (Ptr{Cvoid},), x.ptr), g)
+        return g
+    end
+end
+launch(ctx::Context, g::Graph) = check(ctx, ccall((:rdhip_graph_launch, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, g.ptr))
+
 # v0.3 spellings (README.md:73-82,128-136; SURVEY.md App. B)
 discrete_jacobian!(::Type{Q}, D::Array{T,3}, model::RD.ContinuousDynamics, Z::PackedTrajectory{n,m,T}) where {Q<:RD.QuadratureRule,n,m,T} =
     RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics{Q}(model), D, nothing, Z)

@@ -76,6 +76,10 @@ _SIGS = {
     "rdhip_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rdhip_state_diff": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "rdhip_nabla_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "rdhip_graph_begin_capture": (C.c_int, [_P]),
+    "rdhip_graph_end_capture": (C.c_int, [_P, C.POINTER(_P)]),
+    "rdhip_graph_launch": (C.c_int, [_P, _P]),
+    "rdhip_graph_destroy": (C.c_int, [_P]),
     "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_rollout_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
 }
@@ -145,9 +149,39 @@ class Context:
         check(lib().rdhip_timer_stop(self.handle, C.byref(ms)), self.handle)
         return ms.value
 
+    def begin_capture(self):
+        """Record the following device-memory calls on this context into a HIP graph instead of executing them."""
+        check(lib().rdhip_graph_begin_capture(self.handle), self.handle)
+
+    def end_capture(self):
+        g = _P()
+        check(lib().rdhip_graph_end_capture(self.handle, C.byref(g)), self.handle)
+        return Graph(g)
+
+    def launch(self, graph):
+        check(lib().rdhip_graph_launch(self.handle, graph.handle), self.handle)
+
     def close(self):
         if getattr(self, "handle", None):
             lib().rdhip_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Graph:
+    """A captured sequence of calls (rdhip_graph); replay with Context.launch(graph)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rdhip_graph_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

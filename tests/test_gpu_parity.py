@@ -321,6 +321,53 @@ def test_device_calls_can_be_captured_in_a_hip_graph():
         np.testing.assert_allclose(host(E), om.error_expansion(O.RK4, Zh, t, dt)[0], rtol=0, atol=TOL)
 
 
+def test_c_abi_graph_capture_and_replay():
+    """rdhip_graph_begin_capture / end_capture / launch on a context that owns its stream (what a Julia host without a HIP API uses):
+    the captured sequence (RK4 Jacobians + x_next, discrete dynamics, error-state Jacobians) replays with one launch and follows
+    in-place changes of the inputs; host-memory calls are refused while capturing."""
+    from rdhip import _lib as L
+    rng = np.random.default_rng(28)
+    N = 300
+    model, om = RD.Satellite(), O.satellite()
+    Zn, t, dt = H.rand_rigid(rng, N, 6), np.arange(N) * 0.1, np.full(N, 0.1)
+    Z = traj(model, Zn, t, dt, "cuda")
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y, X2 = torch.empty((N, 13), dtype=torch.float64, device="cuda"), torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    G = RD.alloc_errstate_jacobians(model, N, Z.data)
+    ctx = L.Context(0)                                   # owns a non-blocking stream
+    lib = L.lib()
+    ptrs = (Z.data.data_ptr(), Z.t.data_ptr(), Z.dt.data_ptr())
+
+    def sequence():
+        L.check(lib.rdhip_jacobian(ctx.handle, model._handle, L.RK4, L.FORWARD_AD, L.F64, N, *ptrs, J.data_ptr(), Y.data_ptr(), L.DEVICE), ctx.handle)
+        L.check(lib.rdhip_discrete_dynamics(ctx.handle, model._handle, L.RK4, L.F64, N, *ptrs, X2.data_ptr(), L.DEVICE), ctx.handle)
+        L.check(lib.rdhip_errstate_jacobian(ctx.handle, model._handle, L.F64, N, Z.data.data_ptr(), 19, 1, G.data_ptr(), L.DEVICE), ctx.handle)
+    torch.cuda.synchronize()
+    sequence(); ctx.synchronize()                       # first use outside the capture
+    ctx.begin_capture()
+    sequence()
+    with pytest.raises(ValueError):                     # a host-memory call cannot be captured
+        RDh = np.empty((N, 13))
+        L.check(lib.rdhip_discrete_dynamics(ctx.handle, model._handle, L.RK4, L.F64, N, Zn.ctypes.data, t.ctypes.data, dt.ctypes.data, RDh.ctypes.data, L.HOST), ctx.handle)
+    graph = ctx.end_capture()
+    for scale in (1.0, 0.25):
+        Z.data[:, 7:].mul_(scale)
+        J.zero_(); Y.zero_(); X2.zero_(); G.zero_()
+        torch.cuda.synchronize()
+        ctx.launch(graph); ctx.launch(graph)            # replays are idempotent
+        ctx.synchronize()
+        Zh = host(Z.data)
+        Jr, Yr = om.jacobian(O.RK4, O.FORWARD_AD, Zh, t, dt)
+        np.testing.assert_allclose(host(J), Jr, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(Y), Yr, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(X2), Yr, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(G), om.errstate_jacobian(Zh[:, :13]), rtol=0, atol=TOL)
+    with pytest.raises(ValueError):
+        ctx.end_capture()                               # not capturing
+    graph.close(); ctx.close()
+
+
 @pytest.mark.parametrize("where", ["host", "cuda"])
 def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
     """state_diff(s::LieState, x, x0) on raw rand(n) vectors, as test/liestate.jl:33-51 (QuatRotation, P = (3,2,3)) and :56-68
