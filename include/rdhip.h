@@ -231,6 +231,21 @@ int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype,
 int rdhip_rollout_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long K, long long M, int layout,
                            void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace);
 
+/* ---- several GPUs in ONE process (hosts without torch.distributed / RCCL, e.g. the Julia wrapper) ----
+ * The multi-GPU layout of this library is one context per device and contiguous blocks of knot points per device (knot points are
+ * independent: no data-path collective).  rdhip_shard_range: block i of nshards = [begin, begin + count), ceil(N / nshards) knot points
+ * each, the last blocks short or empty.
+ * rdhip_jacobian_sharded: rdhip_jacobian on HOST arrays of the whole batch, block i on ctxs[i], all blocks concurrently (one host
+ * thread per context inside the call); the stacked result is complete in host memory when the call returns ("gather to the host").
+ * Several contexts may sit on the same device.  Returns the first non-zero status; its message is in that context and in
+ * rdhip_last_error(NULL).
+ * rdhip_memcpy_peer: device-to-device copy between two contexts' devices over xGMI (to stack device-resident shards on one GPU):
+ * ordered after the work already queued on src_ctx's stream, executed on dst_ctx's stream, asynchronous. */
+int rdhip_shard_range(long long N, int nshards, int i, long long* begin, long long* count);
+int rdhip_jacobian_sharded(rdhip_ctx* const* ctxs, int nctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
+                           const void* Z, const double* t, const double* dt, void* J, void* Y);
+int rdhip_memcpy_peer(rdhip_ctx* dst_ctx, void* dst, rdhip_ctx* src_ctx, const void* src, unsigned long long bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -628,6 +629,52 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     int k = kernel_status(c, implicit ? family_implicit(d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
     if (!k) k = kernel_status(c, implicit ? family_implicit(d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
+
+// ---- several GPUs in ONE process (hosts without torch.distributed / RCCL) --------------------------------------------------------
+int rdhip_shard_range(long long N, int nshards, int i, long long* begin, long long* count) {
+    if (N < 0 || nshards <= 0 || i < 0 || i >= nshards || !begin || !count) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_shard_range: bad arguments");
+    const long long per = (N + nshards - 1) / nshards;
+    const long long lo = (long long)i * per < N ? (long long)i * per : N;
+    const long long hi = lo + per < N ? lo + per : N;
+    *begin = lo; *count = hi - lo;
+    return RDHIP_OK;
+}
+int rdhip_jacobian_sharded(rdhip_ctx* const* ctxs, int nctx, const rdhip_model* M, int rule, int diff, int dtype, long long N,
+                           const void* Z, const double* t, const double* dt, void* J, void* Y) {
+    if (!ctxs || nctx <= 0) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_jacobian_sharded: no contexts");
+    for (int i = 0; i < nctx; ++i) {
+        if (!ctxs[i]) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_jacobian_sharded: context %d is NULL", i);
+        for (int k = 0; k < i; ++k) if (ctxs[k] == ctxs[i]) return fail(ctxs[i], RDHIP_ERR_INVALID_ARG, "rdhip_jacobian_sharded: context %d is listed twice (a context serves one host thread)", i);
+    }
+    if (!M) return fail(ctxs[0], RDHIP_ERR_INVALID_ARG, "model is NULL");
+    if (dtype != RDHIP_F64 && dtype != RDHIP_F32) return fail(ctxs[0], RDHIP_ERR_INVALID_ARG, "bad dtype %d", dtype);
+    if (N < 0) return fail(ctxs[0], RDHIP_ERR_INVALID_ARG, "negative N");
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int n = M->d.n, nz = M->d.n + M->d.m;
+    std::vector<int> rcs(nctx, RDHIP_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nctx; ++i) {
+        long long lo = 0, cnt = 0; rdhip_shard_range(N, nctx, i, &lo, &cnt);
+        th.emplace_back([=, &rcs]() {
+            rcs[i] = rdhip_jacobian(ctxs[i], M, rule, diff, dtype, cnt, Z ? (const char*)Z + (size_t)lo * nz * ts : nullptr, t ? t + lo : nullptr, dt ? dt + lo : nullptr,
+                                    J ? (char*)J + (size_t)lo * n * nz * ts : nullptr, Y ? (char*)Y + (size_t)lo * n * ts : nullptr, RDHIP_HOST);
+        });
+    }
+    for (auto& x : th) x.join();
+    for (int i = 0; i < nctx; ++i) if (rcs[i]) { g_err = ctxs[i]->err; return rcs[i]; }     // also readable through rdhip_last_error(NULL)
+    return RDHIP_OK;
+}
+int rdhip_memcpy_peer(rdhip_ctx* dc, void* dst, rdhip_ctx* sc, const void* src, unsigned long long bytes) {
+    if (!dc || !sc) return fail(dc ? dc : sc, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (bytes == 0) return RDHIP_OK;
+    if (!dst || !src) return fail(dc, RDHIP_ERR_INVALID_ARG, "rdhip_memcpy_peer: NULL pointer");
+    // order after the producer's stream, run on the consumer's stream
+    HIP_TRY(sc, hipSetDevice(sc->device));
+    HIP_TRY(sc, hipEventRecord(sc->ev1, sc->stream));
+    HIP_TRY(dc, hipSetDevice(dc->device));
+    HIP_TRY(dc, hipStreamWaitEvent(dc->stream, sc->ev1, 0));
+    HIP_TRY(dc, hipMemcpyPeerAsync(dst, dc->device, src, sc->device, bytes, dc->stream));
+    return RDHIP_OK;
 }
 
 }  // extern "C"

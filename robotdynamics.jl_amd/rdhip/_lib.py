@@ -80,6 +80,9 @@ _SIGS = {
     "rdhip_graph_end_capture": (C.c_int, [_P, C.POINTER(_P)]),
     "rdhip_graph_launch": (C.c_int, [_P, _P]),
     "rdhip_graph_destroy": (C.c_int, [_P]),
+    "rdhip_shard_range": (C.c_int, [_LL, C.c_int, C.c_int, C.POINTER(_LL), C.POINTER(_LL)]),
+    "rdhip_jacobian_sharded": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P]),
+    "rdhip_memcpy_peer": (C.c_int, [_P, _P, _P, _P, C.c_ulonglong]),
     "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_rollout_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
 }

@@ -1265,6 +1265,47 @@ def jacobian_(*args):
     return None
 
 
+_shard_ctx = {}
+
+
+def jacobian_sharded_(sig, diff, fun, J, y, Z, devices):
+    """jacobian!(sig, diff, fun, J, y, Z) for host (numpy) arrays with the knot points cut into len(devices) contiguous blocks, block i on
+    GPU devices[i] of THIS process, all blocks concurrently (rdhip_jacobian_sharded: one context and one host thread per entry; a device
+    may be listed more than once).  The stacked J / y are complete on return.  The one-process alternative to rdhip.parallel for
+    hosts without torch.distributed."""
+    if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+        raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+    model, rule = _model_rule(fun)
+    if rule == L.IMPLICIT_MIDPOINT:
+        if not isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError(f"Must call jacobian! on an implicit model with the ImplicitFunctionTheorem diff method. Got {type(diff).__name__}.")
+        diff = diff.diff
+    if not isinstance(Z, PackedTrajectory) or _is_torch(Z.data):
+        raise TypeError("jacobian_sharded_ takes a host (numpy) PackedTrajectory")
+    n, m = _check_traj(fun, Z)
+    N = len(Z)
+    _dense(J, (N, n, n + m), "J", transposed_last2=True)
+    az, at, adt = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t"), _Arg(Z.dt, "Z.dt")
+    aj, ay = _Arg(J, "J", az.dtype), _Arg(y, "y", az.dtype)
+    if y is not None:
+        _dense(y, (N, n), "y")
+    if any(a.space != L.HOST for a in (az, at, adt, aj) if a.ptr is not None) or (ay.ptr is not None and ay.space != L.HOST):
+        raise ValueError("jacobian_sharded_ takes host arrays")
+    devices = [int(d) for d in devices]
+    if not devices:
+        raise ValueError("no devices")
+    ctxs = []
+    for i, d in enumerate(devices):
+        key = (d, devices[:i].count(d))
+        if key not in _shard_ctx:
+            _shard_ctx[key] = L.Context(d)
+        ctxs.append(_shard_ctx[key])
+    arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    rc = L.lib().rdhip_jacobian_sharded(arr, len(ctxs), model._handle, rule, diff.code, az.dtype, N, az.ptr, at.ptr, adt.ptr, aj.ptr, ay.ptr)
+    L.check(rc, None)
+    return None
+
+
 class PreparedJacobian:
     """jacobian!(sig, diff, fun, J, y, Z) with the argument checking done ONCE: calling the object re-issues the same batched
     call on the same arrays (their contents may change, their memory may not).  For solver loops that evaluate the same packed

@@ -368,6 +368,43 @@ def test_c_abi_graph_capture_and_replay():
     graph.close(); ctx.close()
 
 
+def test_one_process_sharded_jacobian_and_peer_copy():
+    """rdhip_jacobian_sharded: host arrays, contiguous blocks of knot points on several contexts of ONE process (here: three contexts on
+    the only GPU of the test box, ragged blocks incl. an empty one for tiny N), concurrently; rdhip_memcpy_peer stacks device shards."""
+    from rdhip import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(29)
+    model, om = RD.Quadrotor(), O.quadrotor()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    for N in (1000, 2, 0):
+        Zn, t, dt = H.rand_rigid(rng, N, 4) if N else np.zeros((0, 17)), np.arange(N) * 0.1, np.full(N, 0.1)
+        Z = traj(model, Zn, t, dt, None)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        Y = np.empty((N, 13))
+        RD.jacobian_sharded_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z, devices=[0, 0, 0])
+        if N:
+            Jr, Yr = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+            np.testing.assert_allclose(J, Jr, rtol=0, atol=TOL)
+            np.testing.assert_allclose(Y, Yr, rtol=0, atol=TOL)
+    lo, cnt = C.c_longlong(), C.c_longlong()
+    spans = []
+    for i in range(3):
+        L.check(L.lib().rdhip_shard_range(1000, 3, i, C.byref(lo), C.byref(cnt)))
+        spans.append((lo.value, lo.value + cnt.value))
+    assert spans == [RD.parallel.shard_range(1000, i, 3) for i in range(3)] == [(0, 334), (334, 668), (668, 1000)]
+    with pytest.raises(TypeError):                      # device arrays are the business of rdhip.parallel / one context per device
+        RD.jacobian_sharded_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, traj(model, np.zeros((0, 17)), np.zeros(0), np.zeros(0), "cuda"), devices=[0])
+    # peer copy (same device here): ordered after the producer stream, runs on the consumer stream
+    a, b = L.Context(0), L.Context(0)
+    src = torch.arange(4096, dtype=torch.float64, device="cuda")
+    dst = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    L.check(L.lib().rdhip_memcpy_peer(b.handle, dst.data_ptr(), a.handle, src.data_ptr(), 4096 * 8), b.handle)
+    b.synchronize()
+    assert torch.equal(src, dst)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("where", ["host", "cuda"])
 def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
     """state_diff(s::LieState, x, x0) on raw rand(n) vectors, as test/liestate.jl:33-51 (QuatRotation, P = (3,2,3)) and :56-68
