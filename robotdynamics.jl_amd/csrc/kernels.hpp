@@ -52,10 +52,19 @@ template <class Fn, class T>
 __global__ void __launch_bounds__(256) eval_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                    const double* __restrict__ dtt, T* __restrict__ Y) {
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NB = 256;
-    __shared__ T lds[NB * (NZ > NY ? NZ : NY)];
+    constexpr int VN = 16 / (int)sizeof(T);                  // elements per 16-byte unit
+    typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+    __shared__ __attribute__((aligned(16))) T lds[NB * (NZ > NY ? NZ : NY)];
     const long long k0 = (long long)blockIdx.x * NB;
     const int nk = (int)((N - k0) < NB ? (N - k0) : NB);
-    for (int e = threadIdx.x; e < nk * NZ; e += NB) lds[e] = Z[k0 * NZ + e];
+    // tiles start at multiples of 256 knot points, i.e. at multiples of 16 bytes from the array base: 16-byte units when the base is aligned
+    const bool zal = (reinterpret_cast<unsigned long long>(Z) & 15) == 0, yal = (reinterpret_cast<unsigned long long>(Y) & 15) == 0;
+    {
+        const T* src = Z + k0 * NZ;
+        const int total = nk * NZ, nv = zal ? total / VN : 0;
+        for (int e = threadIdx.x; e < nv; e += NB) reinterpret_cast<V*>(lds)[e] = reinterpret_cast<const V*>(src)[e];
+        for (int e = nv * VN + threadIdx.x; e < total; e += NB) lds[e] = src[e];
+    }
     __syncthreads();
     const int kl = threadIdx.x < nk ? threadIdx.x : nk - 1;
     const T t = (T)tt[k0 + kl], h = (T)dtt[k0 + kl];
@@ -66,7 +75,12 @@ __global__ void __launch_bounds__(256) eval_kernel(Fn fn, long long N, const T* 
 #pragma unroll
     for (int i = 0; i < NY; ++i) lds[threadIdx.x * NY + i] = y[i];
     __syncthreads();
-    for (int e = threadIdx.x; e < nk * NY; e += NB) Y[k0 * NY + e] = lds[e];
+    {
+        T* dst = Y + k0 * NY;
+        const int total = nk * NY, nv = yal ? total / VN : 0;
+        for (int e = threadIdx.x; e < nv; e += NB) reinterpret_cast<V*>(dst)[e] = reinterpret_cast<const V*>(lds)[e];
+        for (int e = nv * VN + threadIdx.x; e < total; e += NB) dst[e] = lds[e];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
