@@ -113,7 +113,20 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                     # fail here, not inside the timed region, if RCCL cannot talk
+                torch.cuda.synchronize()
+            except Exception as e:                         # the data path has no collective: keep measuring with a CPU control path
+                print(f"[bench] rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); control path falls back to gloo, gather skipped", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                args.backend = "gloo"
+                red_dev = torch.device("cpu")
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
 
@@ -187,18 +200,21 @@ def main():
 
     gather = None
     if world > 1 and args.gather != "none" and args.backend == "nccl":
-        reps = 5
-        P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)     # warm (dense (N, n+m, n) slabs)
-        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        g0 = _time.perf_counter()
-        for i in range(reps):
-            step(i)
-            P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
-        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(gl, op=dist.ReduceOp.MAX)
-        gather = {"mode": args.gather, "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps,
-                  "bytes_per_rank": N * NX * NZ * 8}
+        try:
+            reps = 5
+            P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)     # warm (dense (N, n+m, n) slabs)
+            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            g0 = _time.perf_counter()
+            for i in range(reps):
+                step(i)
+                P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
+            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(gl, op=dist.ReduceOp.MAX)
+            gather = {"mode": args.gather, "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps,
+                      "bytes_per_rank": N * NX * NZ * 8}
+        except Exception as e:                               # the exchange is an extra: never lose the bench line over it
+            gather = {"mode": args.gather, "error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
