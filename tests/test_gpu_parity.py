@@ -181,14 +181,14 @@ def test_unaligned_output_slabs_take_the_fallback_kernel():
     t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
     Z = traj(model, Zn, t, dt, "cuda")
     Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
-    for diff in (RD.ForwardAD(), RD.UserDefined()):
+    for diff in (RD.ForwardAD(), RD.UserDefined(), RD.FiniteDifference()):
         bufJ = torch.zeros(N * 247 + 1, dtype=torch.float64, device="cuda")
         bufY = torch.zeros(N * 13 + 1, dtype=torch.float64, device="cuda")
         J = bufJ[1:].view(N, 19, 13).transpose(1, 2)          # data_ptr is 8 mod 16
         Y = bufY[1:].view(N, 13)
         assert J.data_ptr() % 16 == 8 and Y.data_ptr() % 16 == 8
         RD.jacobian_(RD.StaticReturn(), diff, dm, J, Y, Z)
-        np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(J), Jo, rtol=0, atol=1e-6 if isinstance(diff, RD.FiniteDifference) else TOL)
         np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
         assert float(bufJ[0]) == 0.0 and float(bufY[0]) == 0.0   # nothing written in front of the slab
 
@@ -687,8 +687,11 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     Z = traj(sat, Zn, t, dt, "cuda")
     buf = torch.zeros(N * 247 + 1, dtype=torch.float64, device="cuda")
     Ju = buf[1:].view(N, 19, 13).transpose(1, 2)
-    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics(sat, RD.RK4), Ju, None, Z)
-    np.testing.assert_allclose(host(Ju), O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)[0], rtol=0, atol=TOL)
+    for diff, tol in ((RD.ForwardAD(), TOL), (RD.FiniteDifference(), 1e-6), (RD.UserDefined(), TOL)):
+        Ju.fill_(5.0)
+        RD.jacobian_(RD.StaticReturn(), diff, RD.DiscretizedDynamics(sat, RD.RK4), Ju, None, Z)
+        np.testing.assert_allclose(host(Ju), O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)[0], rtol=0, atol=tol)
+    assert float(buf[0]) == 0.0
     # cost-balanced column plan (columns JIT-compiled one by one, code size = cost): same numbers as the contiguous plan
     satb = RD.CustomModel(13, 6, H.SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6))).balance_columns()
     Jb = RD.alloc_jacobians(RD.DiscretizedDynamics(satb, RD.RK4), N, Z.data)
