@@ -2,6 +2,11 @@
 // `Satellite` of test/liemodel.jl.
 #include "dispatch.hpp"
 namespace rd {
+// SatellitePair columns: q1 0-3, w1 4-6, q2 7-10, w2 11-13, tau1 14-16, tau2 17-19.  The two bodies are decoupled, so with compile-time
+// tangent seeds half of every column folds away; per-column costs as for the single satellite (w > tau > q) give four waves of about
+// w,w,w,tau | w,w,w,tau | tau,tau,q,q,q,q | tau,tau,q,q,q,q.
+using PairPlan = TablePlan<20, 4, 0, /*q1*/ 2, 2, 2, 2, /*w1*/ 0, 0, 0, /*q2*/ 3, 3, 3, 3, /*w2*/ 1, 1, 1, /*tau1*/ 0, 2, 2, /*tau2*/ 1, 3, 3>;
+template <class T, int RULE> struct UnrollPolicy<SatellitePair<T>, RULE> { static constexpr bool value = true; using Plan = PairPlan; static constexpr int NC = 4; };
 int fam_lie_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
     return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_eval<SatellitePair>(md, rule, dtype, a) : dispatch_eval<LieSatellite>(md, rule, dtype, a);
 }

@@ -222,6 +222,14 @@ def main():
     f64, f32 = np.float64, np.float32
     sat, cart, quad = RD.Satellite(), RD.Cartpole(), RD.Quadrotor()
     AD, FD, UD = RD.ForwardAD(), RD.FiniteDifference(), RD.UserDefined()
+    if a.only == "pair":
+        pair = RD.SatellitePair()
+        qa, qb = rng.standard_normal((65536, 4)), rng.standard_normal((65536, 4))
+        Zp = np.concatenate([qa / np.linalg.norm(qa, axis=1, keepdims=True), rng.random((65536, 3)), qb / np.linalg.norm(qb, axis=1, keepdims=True), rng.random((65536, 9))], axis=1)
+        jac_case("satellite pair (n=14, m=6) RK4 jacobian ForwardAD", pair, Zp, RD.RK4, AD, f64, a.reps)
+        jac_case("satellite pair (n=14, m=6) RK3 jacobian ForwardAD", pair, Zp, RD.RK3, AD, f64, a.reps)
+        jac_case("satellite pair (n=14, m=6) continuous jacobian ForwardAD", pair, Zp, None, AD, f64, a.reps)
+        return
     if a.only == "rolljac":
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
@@ -244,6 +252,10 @@ def main():
     jac_case("C3 satellite RK3 jacobian ForwardAD", sat, Zs, RD.RK3, AD, f64, a.reps)
     jac_case("satellite full-inertia RK4 jacobian ForwardAD", RD.Satellite(mass=1.5, J=np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])), Zs, RD.RK4, AD, f64, a.reps)
     jac_case("quadrotor RK4 jacobian ForwardAD", quad, rigid_inputs(65536, 4, rng, 0.6, 1.9), RD.RK4, AD, f64, a.reps)
+    pair = RD.SatellitePair()
+    qa, qb = rng.standard_normal((65536, 4)), rng.standard_normal((65536, 4))
+    Zp = np.concatenate([qa / np.linalg.norm(qa, axis=1, keepdims=True), rng.random((65536, 3)), qb / np.linalg.norm(qb, axis=1, keepdims=True), rng.random((65536, 9))], axis=1)
+    jac_case("satellite pair (n=14, m=6) RK4 jacobian ForwardAD", pair, Zp, RD.RK4, AD, f64, a.reps)
     # C4: Quadrotor errstate Jacobian, 262144 knot points = 8 x 32768; one rank's share and the whole
     for N in (32768, 262144):
         Zq = rigid_inputs(N, 4, rng, 0.6, 1.9)
