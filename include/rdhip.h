@@ -186,8 +186,8 @@ int rdhip_dynamics_error_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
  *     Ebar[k] = [ G(x_{k+1})' A_k G(x_k)  |  G(x_{k+1})' B_k ],   k = 0..N-2,
  * with [A_k B_k] = the ForwardAD Jacobian of discrete_dynamics(DiscretizedDynamics{rule}(model), z_k) (src/discretized_dynamics.jl:169)
  * and G = errstate_jacobian! (src/liestate.jl:262-298; identity for EuclideanState models, src/statevectortype.jl:149-155).
- * Fused into the Jacobian kernel for RigidBody{QuatRotation} models (the n x (n+m) Jacobian never reaches memory); EuclideanState
- * models return [A_k B_k]; other LieGroupModels go through a workspace Jacobian stack and a projection kernel.
+ * Fused into the Jacobian kernel for the compiled-in LieGroupModels (the n x (n+m) Jacobian never reaches memory); EuclideanState
+ * models return [A_k B_k]; custom (JIT) LieGroupModels go through a workspace Jacobian stack and a projection kernel.
  * Ebar: e x (e+m) x (N-1), each slab column-major; Y: n x (N-1) or NULL receives f(z_k).  Device pointers must be 16-byte aligned. */
 int rdhip_error_expansion(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
                           const void* Z, const double* t, const double* dt, void* Ebar, void* Y, int memspace);

@@ -504,6 +504,7 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     rc = check_rotation(c, M); if (rc) return rc;
     const ModelDesc& d = M->d;
     const bool rigid = d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR;
+    const bool lie_fused = d.kind == RDHIP_MODEL_SATELLITE_PAIR || d.kind == RDHIP_MODEL_LIE_SATELLITE;   // compiled-in LieGroupModels: fused kernel too
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = d.n + d.m;
     Stage s(c);
     LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = Z; a.t = t; a.dt = dt; a.J = Ebar; a.Y = Y;
@@ -514,8 +515,9 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     }
     int k;
     if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
+    else if (lie_fused && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) k = fam_lie_errexp(d, rule, dtype, a);
     else if (!rigid) {
-        // other LieGroupModels: Jacobians into a context workspace, then the generic projection kernel
+        // custom LieGroupModels (and unaligned outputs): Jacobians into a context workspace, then the generic projection kernel
         void* Jw = s.reserve((size_t)P * d.n * nz * ts);
         if (s.rc) return s.rc;
         void* Eout = a.J;

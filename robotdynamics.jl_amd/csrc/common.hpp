@@ -67,7 +67,8 @@ RD_DECLARE_FAMILY(fam_satellite)
 RD_DECLARE_FAMILY(fam_quadrotor)
 RD_DECLARE_FAMILY(fam_lie)
 int fam_satellite_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
-int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);         // satellite pair, lie satellite
+int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);               // satellite pair, lie satellite
 
 // hipRTC model plug-in (jit.hip)
 void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np);

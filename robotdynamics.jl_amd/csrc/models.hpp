@@ -194,6 +194,8 @@ template <class T_> struct SatellitePair {
     using T = T_;
     static constexpr int NX = 14, NU = 6;
     static constexpr bool HAS_USER_JACOBIAN = false;    // examples/satellite_pair.jl defines none -> NotImplementedError (src/functionbase.jl:257)
+    static constexpr int NROT = 2;                       // LieState{QuatRotation,(0,3,3)}: quaternions at state indices 0 and 7
+    static constexpr int rot_start(int r) { return r == 0 ? 0 : 7; }
     T J[2][9], Jinv[2][9];
     static SatellitePair make(const double* p) {
         SatellitePair M;
@@ -221,6 +223,8 @@ template <class T_> struct LieSatellite {
     using T = T_;
     static constexpr int NX = 7, NU = 3;
     static constexpr bool HAS_USER_JACOBIAN = false;    // test/liemodel.jl defines none
+    static constexpr int NROT = 1;                       // LieState{QuatRotation,(3,0)}: the quaternion at state index 3
+    static constexpr int rot_start(int) { return 3; }
     T Jd[3], Jdinv[3];
     static LieSatellite make(const double* p) {
         LieSatellite M;

@@ -229,6 +229,7 @@ def main():
         jac_case("satellite pair (n=14, m=6) RK4 jacobian ForwardAD", pair, Zp, RD.RK4, AD, f64, a.reps)
         jac_case("satellite pair (n=14, m=6) RK3 jacobian ForwardAD", pair, Zp, RD.RK3, AD, f64, a.reps)
         jac_case("satellite pair (n=14, m=6) continuous jacobian ForwardAD", pair, Zp, None, AD, f64, a.reps)
+        errexp_case("satellite pair RK4 error-state expansion fused", pair, Zp, RD.RK4, f64, a.reps)
         return
     if a.only == "rolljac":
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
