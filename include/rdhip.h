@@ -130,7 +130,7 @@ int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_t
 int rdhip_model_balance_columns(rdhip_model* model);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
- * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT); custom models only */
+ * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT), 12 = fused error-state expansion (LieState models); custom models only */
 int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
 /* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
 int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);
@@ -187,7 +187,7 @@ int rdhip_dynamics_error_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
  * with [A_k B_k] = the ForwardAD Jacobian of discrete_dynamics(DiscretizedDynamics{rule}(model), z_k) (src/discretized_dynamics.jl:169)
  * and G = errstate_jacobian! (src/liestate.jl:262-298; identity for EuclideanState models, src/statevectortype.jl:149-155).
  * Fused into the Jacobian kernel for the compiled-in LieGroupModels (the n x (n+m) Jacobian never reaches memory); EuclideanState
- * models return [A_k B_k]; custom (JIT) LieGroupModels go through a workspace Jacobian stack and a projection kernel.
+ * models return [A_k B_k]; unaligned outputs of the other LieGroupModels go through a workspace Jacobian stack and a projection kernel.
  * Ebar: e x (e+m) x (N-1), each slab column-major; Y: n x (N-1) or NULL receives f(z_k).  Device pointers must be 16-byte aligned. */
 int rdhip_error_expansion(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
                           const void* Z, const double* t, const double* dt, void* Ebar, void* Y, int memspace);

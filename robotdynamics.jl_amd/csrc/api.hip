@@ -232,7 +232,7 @@ int rdhip_model_create_custom(int n, int m, const char* body, const char* preamb
         if (len != n) { delete M; return fail(nullptr, RDHIP_ERR_DIM_MISMATCH, "LieState partition has length %d but n = %d", len, n); }
         d.e = 3 * (nP - 1) + sp;
     } else d.e = n;
-    d.jit = jit_model_create(n, m, body, preamble, d.params, nparams);
+    d.jit = jit_model_create(n, m, body, preamble, d.params, nparams, d.rot == RDHIP_ROT_QUAT, d.lie_P, nP);
     d.newton_iters = 10; d.newton_tol = 1e-12;
     build_lie(M);
     *out = M; return RDHIP_OK;
@@ -249,7 +249,7 @@ int rdhip_model_balance_columns(rdhip_model* M) {
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 11 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || op > 12 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
@@ -516,8 +516,11 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     int k;
     if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
     else if (lie_fused && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) k = fam_lie_errexp(d, rule, dtype, a);
+    else if (d.kind == RDHIP_MODEL_CUSTOM && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) {
+        k = jit_errexp(d.jit, rule, dtype, a); if (k) g_jit_model = &d;          // custom LieGroupModels: the same fused kernel, JIT-compiled
+    }
     else if (!rigid) {
-        // custom LieGroupModels (and unaligned outputs): Jacobians into a context workspace, then the generic projection kernel
+        // unaligned outputs: Jacobians into a context workspace, then the generic projection kernel
         void* Jw = s.reserve((size_t)P * d.n * nz * ts);
         if (s.rc) return s.rc;
         void* Eout = a.J;

@@ -71,7 +71,7 @@ int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchA
 int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);               // satellite pair, lie satellite
 
 // hipRTC model plug-in (jit.hip)
-void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np);
+void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np, int quat_rotations, const int* P, int nP);
 void jit_model_destroy(void* h);
 const char* jit_last_error(void* h);
 int jit_precompile(void* h, int op, int rule, int dtype);
@@ -79,6 +79,7 @@ int jit_balance(void* h);
 int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a);
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a);
 int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a);
+int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a);
 int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a);
 
 // error-state kernels (errstate.hip)

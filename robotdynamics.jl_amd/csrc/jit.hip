@@ -38,16 +38,24 @@ struct JitModel {
     std::string err;
     std::vector<int> plan_wave;                           // column -> compute wave (after jit_balance); empty: contiguous ranges
     int plan_value_wave = 0;
+    std::vector<int> rot_starts;                         // LieState{QuatRotation,P}: state index of every quaternion (empty: EuclideanState or MRP / RP)
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
-       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
 
+static std::string rot_start_expr(const JitModel& M) {
+    std::ostringstream e;
+    for (size_t r = 0; r + 1 < M.rot_starts.size(); ++r) e << "if (r == " << r << ") return " << M.rot_starts[r] << "; ";
+    e << "return " << (M.rot_starts.empty() ? 0 : M.rot_starts.back()) << ";";
+    return e.str();
+}
 static std::string program_source(const JitModel& M) {
     std::ostringstream s;
     s << "#include \"implicit.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
       << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
-      << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
+      << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    static constexpr int NROT = " << M.rot_starts.size() << ";\n"
+      << "    static constexpr int rot_start(int r) { " << rot_start_expr(M) << " }\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
       << "    template <class S> RD_DEV void f(const S* x, const S* u, S* xdot) const {\n" << M.body << "\n    }\n};\n}\n";
     return s.str();
 }
@@ -60,6 +68,22 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
         s << "rd::" << k << "<rd::UserModel<" << T << ">, " << T;
         if (op == JOP_IMPLICIT_X) s << ", false"; else if (op == JOP_IMPLICIT_J) s << ", true";
         s << ">";
+        return s.str();
+    }
+    if (op == JOP_ERREXP) {          // the Jacobian kernel with the tangent seeded in error coordinates and the rows projected (kernels.hpp)
+        const int ne = M.n - (int)M.rot_starts.size(), nc = ne + M.m;
+        std::ostringstream plan;
+        if (!M.plan_wave.empty() && nc >= 4) {           // balanced state columns -> error columns: a rotation's 3 error columns inherit the waves of its first 3 quaternion columns
+            plan << "rd::TablePlan<" << nc << ", 4, " << M.plan_value_wave;
+            size_t r = 0;
+            for (int st = 0; st < M.n;) {
+                if (r < M.rot_starts.size() && st == M.rot_starts[r]) { for (int j = 0; j < 3; ++j) plan << ", " << M.plan_wave[st + j]; st += 4; ++r; }
+                else { plan << ", " << M.plan_wave[st]; ++st; }
+            }
+            for (int i = 0; i < M.m; ++i) plan << ", " << M.plan_wave[M.n + i];
+            plan << ">";
+        } else plan << "rd::ContiguousPlan<" << nc << ", " << (nc >= 4 ? 4 : nc) << ">";
+        s << "rd::jac_errexp_split_kernel<rd::ErrFun<rd::UserModel<" << T << ">, " << rule << ">, " << T << ", " << plan.str() << ", 4>";
         return s.str();
     }
     fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
@@ -145,6 +169,11 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
             if (2 * 64 * lane_bytes > 160 * 1024) { kp = (int)((80 * 1024) / lane_bytes); if (kp > 64) kp = 64; if (kp < 1) kp = 1; }
             jk.block = 64; jk.knots = kp; jk.lds = (size_t)kp * lane_bytes;
         }
+        else if (op == JOP_ERREXP) {       // SplitLds<ErrFun<...>, T, ContiguousPlan<ne+m, ng>, 4>::BYTES
+            const int ne = M.n - (int)M.rot_starts.size(), nc = ne + M.m, ng = nc >= 4 ? 4 : nc;
+            jk.block = (ng + 4) * 64; jk.persistent = true;
+            jk.lds = a16((size_t)64 * ne * nc * ts) + a16((size_t)64 * ny * ts) + a16((size_t)65 * nz * ts) + 2 * 64 * 8;
+        }
         else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
@@ -196,8 +225,9 @@ int jit_balance(void* h) {
 }
 
 // ---- entry points used by api.hip ------------------------------------------------------------------------------------
-void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np) {
+void* jit_model_create(int n, int m, const char* body, const char* preamble, const double* params, int np, int quat_rotations, const int* P, int nP) {
     JitModel* M = new JitModel();
+    if (quat_rotations && nP > 0) { int s0 = 0; for (int r = 0; r + 1 < nP; ++r) { s0 += P[r]; M->rot_starts.push_back(s0); s0 += 4; } }
     M->n = n; M->m = m; M->np = np; M->body = body ? body : ""; M->preamble = preamble ? preamble : "";
     M->params.assign(params, params + np);
     return M;
@@ -263,6 +293,22 @@ int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
         const long long g = 256LL * per_cu; grid = (unsigned)(ntiles < g ? ntiles : g);
     }
     return launch(M, k, grid, a.stream, args);
+}
+
+// fused error-state expansion of a custom LieState{QuatRotation,P} model (dispatch.hpp launch_errexp)
+int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    if (a.N == 0) return RDHIP_OK;
+    if (M.rot_starts.empty()) { M.err = "error-state expansion kernel: the model has no quaternion"; return RDHIP_ERR_INVALID_ARG; }
+    JitKernel* k; int rc = jit_get(M, JOP_ERREXP, rule, dtype, &k); if (rc) return rc;
+    std::vector<unsigned char> fn; pack_params(M, dtype, fn);
+    long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* E = a.J; void* Y = a.Y;
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &E, &Y};
+    const long long ntiles = (N + 63) / 64;
+    int per_cu = (int)(160 * 1024 / (k->lds ? k->lds : 1)); const int by_waves = 2048 / k->block;
+    if (per_cu > by_waves) per_cu = by_waves; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+    const long long g = 256LL * per_cu;
+    return launch(M, k, (unsigned)(ntiles < g ? ntiles : g), a.stream, args);
 }
 
 // DiscretizedDynamics{ImplicitMidpoint}(custom model): mode as in dispatch.hpp launch_implicit

@@ -700,6 +700,9 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     Jo, Yo = O.body().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
     np.testing.assert_allclose(host(Jb), Jo, rtol=0, atol=TOL)
     np.testing.assert_allclose(host(Yb), Yo, rtol=0, atol=TOL)
+    Eb = RD.alloc_error_expansions(RD.DiscretizedDynamics(satb, RD.RK4), N, Z.data)      # the fused expansion inherits the balanced plan
+    RD.error_expansion_(RD.DiscretizedDynamics(satb, RD.RK4), Eb, None, Z)
+    np.testing.assert_allclose(host(Eb), O.body().error_expansion(O.RK4, Zn, t, dt)[0], rtol=0, atol=TOL * 10)
     # rollout of the custom cartpole
     M, K = 9, 30
     data = rng.random((M, K, 5)); tt = np.tile(np.arange(K) * 0.02, (M, 1)); dd = np.full((M, K), 0.02)

@@ -241,6 +241,9 @@ def test_custom_model_jit_compiles_without_a_gpu():
         bad.precompile("evaluate", RD.RK4)
     lie = RD.CustomModel(7, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0)))
     assert RD.errstate_dim(lie) == 6 and isinstance(RD.statevectortype(lie), RD.RotationState)
+    lie.precompile("error_expansion", RD.RK4)           # the fused error-state expansion kernel: quaternion at state index 3 of LieState(R,(3,0))
+    pair = RD.CustomModel(14, 6, "for (int i = 0; i < 14; ++i) xdot[i] = x[i] * u[i % 6];", liestate=(RD.QuatRotation, (0, 3, 3)))
+    pair.precompile("error_expansion", RD.RK3, np.float32)   # two rotations (state indices 0 and 7)
     with pytest.raises(ValueError):
         RD.dims(RD.CustomModel(8, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0))))     # LieState length 7 != n
 

@@ -13,3 +13,6 @@ satb = RD.CustomModel(13, 6, SATELLITE_SRC, params=(1.0, 1.0, 1.0, 1.0), liestat
 B.jac_case("JIT satellite RK4 jacobian ForwardAD (cost-balanced columns)", satb, Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
 B.jac_case("built-in satellite RK4 jacobian ForwardAD", RD.Satellite(), Zs, RD.RK4, RD.ForwardAD(), np.float64, 30)
 B.eval_case("JIT satellite RK4 discrete_dynamics", sat, Zs, RD.RK4, np.float64, 30)
+B.errexp_case("JIT satellite RK4 error-state expansion (fused, JIT)", sat, Zs, RD.RK4, np.float64, 30)
+B.errexp_case("JIT satellite RK4 error-state expansion (fused, JIT, cost-balanced columns)", satb, Zs, RD.RK4, np.float64, 30)
+B.errexp_case("built-in satellite RK4 error-state expansion (fused)", RD.Satellite(), Zs, RD.RK4, np.float64, 30)
