@@ -118,7 +118,9 @@ int rdhip_model_destroy(rdhip_model* model);
  * first use per (operation, rule, dtype) and cached in the model; every rule, diff method and dtype of the compiled-in models works.
  * LieState models: pass rotation = RDHIP_ROT_QUAT and the partition P (as LieState{R,P}, src/liestate.jl:75-83), nP = 0 for Euclidean.
  * n <= 16, m <= 8, nparams <= 64.  Compilation errors come back as RDHIP_ERR_INVALID_ARG with the compiler log in rdhip_last_error(NULL)
- * (creation does not compile; the first use or rdhip_model_precompile does). */
+ * (creation does not compile; the first use or rdhip_model_precompile does).  With the environment variable RDHIP_CACHE_DIR set, compiled
+ * kernels are kept there as code objects (keyed by a hash of the generated source, the kernel templates and the HIP version) and later
+ * processes load them instead of compiling. */
 int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const char* preamble, const double* params, int nparams,
                               int rotation, const int* P, int nP, rdhip_model** out);
 /* setnewtoniters / setnewtontolerance of an ImplicitDynamicsModel (src/discretized_dynamics.jl:225-228); defaults 10 and 1e-12

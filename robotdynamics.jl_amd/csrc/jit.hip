@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -116,10 +119,52 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     return s.str();
 }
 
+// ---- optional on-disk cache of compiled kernels (RDHIP_CACHE_DIR): a solver process pays the 2-5 s per kernel once, not per run ----
+static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+static std::string cache_path(const std::string& src, const std::string& expr) {
+    const char* dir = getenv("RDHIP_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    uint64_t h = fnv1a(src);
+    h = fnv1a(expr, h);
+    for (int i = 0; i < rdhip_embedded_count; ++i) h = fnv1a(rdhip_embedded_sources[i], h);      // the kernel templates themselves
+    h = fnv1a(std::to_string(HIP_VERSION), h);
+    char name[40]; snprintf(name, sizeof name, "/rdhip_%016llx.co", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+static bool cache_load(const std::string& path, std::string& lowered, std::vector<char>& code) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    uint32_t magic = 0, nl = 0; uint64_t nc = 0;
+    if (fread(&magic, 4, 1, f) == 1 && magic == 0x52444843u && fread(&nl, 4, 1, f) == 1 && fread(&nc, 8, 1, f) == 1 && nl < 65536 && nc < (1ull << 30)) {
+        lowered.resize(nl); code.resize(nc);
+        ok = fread(&lowered[0], 1, nl, f) == nl && fread(code.data(), 1, nc, f) == nc;
+    }
+    fclose(f);
+    return ok;
+}
+static void cache_store(const std::string& path, const std::string& lowered, const std::vector<char>& code) {
+    const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                        // an unwritable cache directory is not an error
+    const uint32_t magic = 0x52444843u, nl = (uint32_t)lowered.size(); const uint64_t nc = code.size();
+    const bool ok = fwrite(&magic, 4, 1, f) == 1 && fwrite(&nl, 4, 1, f) == 1 && fwrite(&nc, 8, 1, f) == 1 && fwrite(lowered.data(), 1, nl, f) == nl && fwrite(code.data(), 1, nc, f) == nc;
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());       // rename: readers never see a partial file
+}
+
 // compile (no GPU needed): code object + lowered kernel name for (op, rule, dtype)
 static int jit_compile(JitModel& M, int op, int rule, int dtype, const std::string& key) {
     if (M.code.count(key)) return RDHIP_OK;
     const std::string src = program_source(M), expr = kernel_expr(M, op, rule, dtype);
+    const std::string cpath = cache_path(src, expr);
+    if (!cpath.empty()) {
+        std::string low; std::vector<char> code;
+        if (cache_load(cpath, low, code)) { M.lowered[key] = low; M.code[key] = std::move(code); return RDHIP_OK; }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rdhip_user_model.hip", rdhip_embedded_count, rdhip_embedded_sources, rdhip_embedded_names) != HIPRTC_SUCCESS) {
         M.err = "hiprtcCreateProgram failed"; return RDHIP_ERR_HIP;
@@ -141,6 +186,7 @@ static int jit_compile(JitModel& M, int op, int rule, int dtype, const std::stri
     std::vector<char> code(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    if (!cpath.empty()) cache_store(cpath, M.lowered[key], code);
     M.code[key] = std::move(code);
     return RDHIP_OK;
 }

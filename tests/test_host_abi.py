@@ -248,6 +248,30 @@ def test_custom_model_jit_compiles_without_a_gpu():
         RD.dims(RD.CustomModel(8, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0))))     # LieState length 7 != n
 
 
+def test_jit_disk_cache_is_opt_in_and_survives_corruption(tmp_path, monkeypatch):
+    """RDHIP_CACHE_DIR: compiled kernels of custom models are stored as code objects keyed by a hash of the generated source, the kernel
+    templates and the HIP version; a second model object (a new process in real life) loads them instead of compiling; a damaged file is
+    ignored and rewritten."""
+    import time
+    monkeypatch.setenv("RDHIP_CACHE_DIR", str(tmp_path))
+    src = H.CARTPOLE_SRC + "\n// cache test " + str(time.time())         # unique source -> unique key
+    t0 = time.perf_counter()
+    RD.CustomModel(4, 1, src, params=(1.0, 0.2, 0.5, 9.81)).precompile("ForwardAD", RD.RK4)
+    cold = time.perf_counter() - t0
+    files = sorted(tmp_path.glob("rdhip_*.co"))
+    assert len(files) == 1 and files[0].stat().st_size > 1000
+    t0 = time.perf_counter()
+    RD.CustomModel(4, 1, src, params=(1.0, 0.2, 0.5, 9.81)).precompile("ForwardAD", RD.RK4)
+    warm = time.perf_counter() - t0
+    assert warm < 0.25 * cold, (cold, warm)
+    files[0].write_bytes(b"garbage")
+    RD.CustomModel(4, 1, src, params=(1.0, 0.2, 0.5, 9.81)).precompile("ForwardAD", RD.RK4)     # recompiles and rewrites
+    assert files[0].stat().st_size > 1000
+    monkeypatch.delenv("RDHIP_CACHE_DIR")
+    RD.CustomModel(4, 1, src + " ", params=(1.0, 0.2, 0.5, 9.81)).precompile("evaluate", RD.RK4)
+    assert len(list(tmp_path.glob("rdhip_*.co"))) == 1                   # no cache without the variable
+
+
 def test_header_is_plain_c_and_the_c_demo_links_and_runs():
     """include/rdhip.h must be consumable by a C compiler (the boundary is a C ABI): compile examples/c_abi_demo.c as C99 with
     -Wall -Wextra -Werror, link it against librdhip.so and run it (on a box without a GPU it exercises the model queries and exits 0)."""
