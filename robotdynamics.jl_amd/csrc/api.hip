@@ -169,11 +169,11 @@ int rdhip_free(rdhip_ctx* c, void* p) {
 }
 int rdhip_memcpy_h2d(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
 }
 int rdhip_memcpy_d2h(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
