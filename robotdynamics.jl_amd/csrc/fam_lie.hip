@@ -1,29 +1,11 @@
-// fam_lie.hip -- LieGroupModels that are not RigidBodies: SatellitePair (examples/satellite_pair.jl) and the
-// `Satellite` of test/liemodel.jl.
-#include "dispatch.hpp"
+// fam_lie.hip -- LieGroupModels that are not RigidBodies: run-time selection between SatellitePair (examples/satellite_pair.jl) and the
+// `Satellite` of test/liemodel.jl; the kernels are instantiated in fam_pair*.hip and fam_liesat.hip.
+#include "fam_lie.hpp"
 namespace rd {
-// SatellitePair columns: q1 0-3, w1 4-6, q2 7-10, w2 11-13, tau1 14-16, tau2 17-19.  The two bodies are decoupled, so with compile-time
-// tangent seeds half of every column folds away; per-column costs as for the single satellite (w > tau > q) give four waves of about
-// w,w,w,tau | w,w,w,tau | tau,tau,q,q,q,q | tau,tau,q,q,q,q.
-using PairPlan = TablePlan<20, 4, 0, /*q1*/ 2, 2, 2, 2, /*w1*/ 0, 0, 0, /*q2*/ 3, 3, 3, 3, /*w2*/ 1, 1, 1, /*tau1*/ 0, 2, 2, /*tau2*/ 1, 3, 3>;
-template <class T, int RULE> struct UnrollPolicy<SatellitePair<T>, RULE> { static constexpr bool value = true; using Plan = PairPlan; static constexpr int NC = 4; };
-// error-state columns: phi1 0-2, w1 3-5, phi2 6-8, w2 9-11, tau1 12-14, tau2 15-17 (same grouping as PairPlan); LieSatellite: w 0-2, phi 3-5, u 6-8
-using PairErrPlan = TablePlan<18, 4, 0, /*phi1*/ 2, 2, 2, /*w1*/ 0, 0, 0, /*phi2*/ 3, 3, 3, /*w2*/ 1, 1, 1, /*tau1*/ 0, 2, 2, /*tau2*/ 1, 3, 3>;
-template <class T, int RULE> struct ErrPlanOf<SatellitePair<T>, RULE> { using Plan = PairErrPlan; };
-template <class T, int RULE> struct ErrPlanOf<LieSatellite<T>, RULE> { using Plan = ContiguousPlan<9, 4>; };
-int fam_lie_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
-    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_eval<SatellitePair>(md, rule, dtype, a) : dispatch_eval<LieSatellite>(md, rule, dtype, a);
-}
-int fam_lie_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) {
-    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_jacobian<SatellitePair>(md, rule, diff, dtype, a) : dispatch_jacobian<LieSatellite>(md, rule, diff, dtype, a);
-}
-int fam_lie_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
-    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_rollout<SatellitePair>(md, rule, dtype, a) : dispatch_rollout<LieSatellite>(md, rule, dtype, a);
-}
-int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) {
-    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_errexp<SatellitePair>(md, rule, dtype, a) : dispatch_errexp<LieSatellite>(md, rule, dtype, a);
-}
-int fam_lie_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) {
-    return md.kind == RDHIP_MODEL_SATELLITE_PAIR ? dispatch_implicit<SatellitePair>(md, mode, dtype, a) : dispatch_implicit<LieSatellite>(md, mode, dtype, a);
-}
+#define RD_PICK(fn, ...) (md.kind == RDHIP_MODEL_SATELLITE_PAIR ? pair_##fn(__VA_ARGS__) : liesat_##fn(__VA_ARGS__))
+int fam_lie_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(eval, md, rule, dtype, a); }
+int fam_lie_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return RD_PICK(jacobian, md, rule, diff, dtype, a); }
+int fam_lie_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(rollout, md, rule, dtype, a); }
+int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(errexp, md, rule, dtype, a); }
+int fam_lie_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) { return RD_PICK(implicit, md, mode, dtype, a); }
 }  // namespace rd
