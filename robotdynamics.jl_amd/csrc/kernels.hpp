@@ -45,6 +45,18 @@ RD_DEV void read_knot(const T* zs, int lane, bool term, T (&x)[Fn::NX], T (&u)[F
     for (int i = 0; i < Fn::NU; ++i) u[i] = term ? T(0) : zs[lane * NZ + Fn::NX + i];
 }
 
+// global -> LDS staging of `total` (<= MAXE) consecutive elements by NT threads: every thread issues ALL of its loads before it waits
+// for any (a run-time `load, wait, ds_write` loop costs one memory round trip per pass -- measured as several microseconds in front of
+// the first arithmetic of a kernel); out-of-range lanes re-read element 0 so that the loads stay unconditional
+template <class E, int MAXE, int NT> RD_DEV void stage_in(const E* __restrict__ src, E* dst, int total, int tid) {
+    constexpr int PT = (MAXE + NT - 1) / NT;
+    E r[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { const int e = i * NT + tid; r[i] = src[e < total ? e : 0]; }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { const int e = i * NT + tid; if (e < total) dst[e] = r[i]; }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // evaluate: Y[:,k] = fun(z_k)      (dynamics / discrete_dynamics)
 // ------------------------------------------------------------------------------------------------------------
@@ -61,9 +73,12 @@ __global__ void __launch_bounds__(256) eval_kernel(Fn fn, long long N, const T* 
     const bool zal = (reinterpret_cast<unsigned long long>(Z) & 15) == 0, yal = (reinterpret_cast<unsigned long long>(Y) & 15) == 0;
     {
         const T* src = Z + k0 * NZ;
-        const int total = nk * NZ, nv = zal ? total / VN : 0;
-        for (int e = threadIdx.x; e < nv; e += NB) reinterpret_cast<V*>(lds)[e] = reinterpret_cast<const V*>(src)[e];
-        for (int e = nv * VN + threadIdx.x; e < total; e += NB) lds[e] = src[e];
+        const int total = nk * NZ;
+        if (zal) {
+            const int nv = total / VN;
+            stage_in<V, (NB * NZ + VN - 1) / VN, NB>(reinterpret_cast<const V*>(src), reinterpret_cast<V*>(lds), nv, threadIdx.x);
+            for (int e = nv * VN + threadIdx.x; e < total; e += NB) lds[e] = src[e];     // < VN elements
+        } else stage_in<T, NB * NZ, NB>(src, lds, total, threadIdx.x);
     }
     __syncthreads();
     const int kl = threadIdx.x < nk ? threadIdx.x : nk - 1;
@@ -250,9 +265,11 @@ RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, co
     {   // first tile: stage z, t, dt
         const long long k0 = tile * TILE;
         const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
-        for (int e = threadIdx.x; e < nk * NZ; e += NT) zs[e] = Z[k0 * NZ + e];
-        if (threadIdx.x < nk) ts[threadIdx.x] = tt[k0 + threadIdx.x];
-        else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
+        const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+        const int idx = threadIdx.x & (TILE - 1);
+        const double t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
+        stage_in<T, TILE * NZ, NT>(Z + k0 * NZ, zs, nk * NZ, threadIdx.x);
+        if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -452,13 +469,22 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
         fr.want_y = (Y != nullptr);
-        {
+        {   // first tile: all of a thread's loads are issued before any is waited for (a load -> wait -> LDS-write loop costs one memory
+            // round trip per pass: five of them in front of the first arithmetic of the kernel)
             const long long k0 = tile * TILE;
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
             const int nin = (int)((NIN - k0) < TIN ? (NIN - k0) : TIN);
-            for (int e = threadIdx.x; e < nin * NZ; e += NTC) zs[e] = Z[k0 * NZ + e];
-            if (threadIdx.x < nk) ts[threadIdx.x] = tt[k0 + threadIdx.x];
-            else if (threadIdx.x >= TILE && threadIdx.x < TILE + nk) ts[threadIdx.x] = dtt[k0 + threadIdx.x - TILE];
+            T z0[ZPT]; double t0;
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[(e < nin * NZ) ? k0 * NZ + e : 0]; }
+            {
+                const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+                const int idx = threadIdx.x & (TILE - 1);
+                t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = z0[r]; }
+            if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
         }
         __syncthreads();                                   // barrier 0
         for (; tile < tend; tile += tstep) {
@@ -669,9 +695,10 @@ __global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long
     const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
     const int kl = lane < nk ? lane : nk - 1;
     // stage z: lane-contiguous loads of the tile's nk*NZ values -> LDS -> one knot point per lane
-    for (int e = lane; e < nk * NZ; e += TILE) lds[e] = Z[k0 * NZ + e];
     const double hd = dtt[k0 + kl];
-    const T t = (T)tt[k0 + kl], h = (T)hd;
+    const double td = tt[k0 + kl];
+    stage_in<T, TILE * NZ, TILE>(Z + k0 * NZ, lds, nk * NZ, lane);
+    const T t = (T)td, h = (T)hd;
     const bool term = is_terminal_dt(hd);
     wave_sync();
     D xd[NX], ud[NU], yd[NY];
