@@ -84,7 +84,10 @@ __global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long
     if (owner) {
         T* g = tile + threadIdx.x * per;
         if (MODE == 0) {
-            for (int r = 0; r < d.n; ++r) if (d.row_kind[r] == 0) g[r + d.row_col[r] * d.n] = T(1);
+            // constant trip count: the descriptor bytes are then read with (batched) scalar loads from the kernel arguments; a loop with a
+            // run-time bound indexes the descriptor dynamically, which turns into one dependent global load per row (13 serial round trips)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < d.n && d.row_kind[r] == 0) g[r + d.row_col[r] * d.n] = T(1);
         }
 #pragma unroll
         for (int rot = 0; rot < 4; ++rot) {
@@ -107,6 +110,7 @@ __global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long
     __syncthreads();
     T* out = G + k0 * per;
     const int nv = total / VN;
+#pragma unroll 4
     for (int i = threadIdx.x; i < nv; i += 256) reinterpret_cast<V*>(out)[i] = reinterpret_cast<const V*>(tile)[i];
     for (int i = nv * VN + threadIdx.x; i < total; i += 256) out[i] = tile[i];
 }
