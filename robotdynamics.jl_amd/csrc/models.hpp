@@ -82,9 +82,9 @@ template <class T_> struct Cartpole {
         const S H12 = c * (mp * l);
         const S r0 = (x[3] * x[3]) * s * (-(mp * l)) - u[0];   // C*qd + G - B*u, row 1
         const S r1 = s * (mp * g * l);                           // row 2
-        const S det = H12 * H12 * T(-1) + H11 * H22;
-        const S y0 = (r0 * H22 - H12 * r1) / det;
-        const S y1 = (r1 * H11 - H12 * r0) / det;
+        const S idet = recip_(H12 * H12 * T(-1) + H11 * H22);    // one fp64 division per evaluation instead of four (value and tangent of two quotients)
+        const S y0 = (r0 * H22 - H12 * r1) * idet;
+        const S y1 = (r1 * H11 - H12 * r0) * idet;
         xd[0] = x[2]; xd[1] = x[3]; xd[2] = -y0; xd[3] = -y1;
     }
 };

@@ -69,30 +69,69 @@ template <class T, int K> RD_DEV Dual<T, K> operator/(const Dual<T, K>& a, T b) 
     return r;
 }
 
-RD_DEV float sin_(float a) { return sinf(a); }
-RD_DEV float cos_(float a) { return cosf(a); }
+// sin and cos together, < 1 ulp each for |x| < 8e5 (checked against long-double sinl / cosl on 10^7 arguments): three-stage Cody-Waite
+// reduction by pi/2 (the medium-argument path of fdlibm's e_rem_pio2, all stages unconditionally so that there is no divergence) and
+// the fdlibm kernel polynomials with the tail correction.  ~55 fp64 instructions for both values; the device library's separate
+// sin and cos (each with its own extended-precision reduction) cost ~300, which made the cartpole kernels transcendental-bound.
+// Larger arguments fall back to the library.
+RD_DEV void sincos_(double x, double& sn, double& cs) {
+    if (__builtin_fabs(x) < 8.0e5) {
+        const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+        double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x), t = r;
+        double w = fn * 6.07710050630396597660e-11;
+        r = t - w; w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+        t = r;
+        w = fn * 2.02226624871116645580e-21;
+        r = t - w; w = fn * 8.47842766036889956997e-32 - ((t - r) - w);
+        const double y0 = r - w, y1 = (r - y0) - w;
+        const double z = y0 * y0, v = z * y0;
+        const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+        const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+        const double ww = z * z;
+        const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                          ww * ww * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+        const double hz = 0.5 * z, w1 = 1.0 - hz;
+        const double kc = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
+        const int n = (int)fn;
+        const double a = (n & 1) ? kc : ks, b = (n & 1) ? ks : kc;
+        sn = (n & 2) ? -a : a;
+        cs = ((n + 1) & 2) ? -b : b;
+    } else { sn = sin(x); cs = cos(x); }
+}
+RD_DEV void sincos_(float x, float& sn, float& cs) { sn = sinf(x); cs = cosf(x); }   // (through the fp64 path: fewer instructions but a longer dependent chain -- the fp32 rollout ran 1.6x slower)
+RD_DEV float sin_(float a) { float s, c; sincos_(a, s, c); return s; }
+RD_DEV float cos_(float a) { float s, c; sincos_(a, s, c); return c; }
 RD_DEV float sqrt_(float a) { return sqrtf(a); }
-RD_DEV double sin_(double a) { return sin(a); }
-RD_DEV double cos_(double a) { return cos(a); }
+RD_DEV double sin_(double a) { double s, c; sincos_(a, s, c); return s; }
+RD_DEV double cos_(double a) { double s, c; sincos_(a, s, c); return c; }
 RD_DEV double sqrt_(double a) { return sqrt(a); }
+// 1 / a: one division shared by several quotients with the same denominator (each quotient then differs from a true division by <= 1 ulp)
+RD_DEV float recip_(float a) { return 1.0f / a; }
+RD_DEV double recip_(double a) { return 1.0 / a; }
 // max(0, a) with ForwardDiff's tie rule: ifelse(0 > a, 0, a)
 RD_DEV float max0_(float a) { return (0.0f > a) ? 0.0f : a; }
 RD_DEV double max0_(double a) { return (0.0 > a) ? 0.0 : a; }
 
 template <class T, int K> RD_DEV Dual<T, K> sin_(const Dual<T, K>& a) {
-    Dual<T, K> r; r.v = sin_(a.v); const T c = cos_(a.v);
+    Dual<T, K> r; T c; sincos_(a.v, r.v, c);
 #pragma unroll
     for (int i = 0; i < K; ++i) r.d[i] = c * a.d[i];
     return r;
 }
 template <class T, int K> RD_DEV Dual<T, K> cos_(const Dual<T, K>& a) {
-    Dual<T, K> r; r.v = cos_(a.v); const T s = -sin_(a.v);
+    Dual<T, K> r; T sp; sincos_(a.v, sp, r.v); const T s = -sp;
 #pragma unroll
     for (int i = 0; i < K; ++i) r.d[i] = s * a.d[i];
     return r;
 }
 template <class T, int K> RD_DEV Dual<T, K> sqrt_(const Dual<T, K>& a) {
     Dual<T, K> r; r.v = sqrt_(a.v); const T c = T(0.5) / r.v;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r.d[i] = c * a.d[i];
+    return r;
+}
+template <class T, int K> RD_DEV Dual<T, K> recip_(const Dual<T, K>& a) {
+    Dual<T, K> r; r.v = T(1) / a.v; const T c = -(r.v * r.v);
 #pragma unroll
     for (int i = 0; i < K; ++i) r.d[i] = c * a.d[i];
     return r;
