@@ -405,6 +405,27 @@ def test_one_process_sharded_jacobian_and_peer_copy():
     a.close(); b.close()
 
 
+def test_sincos_argument_reduction_over_the_whole_range():
+    """scalar.hpp's fp64 sincos_ (Cody-Waite reduction, < 8e5) and its library fallback (beyond): the cartpole's dynamics and RK4 Jacobian at
+    pole angles from 1e-300 to 1e15 must match the oracle (glibc sin / cos) -- a wrong reduction constant shows up at large angles."""
+    rng = np.random.default_rng(33)
+    mags = np.array([1e-300, 1e-8, 0.5, 3.0, 1e2, 12345.678, 7.9e5, 7.99999e5, 8.0e5, 8.00001e5, 1e6, 1e9, 1e15])
+    th = np.concatenate([mags, -mags, rng.uniform(-8e5, 8e5, 3000), rng.uniform(-50, 50, 3000), np.arange(1, 2000) * (np.pi / 2)])
+    N = th.size
+    Zn = rng.random((N, 5)); Zn[:, 1] = th
+    t, dt = np.zeros(N), np.full(N, 1e-3)
+    model, om = RD.Cartpole(), O.cartpole()
+    Z = traj(model, Zn, t, dt, "cuda")
+    np.testing.assert_allclose(host(RD.dynamics(model, Z)), om.dynamics(Zn, t, dt), rtol=1e-13, atol=1e-12)
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    np.testing.assert_allclose(host(Y), Yo, rtol=1e-13, atol=1e-9)
+    np.testing.assert_allclose(host(J), Jo, rtol=1e-12, atol=TOL)
+
+
 @pytest.mark.parametrize("where", ["host", "cuda"])
 def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
     """state_diff(s::LieState, x, x0) on raw rand(n) vectors, as test/liestate.jl:33-51 (QuatRotation, P = (3,2,3)) and :56-68
