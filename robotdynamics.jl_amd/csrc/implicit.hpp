@@ -66,9 +66,16 @@ template <class Mdl, class T> struct ImplicitOps {
             { const int tmp = piv[K]; piv[K] = piv[p]; piv[p] = tmp; }   // piv[] holds the row permutation: row i of P*A is row piv[i] of A
             // swap rows K and p (all columns: the stored multipliers move with their rows); the new row K stays in registers
             T rk[NX];
+            if (p != K) {
 #pragma unroll
-            for (int jj = 0; jj < NX; ++jj) { const T a = A[K + jj * NX], b = A[p + jj * NX]; A[K + jj * NX] = b; A[p + jj * NX] = a; rk[jj] = b; }
+                for (int jj = 0; jj < NX; ++jj) { const T a = A[K + jj * NX], b = A[p + jj * NX]; A[K + jj * NX] = b; A[p + jj * NX] = a; rk[jj] = b; }
+            } else {                                             // no exchange (the usual case for I - (h/2) A): only the part of row K that the step uses
+                rk[K] = ck[K];
+#pragma unroll
+                for (int jj = K + 1; jj < NX; ++jj) rk[jj] = A[K + jj * NX];
+            }
             const T inv = T(1) / rk[K];
+            A[K + K * NX] = inv;                                  // the diagonal of U is kept as its reciprocal: the solves multiply instead of dividing
 #pragma unroll
             for (int i = K + 1; i < NX; ++i) {
                 const T l = A[i + K * NX] * inv;               // (re-read: row p's entry moved to row K's old place)
@@ -84,7 +91,7 @@ template <class Mdl, class T> struct ImplicitOps {
         for (int i = 0; i < NX; ++i) piv[i] = i;
         lu_step<0>(A, piv);
     }
-    // b <- A^{-1} b with the factors above; b in registers (compile-time indices).  The row permutation is applied through the
+    // b <- A^{-1} b with the factors above (unit-lower L, U with its diagonal stored as reciprocals); b in registers (compile-time indices).  The row permutation is applied through the
     // lane's LDS staging vector: a select chain on registers is turned into a dynamically indexed private array (scratch memory).
     static RD_DEV void solve(T* A, const int* piv, T (&b)[NX]) {
         T* sb = A + NX * NX;
@@ -101,7 +108,7 @@ template <class Mdl, class T> struct ImplicitOps {
         for (int i = NX - 1; i >= 0; --i) {
 #pragma unroll
             for (int j = i + 1; j < NX; ++j) b[i] -= A[i + j * NX] * b[j];
-            b[i] = b[i] / A[i + i * NX];
+            b[i] = b[i] * A[i + i * NX];                         // reciprocal of the pivot (stored by lu_step)
         }
     }
     // IFT columns: J[:, C] = -A2^{-1} J1[:, C],  J1 = [I + (h/2) A, h B]

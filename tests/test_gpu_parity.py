@@ -824,6 +824,38 @@ def test_implicit_midpoint_newton_solve_and_ift_jacobian(where):
     np.testing.assert_allclose(host(RD.discrete_dynamics(dm, traj(model, Zn, t, dt, "cuda" if where == "cuda" else None))), om.implicit_midpoint(Zn, t, dt, newton_iters=1)[0], rtol=0, atol=TOL)
 
 
+def test_implicit_midpoint_lu_with_row_exchanges():
+    """The Newton matrix (h/2) A - I of the physical models is diagonally dominant, so their LU never exchanges rows; a linear system with a
+    large step makes partial pivoting do real work (checked: scipy's LU of the same matrix permutes), and its solution and IFT Jacobian have
+    closed forms: x2 = (I - hA/2)^-1 ((I + hA/2) x1 + h B u), d x2 / d x1 = (I - hA/2)^-1 (I + hA/2), d x2 / d u = h (I - hA/2)^-1 B."""
+    import scipy.linalg
+    rng = np.random.default_rng(35)
+    n, m, h = 6, 3, 1.0
+    A = 4.0 * rng.standard_normal((n, n)); np.fill_diagonal(A, 2.0 / h + 1e-3 * rng.standard_normal(n))     # (h/2) A - I has a tiny diagonal
+    B = rng.standard_normal((n, m))
+    Mn = 0.5 * h * A - np.eye(n)
+    perm = scipy.linalg.lu(Mn)[0]
+    assert not np.allclose(perm, np.eye(n))                  # the factorisation really exchanges rows
+    model, om = RD.LinearModel(A, B), O.linear(A, B)
+    dm = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    N = 200
+    Zn = rng.standard_normal((N, n + m)); t, dt = np.zeros(N), np.full(N, h)
+    Minv = np.linalg.inv(np.eye(n) - 0.5 * h * A)
+    Xc = (Minv @ ((np.eye(n) + 0.5 * h * A) @ Zn[:, :n].T + h * B @ Zn[:, n:].T)).T
+    Jc = np.concatenate([Minv @ (np.eye(n) + 0.5 * h * A), h * Minv @ B], axis=1)
+    for where in ("cuda", None):
+        Z = traj(model, Zn, t, dt, where)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        Y = torch.empty((N, n), dtype=torch.float64, device="cuda") if where else np.empty((N, n))
+        RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dm, J, Y, Z)
+        scale = max(1.0, np.abs(Jc).max())
+        np.testing.assert_allclose(host(Y), Xc, rtol=0, atol=1e-9 * max(1.0, np.abs(Xc).max()))
+        np.testing.assert_allclose(host(J), np.broadcast_to(Jc, (N, n, n + m)), rtol=0, atol=1e-9 * scale)
+        np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), Xc, rtol=0, atol=1e-9 * max(1.0, np.abs(Xc).max()))
+    Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
+    np.testing.assert_allclose(Xo, Xc, rtol=0, atol=1e-9 * max(1.0, np.abs(Xc).max()))
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21
