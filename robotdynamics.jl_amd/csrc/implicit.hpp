@@ -111,20 +111,64 @@ template <class Mdl, class T> struct ImplicitOps {
             b[i] = b[i] * A[i + i * NX];                         // reciprocal of the pivot (stored by lu_step)
         }
     }
-    // IFT columns: J[:, C] = -A2^{-1} J1[:, C],  J1 = [I + (h/2) A, h B]
+    // several right-hand sides at once: every factor entry is read from LDS once per group instead of once per column, and the G
+    // substitution chains are independent of each other (the single-column solve is a chain of LDS round trips)
+    template <int G> static RD_DEV void solve_multi(T* A, const int* piv, T (&b)[G][NX]) {
+        T* sb = A + NX * NX;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sb[i] = b[g][i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) b[g][i] = sb[piv[i]];
+        }
+#pragma unroll
+        for (int i = 1; i < NX; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < i; ++jj) {
+                const T a = A[i + jj * NX];
+#pragma unroll
+                for (int g = 0; g < G; ++g) b[g][i] -= a * b[g][jj];
+            }
+        }
+#pragma unroll
+        for (int i = NX - 1; i >= 0; --i) {
+#pragma unroll
+            for (int jj = i + 1; jj < NX; ++jj) {
+                const T a = A[i + jj * NX];
+#pragma unroll
+                for (int g = 0; g < G; ++g) b[g][i] -= a * b[g][jj];
+            }
+            const T inv = A[i + i * NX];                         // reciprocal of the pivot (stored by lu_step)
+#pragma unroll
+            for (int g = 0; g < G; ++g) b[g][i] = b[g][i] * inv;
+        }
+    }
+    // IFT columns: J[:, C] = -A2^{-1} J1[:, C],  J1 = [I + (h/2) A, h B]; groups of up to 4 columns per solve
+    template <int C, int G> static RD_DEV void ift_rhs(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T (&b)[G][NX]) {
+        if constexpr (C % 4 < G) {      // (C - C0) < G, groups start at multiples of 4
+            T f[NX];
+            jcol<C>(m, xm, u, b[C % 4], f);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) b[C % 4][i] = (C < NX) ? b[C % 4][i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : b[C % 4][i] * h;
+            if constexpr (C % 4 + 1 < G) ift_rhs<C + 1, G>(m, xm, u, h, b);
+        }
+    }
     template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, T* A, const int* piv, T* Jk, bool store) {
         if constexpr (C < NX + NU) {
-            T col[NX], f[NX];
-            jcol<C>(m, xm, u, col, f);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
-            solve(A, piv, col);
-            const T sc = (C >= NX && term) ? T(0) : T(-1);           // control columns of a terminal knot point are zero
+            constexpr int G = (NX + NU - C) < 4 ? (NX + NU - C) : 4;
+            T b[G][NX];
+            ift_rhs<C, G>(m, xm, u, h, b);
+            solve_multi<G>(A, piv, b);
             if (store) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) Jk[C * NX + i] = col[i] * sc;
+                for (int g = 0; g < G; ++g) {
+                    const T sc = (C + g >= NX && term) ? T(0) : T(-1);       // control columns of a terminal knot point are zero
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) Jk[(C + g) * NX + i] = b[g][i] * sc;
+                }
             }
-            ift_cols<C + 1>(m, xm, u, h, term, A, piv, Jk, store);
+            ift_cols<C + 4>(m, xm, u, h, term, A, piv, Jk, store);
         }
     }
 };
