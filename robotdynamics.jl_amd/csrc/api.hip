@@ -21,6 +21,7 @@ struct rdhip_ctx {
     bool own_stream;
     hipEvent_t ev0, ev1;
     bool capturing = false;               // between rdhip_graph_begin_capture and rdhip_graph_end_capture
+    int* d_flag = nullptr;                // device word "a row exchange was needed" of the implicit kernels (allocated on first use)
     std::string err;
     // grow-only device workspace slots for RDHIP_HOST staging
     void* ws[8];
@@ -101,6 +102,7 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->d_flag) (void)hipFree(c->d_flag);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c; return RDHIP_OK;
@@ -249,7 +251,7 @@ int rdhip_model_balance_columns(rdhip_model* M) {
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 12 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || op > 15 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
@@ -390,9 +392,13 @@ static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchA
     }
 }
 
-static int family_implicit(const ModelDesc& d, int mode, int dtype, LaunchArgs a) {
+static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype, LaunchArgs a) {
     g_jit_model = nullptr;
     a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
+    if (mode != 2) {     // Newton kernels: register pass + gated LDS pass communicate through a device word
+        if (!c->d_flag && hipMalloc(&c->d_flag, 256) != hipSuccess) { (void)hipGetLastError(); return RDHIP_ERR_HIP; }
+        a.flag = c->d_flag;
+    }
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_implicit(d, mode, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_implicit(d, mode, dtype, a);
@@ -412,12 +418,12 @@ static int eval_common(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, 
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
     LaunchArgs a{}; a.stream = c->stream; a.N = N;
-    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.Y = Y; return kernel_status(c, implicit ? family_implicit(d, 0, dtype, a) : family_eval(d, rule, dtype, a), what); }
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.Y = Y; return kernel_status(c, implicit ? family_implicit(c, d, 0, dtype, a) : family_eval(d, rule, dtype, a), what); }
     Stage s(c);
     a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts); a.t = (const double*)s.in(t, (size_t)N * 8); a.dt = (const double*)s.in(dt, (size_t)N * 8);
     a.Y = s.out(Y, (size_t)N * d.n * ts);
     if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, implicit ? family_implicit(d, 0, dtype, a) : family_eval(d, rule, dtype, a), what));
+    return s.finish(kernel_status(c, implicit ? family_implicit(c, d, 0, dtype, a) : family_eval(d, rule, dtype, a), what));
 }
 
 int rdhip_dynamics(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, const double* t, const double* dt, void* Xdot, int memspace) {
@@ -448,7 +454,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
         if (s.rc) return s.rc;
     }
     if (implicit && !a.Y && N > 0) { a.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }     // the Newton solution has to land somewhere
-    const int k = kernel_status(c, implicit ? family_implicit(d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
+    const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
 
@@ -475,7 +481,7 @@ static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     if (rule == RDHIP_IMPLICIT_MIDPOINT) {          // e = x1 + h f((x1+x2)/2, u1) - x2 ; J1 = [I + (h/2)A, hB] ; J2 = [(h/2)A - I, 0]  (src/integration.jl:631-690)
         if (want_jac && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: ForwardAD only for implicit rules", what);
         a.Y = dE; a.J = want_jac ? dJ1 : nullptr; a.J2 = want_jac ? dJ2 : nullptr;
-        k = kernel_status(c, family_implicit(d, 2, dtype, a), what);
+        k = kernel_status(c, family_implicit(c, d, 2, dtype, a), what);
         return memspace == RDHIP_HOST ? s.finish(k) : k;
     }
     if (want_jac && dJ1) { a.J = dJ1; a.Y = dE; k = family_jacobian(d, rule, diff, dtype, a); }       // f(z_k) lands in E
@@ -592,13 +598,13 @@ int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long 
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
-    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, implicit ? family_implicit(d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what); }
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what); }
     Stage s(c);
     a.Z = s.out(Z, (size_t)K * Mt * (d.n + d.m) * ts, /*preload=*/true);
     a.t = (const double*)s.in(t, (size_t)K * Mt * 8); a.dt = (const double*)s.in(dt, (size_t)K * Mt * 8);
     a.X0 = s.in(X0, (size_t)Mt * d.n * ts);
     if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, implicit ? family_implicit(d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
+    return s.finish(kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
 }
 
 // rollout!, then the Jacobians along the rollout: what a shooting / iLQR forward pass + linearisation needs, in one call.
@@ -631,8 +637,8 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     }
     LaunchArgs j{}; j.stream = c->stream; j.N = N; j.Z = r.Z; j.t = r.t; j.dt = r.dt; j.J = dJ;
     if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
-    int k = kernel_status(c, implicit ? family_implicit(d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
-    if (!k) k = kernel_status(c, implicit ? family_implicit(d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
+    int k = kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
+    if (!k) k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
 

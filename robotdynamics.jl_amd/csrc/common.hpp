@@ -53,6 +53,7 @@ struct LaunchArgs {
     int newton_iters;   // implicit rules
     double newton_tol;
     int time_major;     // rollout: knot k of trajectory j at k*M + j instead of j*K + k
+    int* flag;          // implicit rules: device word of the context ("a row exchange was needed"); NULL = LDS kernels only
 };
 
 // per-family entry points (one translation unit each so they compile in parallel)

@@ -175,11 +175,12 @@ template <class Mdl, class T> struct ImplicitOps {
 
 template <class Mdl, class T, bool WANT_J>
 __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol) {
+                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate && *gate == 0) return;                                      // second pass behind the register kernel: only if a row exchange was needed
     if (threadIdx.x >= L::KP) return;                                    // lanes without a matrix slot stay idle
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
@@ -231,6 +232,192 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
     }
 }
 
+// ---- the Newton matrix in REGISTERS --------------------------------------------------------------------------------------------
+// With the continuous Jacobian columns produced by compile-time tangent seeds, the compiler knows the sparsity pattern of (h/2) A - I
+// and of its LU fill-in: a fully unrolled factorisation WITHOUT row exchanges keeps only the structurally non-zero entries (the
+// satellite's 13 x 13 matrix fits 238 VGPRs, no LDS, two waves per SIMD) and skips the arithmetic on the zeros -- an order of magnitude
+// faster than the LDS version above.  For n > 6 partial pivoting is reproduced exactly as long as it would not have exchanged rows (|pivot| >=
+// every entry below it, the usual case for I - (h/2) A); every lane checks that, and if any lane of the launch fails the check a flag
+// is raised and the LDS kernels above (launched behind this one, gated on the flag) recompute the whole batch with real row exchanges.
+template <class Mdl, class T> struct ImplicitRegOps {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    using Ops = ImplicitOps<Mdl, T>;
+    template <int C> static RD_DEV void fill(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T (&a)[NX][NX], T (&f)[NX]) {
+        if constexpr (C < NX) {
+            T col[NX];
+            Ops::template jcol<C>(m, xm, u, col, f);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) a[i][C] = col[i] * (h * T(0.5)) - ((i == C) ? T(1) : T(0));
+            fill<C + 1>(m, xm, u, h, a, f);
+        }
+    }
+    // Small matrices (n <= 6: cartpole, double integrators, the linear test systems) carry partial pivoting in registers: the row exchange
+    // is a select per element and candidate row (~n^3 selects), the compile-time sparsity is lost but 36 entries fit anyway, and no second
+    // pass is ever needed.  (The cartpole's Newton matrix does exchange rows for ordinary inputs.)
+    static constexpr bool PIVOT = NX <= 6;
+    // LU, pivots stored as reciprocals.  PIVOT: with row exchanges recorded in piv.  Otherwise: without exchanges; returns true if partial
+    // pivoting would have exchanged rows somewhere.
+    static RD_DEV bool lu(T (&a)[NX][NX], int (&piv)[NX]) {
+        bool need = false;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            T pk = a[k][k] < T(0) ? -a[k][k] : a[k][k];
+            if constexpr (PIVOT) {
+                int p = k;
+#pragma unroll
+                for (int i = k + 1; i < NX; ++i) { const T v = a[i][k] < T(0) ? -a[i][k] : a[i][k]; if (v > pk) { pk = v; p = i; } }
+                piv[k] = p;
+#pragma unroll
+                for (int i = k + 1; i < NX; ++i) {
+                    const bool sw = (p == i);
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) { const T x = a[k][j], y = a[i][j]; a[k][j] = sw ? y : x; a[i][j] = sw ? x : y; }
+                }
+            } else {
+#pragma unroll
+                for (int i = k + 1; i < NX; ++i) { const T v = a[i][k] < T(0) ? -a[i][k] : a[i][k]; need = need || (v > pk); }
+            }
+            const T inv = T(1) / a[k][k];
+            a[k][k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < NX; ++i) {
+                const T l = a[i][k] * inv; a[i][k] = l;
+#pragma unroll
+                for (int j = k + 1; j < NX; ++j) a[i][j] -= l * a[k][j];
+            }
+        }
+        return need;
+    }
+    static RD_DEV void solve(const T (&a)[NX][NX], const int (&piv)[NX], T (&b)[NX]) {
+        if constexpr (PIVOT) {                                    // the recorded exchanges, in order, on the right-hand side
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+#pragma unroll
+                for (int i = k + 1; i < NX; ++i) { const bool sw = (piv[k] == i); const T x = b[k], y = b[i]; b[k] = sw ? y : x; b[i] = sw ? x : y; }
+            }
+        }
+#pragma unroll
+        for (int i = 1; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < i; ++j) b[i] -= a[i][j] * b[j];
+        }
+#pragma unroll
+        for (int i = NX - 1; i >= 0; --i) {
+#pragma unroll
+            for (int j = i + 1; j < NX; ++j) b[i] -= a[i][j] * b[j];
+            b[i] = b[i] * a[i][i];
+        }
+    }
+    // one Newton solve from x1 (src/integration.jl:422-463): xn = solution, xl = last tested iterate; true if a row exchange was needed
+    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX]) {
+        T xm[NX], f[NX], r[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xn[i] = x1[i]; xl[i] = x1[i]; }
+        bool done = false, need = false;
+        for (int it = 0; it < iters; ++it) {
+            if (!done) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xl[i] = xn[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
+            T a[NX][NX];
+            fill<0>(m, xm, u, h, a, f);
+            T nr = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
+            if ((double)sqrt_(nr) < tol) done = true;
+            if (__all(done)) break;
+            int piv[NX];
+            need = lu(a, piv) || need;
+            solve(a, piv, r);
+            if (!done) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xn[i] = xl[i] - r[i];
+            }
+        }
+        return need;
+    }
+    // IFT columns with the register factors: J[:, C] = -A2^{-1} J1[:, C]
+    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX], T* Jk, bool store) {
+        if constexpr (C < NX + NU) {
+            T col[NX], f[NX];
+            Ops::template jcol<C>(m, xm, u, col, f);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
+            solve(a, piv, col);
+            const T sc = (C >= NX && term) ? T(0) : T(-1);           // control columns of a terminal knot point are zero
+            if (store) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Jk[C * NX + i] = col[i] * sc;
+            }
+            ift_cols<C + 1>(m, xm, u, h, term, a, piv, Jk, store);
+        }
+    }
+};
+
+template <class Mdl, class T, bool WANT_J>
+__global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                                                     T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, int* __restrict__ flag) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    using R = ImplicitRegOps<Mdl, T>;
+    const long long k = (long long)blockIdx.x * TILE + threadIdx.x;
+    const bool active = k < N;
+    const long long kc = active ? k : N - 1;
+    const double hd = dtt[kc];
+    const T h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    T x1[NX], u[NU], xn[NX], xl[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x1[i] = Z[kc * NZ + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[kc * NZ + NX + i];
+    bool need = R::newton(m, x1, u, h, newton_iters, tol, xn, xl);
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xn[k * NX + i] = xn[i];
+    }
+    if constexpr (WANT_J) {
+        // Jacobians at the last TESTED iterate (what the reference's cache holds when the loop exits)
+        T xm[NX], f[NX], a[NX][NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
+        int piv[NX];
+        R::template fill<0>(m, xm, u, h, a, f);
+        need = R::lu(a, piv) || need;
+        R::template ift_cols<0>(m, xm, u, h, term, a, piv, J + kc * NX * NZ, active);
+    }
+    if (need && flag) *flag = 1;
+}
+
+template <class Mdl, class T>
+__global__ void __launch_bounds__(TILE) implicit_rollout_reg_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ dtt,
+                                                                    const T* __restrict__ X0, int newton_iters, double tol, int* __restrict__ flag) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    using R = ImplicitRegOps<Mdl, T>;
+    const long long j = (long long)blockIdx.x * TILE + threadIdx.x;
+    const bool active = j < M;
+    const long long jc = active ? j : M - 1;
+    T* Zj = Z + jc * K * NZ;
+    T x1[NX], u[NU], xn[NX], xl[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x1[i] = X0 ? X0[jc * NX + i] : Zj[i];
+    if (X0 && active) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Zj[i] = x1[i];
+    }
+    bool need = false;
+    for (long long k = 1; k < K; ++k) {
+        const double hd = dtt[jc * K + k - 1];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(hd) ? T(0) : Zj[(k - 1) * NZ + NX + i];
+        need = R::newton(m, x1, u, (T)hd, newton_iters, tol, xn, xl) || need;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x1[i] = xn[i]; if (active) Zj[k * NZ + i] = xn[i]; }
+    }
+    if (need && flag) *flag = 1;
+}
+
 template <class Mdl, class T, int C>
 RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&u)[Mdl::NU], const T (&x1)[Mdl::NX], const T (&x2)[Mdl::NX], T h, T* e, T* j2, T* j1) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
@@ -255,11 +442,12 @@ RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&
 // (src/trajectories.jl:436-441 over src/integration.jl:422-463).  Z: (n+m) x K x M, states of knots 2..K overwritten in place.
 template <class Mdl, class T>
 __global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ dtt,
-                                                                const T* __restrict__ X0, int newton_iters, double tol) {
+                                                                const T* __restrict__ X0, int newton_iters, double tol, const int* __restrict__ gate) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate && *gate == 0) return;
     if (threadIdx.x >= L::KP) return;
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;

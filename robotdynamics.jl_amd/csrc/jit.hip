@@ -45,7 +45,8 @@ struct JitModel {
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
-       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12,
+       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
 
 static std::string rot_start_expr(const JitModel& M) {
     std::ostringstream e;
@@ -66,6 +67,12 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const char* T = dtype == RDHIP_F64 ? "double" : "float";
     const int nz = M.n + M.m;
     std::ostringstream fn, s;
+    if (op >= JOP_IMPLICIT_X_REG) {          // Newton matrix in registers (implicit.hpp)
+        s << "rd::" << (op == JOP_IMPLICIT_ROLLOUT_REG ? "implicit_rollout_reg_kernel" : "implicit_midpoint_reg_kernel") << "<rd::UserModel<" << T << ">, " << T;
+        if (op == JOP_IMPLICIT_X_REG) s << ", false"; else if (op == JOP_IMPLICIT_J_REG) s << ", true";
+        s << ">";
+        return s.str();
+    }
     if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitMidpoint kernels are templated on the model itself
         const char* k = op == JOP_IMPLICIT_ERR ? "implicit_midpoint_error_kernel" : op == JOP_IMPLICIT_ROLLOUT ? "implicit_rollout_kernel" : "implicit_midpoint_kernel";
         s << "rd::" << k << "<rd::UserModel<" << T << ">, " << T;
@@ -208,7 +215,7 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR) jk.block = 64;
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) jk.block = 64;
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
@@ -368,8 +375,20 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     int iters = a.newton_iters; double tol = a.newton_tol; void* nul = nullptr;
     const unsigned grid = (unsigned)(mode == 2 ? (N + 63) / 64 : (N + k->knots - 1) / k->knots);
     if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
-    if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol}; return launch(M, k, grid, a.stream, args); }
-    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol};
+    // n <= 14: the register kernel first (exact for n <= 6, where it pivots in registers); the LDS kernel behind it gated on the flag
+    const int* gate = nullptr;
+    if (a.flag && M.n <= 14) {
+        JitKernel* kr; rc = jit_get(M, mode == 0 ? JOP_IMPLICIT_X_REG : mode == 1 ? JOP_IMPLICIT_J_REG : JOP_IMPLICIT_ROLLOUT_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
+        int* flag = a.flag;
+        if (M.n > 6 && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
+        const unsigned gr = (unsigned)((N + 63) / 64);
+        if (mode == 3) { if (K == 0) return RDHIP_OK; void* ar[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
+        else { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
+        if (rc || M.n <= 6) return rc;
+        gate = flag;
+    }
+    if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol, &gate}; return launch(M, k, grid, a.stream, args); }
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &gate};
     return launch(M, k, grid, a.stream, args);
 }
 

@@ -724,6 +724,14 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     Eb = RD.alloc_error_expansions(RD.DiscretizedDynamics(satb, RD.RK4), N, Z.data)      # the fused expansion inherits the balanced plan
     RD.error_expansion_(RD.DiscretizedDynamics(satb, RD.RK4), Eb, None, Z)
     np.testing.assert_allclose(host(Eb), O.body().error_expansion(O.RK4, Zn, t, dt)[0], rtol=0, atol=TOL * 10)
+    # ImplicitMidpoint on the custom satellite (n = 13: register-matrix Newton kernel, JIT-compiled, LDS kernel gated behind it)
+    dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
+    Ji = RD.alloc_jacobians(dmi, N, Z.data)
+    Yi = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, Ji, Yi, Z)
+    Xo, Jio, _ = O.body().implicit_midpoint(Zn, t, dt)
+    np.testing.assert_allclose(host(Yi), Xo, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(host(Ji), Jio, rtol=0, atol=1e-8 * max(1.0, np.abs(Jio).max()))
     # rollout of the custom cartpole
     M, K = 9, 30
     data = rng.random((M, K, 5)); tt = np.tile(np.arange(K) * 0.02, (M, 1)); dd = np.full((M, K), 0.02)
@@ -854,6 +862,32 @@ def test_implicit_midpoint_lu_with_row_exchanges():
         np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), Xc, rtol=0, atol=1e-9 * max(1.0, np.abs(Xc).max()))
     Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
     np.testing.assert_allclose(Xo, Xc, rtol=0, atol=1e-9 * max(1.0, np.abs(Xc).max()))
+
+
+def test_implicit_midpoint_register_pass_falls_back_when_rows_must_be_exchanged():
+    """Models with n > 6 run the Newton solve with the matrix in registers and WITHOUT row exchanges, check per lane that partial pivoting
+    would not have exchanged rows, and otherwise raise a flag that makes the LDS kernels (real partial pivoting) recompute the batch.  A
+    satellite with a very large step (h = 40: (h/2) A - I far from diagonally dominant) forces that path for some knot points; the
+    results must still be the oracle's (which pivots), for the solve, the IFT Jacobian and the rollout, next to well-behaved knots."""
+    rng = np.random.default_rng(36)
+    model, om = RD.Satellite(2.0, np.diag([2.0, 3.0, 1.0])), O.body()
+    dm = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    RD.setnewtoniters(dm, 4)                                  # the wild knots need not converge: same iterates either way
+    N = 300
+    Zn = H.rand_rigid(rng, N, 6); Zn[:, 10:13] *= 3.0
+    t = np.zeros(N); dt = np.full(N, 0.05); dt[::7] = 40.0
+    Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt, newton_iters=4)
+    assert np.all(np.isfinite(Xo)) and np.all(np.isfinite(Jo))
+    for where in ("cuda", None):
+        Z = traj(model, Zn, t, dt, where)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        Y = torch.empty((N, 13), dtype=torch.float64, device="cuda") if where else np.empty((N, 13))
+        RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dm, J, Y, Z)
+        sx, sj = max(1.0, np.abs(Xo).max()), max(1.0, np.abs(Jo).max())
+        np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=1e-9 * sx)
+        np.testing.assert_allclose(host(J), Jo, rtol=0, atol=1e-8 * sj)
+        np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), Xo, rtol=0, atol=1e-9 * sx)
+    RD.setnewtoniters(dm, 10)
 
 
 def test_rollout_matches_oracle_and_is_idempotent():
