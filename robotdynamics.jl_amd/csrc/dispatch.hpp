@@ -199,7 +199,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {
-        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag);
+        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), TILE * Mdl::NX * sizeof(T), a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;

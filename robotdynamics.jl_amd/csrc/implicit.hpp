@@ -339,7 +339,13 @@ template <class Mdl, class T> struct ImplicitRegOps {
         return need;
     }
     // IFT columns with the register factors: J[:, C] = -A2^{-1} J1[:, C]
-    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX], T* Jk, bool store) {
+    // Every finished column goes through a wave-private LDS buffer (64 x n values) so that the global stores are coalesced: a lane owns a
+    // knot point, i.e. its column entries sit n(n+m) values apart from its neighbour's -- written directly, every store instruction touches
+    // 64 different cache lines (that was half of the kernel's time); transposed, one store instruction writes the columns of 64 / CW knot
+    // points as runs of n consecutive values.  J0 = the wave's first Jacobian, nk = its number of valid knot points.
+    static constexpr int CW = NX <= 8 ? 8 : 16;                      // lanes per knot point in the store sweep
+    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX],
+                                                 T* sb, T* J0, int nk) {
         if constexpr (C < NX + NU) {
             T col[NX], f[NX];
             Ops::template jcol<C>(m, xm, u, col, f);
@@ -347,11 +353,18 @@ template <class Mdl, class T> struct ImplicitRegOps {
             for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
             solve(a, piv, col);
             const T sc = (C >= NX && term) ? T(0) : T(-1);           // control columns of a terminal knot point are zero
-            if (store) {
+            const int lane = threadIdx.x;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) Jk[C * NX + i] = col[i] * sc;
+            for (int i = 0; i < NX; ++i) sb[lane * NX + i] = col[i] * sc;
+            wave_sync();
+            const int e = lane % CW, kq = lane / CW;
+#pragma unroll
+            for (int it = 0; it < CW; ++it) {                        // TILE / (TILE / CW) sweeps of TILE / CW knot points
+                const int kk = it * (TILE / CW) + kq;
+                if (e < NX && kk < nk) J0[(size_t)kk * NX * (NX + NU) + C * NX + e] = sb[kk * NX + e];
             }
-            ift_cols<C + 1>(m, xm, u, h, term, a, piv, Jk, store);
+            wave_sync();
+            ift_cols<C + 1>(m, xm, u, h, term, a, piv, sb, J0, nk);
         }
     }
 };
@@ -385,7 +398,9 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long
         int piv[NX];
         R::template fill<0>(m, xm, u, h, a, f);
         need = R::lu(a, piv) || need;
-        R::template ift_cols<0>(m, xm, u, h, term, a, piv, J + kc * NX * NZ, active);
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_reg[];
+        const long long k0 = (long long)blockIdx.x * TILE;
+        R::template ift_cols<0>(m, xm, u, h, term, a, piv, reinterpret_cast<T*>(smem_reg), J + k0 * NX * NZ, (int)((N - k0) < TILE ? (N - k0) : TILE));
     }
     if (need && flag) *flag = 1;
 }

@@ -215,7 +215,7 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) jk.block = 64;
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ny * ts; }
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
