@@ -343,6 +343,9 @@ def test_c_abi_graph_capture_and_replay():
         L.check(lib.rdhip_jacobian(ctx.handle, model._handle, L.RK4, L.FORWARD_AD, L.F64, N, *ptrs, J.data_ptr(), Y.data_ptr(), L.DEVICE), ctx.handle)
         L.check(lib.rdhip_discrete_dynamics(ctx.handle, model._handle, L.RK4, L.F64, N, *ptrs, X2.data_ptr(), L.DEVICE), ctx.handle)
         L.check(lib.rdhip_errstate_jacobian(ctx.handle, model._handle, L.F64, N, Z.data.data_ptr(), 19, 1, G.data_ptr(), L.DEVICE), ctx.handle)
+        # an implicit step: memset of the context's flag word + register kernel + gated LDS kernel, all capturable
+        L.check(lib.rdhip_discrete_dynamics(ctx.handle, model._handle, L.IMPLICIT_MIDPOINT, L.F64, N, *ptrs, X3.data_ptr(), L.DEVICE), ctx.handle)
+    X3 = torch.empty((N, 13), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     sequence(); ctx.synchronize()                       # first use outside the capture
     ctx.begin_capture()
@@ -353,7 +356,7 @@ def test_c_abi_graph_capture_and_replay():
     graph = ctx.end_capture()
     for scale in (1.0, 0.25):
         Z.data[:, 7:].mul_(scale)
-        J.zero_(); Y.zero_(); X2.zero_(); G.zero_()
+        J.zero_(); Y.zero_(); X2.zero_(); G.zero_(); X3.zero_()
         torch.cuda.synchronize()
         ctx.launch(graph); ctx.launch(graph)            # replays are idempotent
         ctx.synchronize()
@@ -363,6 +366,7 @@ def test_c_abi_graph_capture_and_replay():
         np.testing.assert_allclose(host(Y), Yr, rtol=0, atol=TOL)
         np.testing.assert_allclose(host(X2), Yr, rtol=0, atol=TOL)
         np.testing.assert_allclose(host(G), om.errstate_jacobian(Zh[:, :13]), rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(X3), om.implicit_midpoint(Zh, t, dt, want_jacobian=False)[0], rtol=0, atol=1e-9)
     with pytest.raises(ValueError):
         ctx.end_capture()                               # not capturing
     graph.close(); ctx.close()

@@ -272,6 +272,7 @@ def main():
     rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
     rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
     rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+    rollout_case("satellite ImplicitMidpoint rollout fp64 4096 traj x 101 knots (a Newton solve per step)", sat, 4096, 101, RD.ImplicitMidpoint, f64, 5, rng)
     # ImplicitMidpoint: Newton solve and IFT Jacobian (compute / LDS-latency bound)
     dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
     Zi = RD.PackedTrajectory(13, 6, Zs, np.arange(65536) * 0.1, np.full(65536, 0.1)).to(DEV)
