@@ -298,8 +298,82 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
 int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G) {
     return dtype == RDHIP_F64 ? errstate_T<double>(d, s, N, X, ldx, clear, G) : errstate_T<float>(d, s, N, X, ldx, clear, G);
 }
+// Tiled state_diff: 128 knot points per workgroup; the x and x0 tiles (contiguous spans of the inputs, any leading dimension <= 32) are
+// staged into LDS with lane-contiguous loads issued in batches of four, ONE lane then computes all e error coordinates of its knot point
+// (each relative rotation once, not once per component), and the e x 128 output tile leaves as a lane-contiguous sweep.
+template <class T>
+__global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, T* __restrict__ dX) {
+    constexpr int NB = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sd[];
+    T* xa = reinterpret_cast<T*>(smem_sd);
+    T* xb = xa + NB * ldx;
+    const int RS = d.e | 1;
+    T* out = xb + NB * ldx0;
+    const long long k0 = (long long)blockIdx.x * NB;
+    const int nk = (int)((N - k0) < NB ? (N - k0) : NB);
+    const int tid = threadIdx.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        const T* src = pass == 0 ? X + k0 * ldx : X0 + k0 * ldx0;
+        T* dst = pass == 0 ? xa : xb;
+        const int total = nk * (pass == 0 ? ldx : ldx0);
+        for (int base = 0; base < total; base += 4 * NB) {
+            T r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = base + q * NB + tid; r[q] = src[e < total ? e : 0]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = base + q * NB + tid; if (e < total) dst[e] = r[q]; }
+        }
+    }
+    __syncthreads();
+    if (tid < nk) {
+        const T* x = xa + tid * ldx; const T* x0 = xb + tid * ldx0;
+        T* o = out + tid * RS;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < d.e && d.err_src[c] >= 0) o[c] = x[d.err_src[c]] - x0[d.err_src[c]];
+#pragma unroll
+        for (int rot = 0; rot < 4; ++rot) {
+            if (rot >= d.nrot) break;
+            const T* ra = x + d.rot_row0[rot]; const T* rb = x0 + d.rot_row0[rot];
+            T qa[4], qb[4];
+            if (d.rot == RDHIP_ROT_QUAT) {
+                const T iq = rsqrt_<T>(ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2] + ra[3] * ra[3]);
+                const T ip = rsqrt_<T>(rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2] + rb[3] * rb[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { qa[i] = ra[i] * iq; qb[i] = rb[i] * ip; }
+            } else if (d.rot == RDHIP_ROT_RP) {
+                const T ia = rsqrt_<T>(T(1) + ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2]), ib = rsqrt_<T>(T(1) + rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2]);
+                qa[0] = ia; qb[0] = ib;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { qa[1 + i] = ra[i] * ia; qb[1 + i] = rb[i] * ib; }
+            } else {
+                const T na = ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2], nb = rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2];
+                const T ia = T(1) / (T(1) + na), ib = T(1) / (T(1) + nb);
+                qa[0] = (T(1) - na) * ia; qb[0] = (T(1) - nb) * ib;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { qa[1 + i] = T(2) * ra[i] * ia; qb[1 + i] = T(2) * rb[i] * ib; }
+            }
+            const T a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+            const T b0 = qb[0], b1 = -qb[1], b2 = -qb[2], b3 = -qb[3];
+            const T w = b0 * a0 - b1 * a1 - b2 * a2 - b3 * a3;                   // same expressions as state_diff_kernel below
+            T* oc = o + d.rot_col0[rot];
+            oc[0] = (b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2) / w;
+            oc[1] = (b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1) / w;
+            oc[2] = (b0 * a3 + b1 * a2 - b2 * a1 + b3 * a0) / w;
+        }
+    }
+    __syncthreads();
+    T* dst = dX + k0 * d.e;
+    const int total = nk * d.e;
+    for (int i = tid; i < total; i += NB) { const int r = i / d.e; dst[i] = out[r * RS + (i - r * d.e)]; }
+}
+
 template <class T> static int sdiff_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX) {
     if (N == 0) return RDHIP_OK;
+    const size_t lds = (size_t)128 * (ldx + ldx0 + (d.e | 1)) * sizeof(T);
+    if (ldx <= 32 && ldx0 <= 32 && lds <= 64 * 1024) {
+        hipLaunchKernelGGL((state_diff_tile_kernel<T>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        return st(hipGetLastError());
+    }
     hipLaunchKernelGGL((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
     return st(hipGetLastError());
 }
