@@ -26,3 +26,27 @@ SATELLITE_SRC = """
     S c[3]; cross3(w, Jw, c);
     xdot[10] = (u[3] - c[0]) / p[1]; xdot[11] = (u[4] - c[1]) / p[2]; xdot[12] = (u[5] - c[2]) / p[3];
 """
+
+# Explicitly time-dependent dynamics: `t` (type T) is the time the dynamics are evaluated at -- the knot point's t for `dynamics`, the stage
+# times t, t + h/2, t + h inside the Runge-Kutta rules (src/integration.jl:130-135,280-286), exactly what `dynamics(model, x, u, t)` receives
+# in the reference.  These two are test models (the reference's own example models are time-invariant).
+TV_PENDULUM_SRC = """
+    // parametrically driven pendulum: thdd = -(a + b cos(w t)) sin(th) - c thd + u + b sin(w t);  p = {a, b, w, c}
+    xdot[0] = x[1];
+    xdot[1] = -(sin_(x[0]) * (p[0] + p[1] * cos_(p[2] * t))) - x[1] * p[3] + u[0] + p[1] * sin_(p[2] * t);
+"""
+
+TV_SATELLITE_SRC = """
+    // the satellite of SATELLITE_SRC with a time-dependent disturbance wrench: F += fd [cos wt, 0, sin wt] (world frame),
+    // tau += td [sin wt, cos wt, sin 2wt];  p = {mass, Jxx, Jyy, Jzz, fd, td, w}
+    const S* q = x + 3; const S* v = x + 7; const S* w = x + 10;
+    S F[3]; quat_rotate(q, u, F);
+    const T wt = p[6] * t;
+    F[0] = F[0] + p[4] * cos_(wt); F[2] = F[2] + p[4] * sin_(wt);
+    quat_kinematics(q, w, xdot + 3);
+    const T im = T(1) / p[0];
+    for (int i = 0; i < 3; ++i) { xdot[i] = v[i]; xdot[7 + i] = F[i] * im; }
+    const S Jw[3] = {w[0] * p[1], w[1] * p[2], w[2] * p[3]};
+    S c[3]; cross3(w, Jw, c);
+    xdot[10] = (u[3] + p[5] * sin_(wt) - c[0]) / p[1]; xdot[11] = (u[4] + p[5] * cos_(wt) - c[1]) / p[2]; xdot[12] = (u[5] + p[5] * sin_(T(2) * wt) - c[2]) / p[3];
+"""

@@ -111,9 +111,11 @@ int rdhip_model_create(int kind, int rotation, int velocity_frame, const double*
 int rdhip_model_destroy(rdhip_model* model);
 /* A user-defined ContinuousDynamics model (the reference's `dynamics(model, x, u)` method, src/dynamics.jl:23-45), given as HIP source:
  * `dynamics_body` is the BODY of
- *       template <class S> __device__ void f(const S* x, const S* u, S* xdot) const
+ *       template <class S> __device__ void f(const S* x, const S* u, T t, S* xdot) const
  * written on a generic scalar S (the library instantiates it with T = float/double and with forward duals), with the model parameters
- * available as `p[i]` (type T) and the dual-aware functions sin_, cos_, sqrt_, recip_, max0_ plus + - * / (scalar.hpp); `preamble` (may be NULL)
+ * available as `p[i]` (type T), the time as `t` (type T: dynamics(model, x, u, t), src/dynamics.jl:81-83 -- the knot point's time for
+ * rdhip_dynamics, the stage times t, t + h/2, t + h inside the Runge-Kutta rules, src/integration.jl:130-135,280-286; a body that never
+ * mentions `t` is a time-invariant model, as all of the reference's examples are) and the dual-aware functions sin_, cos_, sqrt_, recip_, max0_ plus + - * / (scalar.hpp); `preamble` (may be NULL)
  * is pasted at namespace scope in front of the model (helper device functions).  Kernels are JIT-compiled with hipRTC for gfx950 on
  * first use per (operation, rule, dtype) and cached in the model; every rule, diff method and dtype of the compiled-in models works.
  * LieState models: pass rotation = RDHIP_ROT_QUAT and the partition P (as LieState{R,P}, src/liestate.jl:75-83), nP = 0 for Euclidean.

@@ -47,7 +47,12 @@
 // enums (kept numerically identical to include/rdhip.h so tests can share constants)
 // ------------------------------------------------------------------------------------------
 enum { M_CARTPOLE = 0, M_DOUBLE_INTEGRATOR = 1, M_LINEAR = 2, M_SATELLITE = 3, M_QUADROTOR = 4,
-       M_SATELLITE_PAIR = 5, M_LIE_SATELLITE = 6 };
+       M_SATELLITE_PAIR = 5, M_LIE_SATELLITE = 6,
+       // explicitly time-dependent TEST models (not in the reference, whose example models are all time-invariant): they exist to check
+       // that the time argument reaches every stage the way src/integration.jl passes it (t, t + h/2, t + h; implicit midpoint: residual
+       // at t + h/2, Jacobian at t).  The product evaluates them as user-defined (hipRTC) models.
+       M_TV_PENDULUM = 8,      // x = [th, thd]: thdd = -(a + b cos(w t)) sin(th) - c thd + u + b sin(w t)          params {a, b, w, c}
+       M_TV_SATELLITE = 9 };   // RigidBody satellite + disturbance: F += fd [cos wt, 0, sin wt] (world), tau += td [sin wt, cos wt, sin 2wt]   params {mass, J[9], fd, td, w}
 enum { ROT_QUAT = 0, ROT_MRP = 1, ROT_RP = 2 };
 enum { FRAME_WORLD = 0, FRAME_BODY = 1 };
 enum { RULE_EULER = 0, RULE_RK2 = 1, RULE_RK3 = 2, RULE_RK4 = 3 };
@@ -205,6 +210,17 @@ template <class S> static void wrench_satellite(const OModel&, const S* x, const
     S f[3] = {u[0], u[1], u[2]}; qrot(x + 3, f, F);
     T[0] = u[3]; T[1] = u[4]; T[2] = u[5];
 }
+template <class S> static void wrench_tv_satellite(const OModel& M, const S* x, const S* u, S t, S F[3], S T[3]) {
+    wrench_satellite(M, x, u, F, T);
+    const double fd = M.p[10], td = M.p[11], w = M.p[12];
+    F[0] = F[0] + fd * cos_(w * t); F[2] = F[2] + fd * sin_(w * t);
+    T[0] = T[0] + td * sin_(w * t); T[1] = T[1] + td * cos_(w * t); T[2] = T[2] + td * sin_((2.0 * w) * t);
+}
+template <class S> static void dyn_tv_pendulum(const OModel& M, const S* x, const S* u, S t, S* xd) {
+    const double a = M.p[0], b = M.p[1], w = M.p[2], c = M.p[3];
+    xd[0] = x[1];
+    xd[1] = -((a + b * cos_(w * t)) * sin_(x[0])) - c * x[1] + u[0] + b * sin_(w * t);
+}
 template <class S> static void wrench_quadrotor(const OModel& M, const S* x, const S* u, S F[3], S T[3]) {
     double mass = M.p[0]; const double* g = M.p + 10; double L = M.p[13], kf = M.p[14], km = M.p[15];
     S F1 = max0_(kf * u[0]), F2 = max0_(kf * u[1]), F3 = max0_(kf * u[2]), F4 = max0_(kf * u[3]);
@@ -214,11 +230,13 @@ template <class S> static void wrench_quadrotor(const OModel& M, const S* x, con
     T[0] = L * (F2 - F4); T[1] = L * (F3 - F1); T[2] = (M1 - M2 + M3 - M4);
 }
 // RigidBody{QuatRotation} Newton-Euler: src/rigidbody.jl:213-236 ; params (mass, J[9] col-major, ...)
-template <class S> static void dyn_rigidbody(const OModel& M, const S* x, const S* u, S* xd) {
+template <class S> static void dyn_rigidbody(const OModel& M, const S* x, const S* u, S t, S* xd) {
     double mass = M.p[0]; const double* J = M.p + 1; double Jinv[9]; inv3(J, Jinv);
     const S* q = x + 3; const S* v = x + 7; const S* w = x + 10;
     S F[3], T[3];
-    if (M.kind == M_SATELLITE) wrench_satellite(M, x, u, F, T); else wrench_quadrotor(M, x, u, F, T);
+    if (M.kind == M_SATELLITE) wrench_satellite(M, x, u, F, T);
+    else if (M.kind == M_TV_SATELLITE) wrench_tv_satellite(M, x, u, t, F, T);
+    else wrench_quadrotor(M, x, u, F, T);
     S qd[4]; kinematics(q, w, qd);
     S rd[3], vd[3];
     if (M.frame == FRAME_WORLD) {
@@ -257,12 +275,14 @@ template <class S> static void dyn_liesat(const OModel& M, const S* x, const S* 
     for (int i = 0; i < 4; ++i) xd[3 + i] = qd[i];
 }
 
-template <class S> static void dynamics(const OModel& M, const S* x, const S* u, S /*t*/, S* xd) {
+// dynamics(model, x, u, t): the reference's models drop t (src/dynamics.jl:83); the two test models use it
+template <class S> static void dynamics(const OModel& M, const S* x, const S* u, S t, S* xd) {
     switch (M.kind) {
         case M_CARTPOLE: dyn_cartpole(M, x, u, xd); break;
         case M_DOUBLE_INTEGRATOR: dyn_di(M, x, u, xd); break;
         case M_LINEAR: dyn_linear(M, x, u, xd); break;
-        case M_SATELLITE: case M_QUADROTOR: dyn_rigidbody(M, x, u, xd); break;
+        case M_SATELLITE: case M_QUADROTOR: case M_TV_SATELLITE: dyn_rigidbody(M, x, u, t, xd); break;
+        case M_TV_PENDULUM: dyn_tv_pendulum(M, x, u, t, xd); break;
         case M_SATELLITE_PAIR: dyn_satpair(M, x, u, xd); break;
         case M_LIE_SATELLITE: dyn_liesat(M, x, u, xd); break;
     }
@@ -340,8 +360,12 @@ static void rotmat(const double q[4], double R[3][3]) {   // columns = q * e_j
     for (int j = 0; j < 3; ++j) { double e[3] = {0, 0, 0}; e[j] = 1; double c[3]; qrot(q, e, c); for (int i = 0; i < 3; ++i) R[i][j] = c[i]; }
 }
 
-static int user_jacobian(const OModel& M, const double* x, const double* u, double /*t*/, double* J) {
+static int user_jacobian(const OModel& M, const double* x, const double* u, double t, double* J) {
     int n = M.n, m = M.m; for (int i = 0; i < n * (n + m); ++i) J[i] = 0;
+    if (M.kind == M_TV_PENDULUM) {   // A(t) = [0 1; -(a + b cos wt) cos th, -c], B = [0; 1]
+        JJ(0, 1) = 1.0; JJ(1, 0) = -((M.p[0] + M.p[1] * std::cos(M.p[2] * t)) * std::cos(x[0])); JJ(1, 1) = -M.p[3]; JJ(1, 2) = 1.0;
+        return 0;
+    }
     if (M.kind == M_CARTPOLE) {   // test/cartpole_model.jl:57-96
         double mc = M.p[0], mp = M.p[1], l = M.p[2], g = M.p[3];
         double s = std::sin(x[1]), c = std::cos(x[1]); double qd[2] = {x[2], x[3]};
@@ -366,7 +390,7 @@ static int user_jacobian(const OModel& M, const double* x, const double* u, doub
         const double* A = M.p + 2; const double* B = A + n * n;
         for (int i = 0; i < n * n; ++i) J[i] = A[i]; for (int i = 0; i < n * m; ++i) J[n * n + i] = B[i]; return 0;
     }
-    if (M.kind == M_SATELLITE || M.kind == M_QUADROTOR) {
+    if (M.kind == M_SATELLITE || M.kind == M_QUADROTOR || M.kind == M_TV_SATELLITE) {      // (the test model's disturbance is additive: same Jacobian)
         // src/rigidbody.jl:260-313 (formulas; the reference method itself references an undefined `z`
         // at :278 and cannot run -- the formulas below are its intended content with the wrench
         // Jacobian supplied analytically: examples/single_satellite.jl:49-61 for the satellite).
@@ -375,8 +399,8 @@ static int user_jacobian(const OModel& M, const double* x, const double* u, doub
         double Fw[3], Tw[3];
         double Wj[6][MAXZ]; for (int i = 0; i < 6; ++i) for (int j = 0; j < n + m; ++j) Wj[i][j] = 0;
         double Rq[3][3]; rotmat(q, Rq);
-        if (M.kind == M_SATELLITE) {
-            wrench_satellite(M, x, u, Fw, Tw);
+        if (M.kind == M_SATELLITE || M.kind == M_TV_SATELLITE) {
+            if (M.kind == M_TV_SATELLITE) wrench_tv_satellite(M, x, u, t, Fw, Tw); else wrench_satellite(M, x, u, Fw, Tw);
             double Gr[3][4]; grad_rotate(q, u, Gr);
             for (int i = 0; i < 3; ++i) { for (int j = 0; j < 4; ++j) Wj[i][3 + j] = Gr[i][j]; for (int j = 0; j < 3; ++j) Wj[i][13 + j] = Rq[i][j]; Wj[3 + i][16 + i] = 1.0; }
         } else {
@@ -534,7 +558,7 @@ static int lie_vec_first(const OLie& s, int i) { int a = 0; for (int k = 0; k < 
 static int model_lie(const OModel& M, OLie* s) {
     s->rot = M.rot;
     switch (M.kind) {
-        case M_SATELLITE: case M_QUADROTOR: s->nP = 2; s->P[0] = 3; s->P[1] = 6; return 1;   // src/rigidbody.jl:48
+        case M_SATELLITE: case M_QUADROTOR: case M_TV_SATELLITE: s->nP = 2; s->P[0] = 3; s->P[1] = 6; return 1;   // src/rigidbody.jl:48
         case M_SATELLITE_PAIR: s->nP = 3; s->P[0] = 0; s->P[1] = 3; s->P[2] = 3; return 1;     // examples/satellite_pair.jl:40
         case M_LIE_SATELLITE: s->nP = 2; s->P[0] = 3; s->P[1] = 0; return 1;                  // test/liemodel.jl:12
         default: return 0;   // EuclideanState
@@ -560,6 +584,8 @@ int oracle_model_init(OModel* M, int kind, int rot, int frame, const double* par
         case M_QUADROTOR: M->n = 9 + rp; M->m = 4; break;
         case M_SATELLITE_PAIR: M->n = 2 * rp + 6; M->m = 6; break;
         case M_LIE_SATELLITE: M->n = 3 + rp; M->m = 3; break;
+        case M_TV_PENDULUM: M->n = 2; M->m = 1; break;
+        case M_TV_SATELLITE: M->n = 9 + rp; M->m = 6; break;
         default: return -1;
     }
     if (M->n > MAXN || M->m > MAXM) return -1;
@@ -723,7 +749,9 @@ static void implicit_midpoint_parts(const OModel& M, const double* x1, const dou
     double zm[MAXZ], Jc[MAXN * MAXZ], f[MAXN];
     for (int i = 0; i < n; ++i) zm[i] = (x1[i] + x2[i]) / 2;
     for (int i = 0; i < M.m; ++i) zm[n + i] = u1[i];
-    jac_table()[nz](M, -1, 0, zm, t + h / 2, h, Jc, f);
+    // the residual evaluates the dynamics at t + h/2 (src/integration.jl:640,659), its Jacobians take the continuous Jacobian at t (:684,:716)
+    jac_table()[nz](M, -1, 0, zm, t, h, Jc, f);
+    dynamics(M, zm, zm + n, t + h / 2, f);
     for (int i = 0; i < n; ++i) e[i] = x1[i] + h * f[i] - x2[i];
     for (int j = 0; j < nz; ++j) for (int i = 0; i < n; ++i) {
         const double a = Jc[i + j * n] * h;

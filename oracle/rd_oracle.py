@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "librd_oracle.so")
 
 # enums -- numerically identical to include/rdhip.h
 CARTPOLE, DOUBLE_INTEGRATOR, LINEAR, SATELLITE, QUADROTOR, SATELLITE_PAIR, LIE_SATELLITE = range(7)
+TV_PENDULUM, TV_SATELLITE = 8, 9     # explicitly time-dependent test models (oracle only; the product runs them as user-defined models)
 ROT_QUAT, ROT_MRP, ROT_RP = range(3)
 FRAME_WORLD, FRAME_BODY = range(2)
 EULER, RK2, RK3, RK4 = range(4)
@@ -307,3 +308,11 @@ def satellite_pair(J1=np.eye(3), J2=2 * np.eye(3)):   # examples/satellite_pair.
 
 def lie_satellite(Jd=(1.0, 1.0, 1.0)):   # test/liemodel.jl:5
     return Model(LIE_SATELLITE, list(Jd))
+
+
+def tv_pendulum(a=9.81, b=2.0, w=3.0, c=0.1):   # test model: thdd = -(a + b cos wt) sin th - c thd + u + b sin wt
+    return Model(TV_PENDULUM, [a, b, w, c])
+
+
+def tv_satellite(mass=2.0, J=np.diag([2.0, 3.0, 1.0]), fd=0.7, td=0.4, w=2.5, frame=FRAME_WORLD):   # test model: the `Body` satellite + a time-dependent disturbance wrench
+    return Model(TV_SATELLITE, np.concatenate([[mass], np.asarray(J, float).flatten(order="F"), [fd, td, w]]), frame=frame)

@@ -21,7 +21,7 @@ struct rdhip_ctx {
     bool own_stream;
     hipEvent_t ev0, ev1;
     bool capturing = false;               // between rdhip_graph_begin_capture and rdhip_graph_end_capture
-    int* d_flag = nullptr;                // device word "a row exchange was needed" of the implicit kernels (allocated on first use)
+    int* d_flag = nullptr;                // device words "a row exchange was needed" of the implicit kernels (allocated with the context: never inside a capture)
     std::string err;
     // grow-only device workspace slots for RDHIP_HOST staging
     void* ws[8];
@@ -94,6 +94,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) { if (c->own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); else c->stream = (hipStream_t)stream; }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc(&c->d_flag, 256);
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
@@ -222,6 +223,7 @@ int rdhip_model_create_custom(int n, int m, const char* body, const char* preamb
     if (nparams < 0 || nparams > 64 || (nparams > 0 && !params)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad params (nparams=%d)", nparams);
     if (nP < 0 || nP > 8 || (nP > 0 && !P)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad LieState partition (nP=%d)", nP);
     if (nP > 0 && (rot < RDHIP_ROT_QUAT || rot > RDHIP_ROT_RP)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad rotation %d", rot);
+    if (nP - 1 > 4) return fail(nullptr, RDHIP_ERR_UNSUPPORTED, "a custom LieState may hold at most 4 rotations (got %d)", nP - 1);
     rdhip_model* M = new (std::nothrow) rdhip_model();
     if (!M) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
     ModelDesc& d = M->d; std::memset(&d, 0, sizeof d);
@@ -299,6 +301,9 @@ struct Stage {
     explicit Stage(rdhip_ctx* ctx) : c(ctx) {}
     void* reserve(size_t bytes) {
         if (rc) return nullptr;
+        // the grow-only workspace may hipMalloc / hipFree (illegal on a capturing thread) and a later call may free the slot a captured
+        // kernel would write to: a call that needs it cannot be recorded into a graph
+        if (c->capturing) { rc = fail(c, RDHIP_ERR_INVALID_ARG, "this call needs the context's internal workspace and cannot be captured into a graph: pass the optional output (Y) / 16-byte aligned buffers so that it does not"); return nullptr; }
         if (slot >= 8) { rc = fail(c, RDHIP_ERR_HIP, "staging slots exhausted"); return nullptr; }
         if (c->ws_bytes[slot] < bytes) {
             if (c->ws[slot]) (void)hipFree(c->ws[slot]);
@@ -396,7 +401,6 @@ static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype
     g_jit_model = nullptr;
     a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
     if (mode != 2) {     // Newton kernels: register pass + gated LDS pass communicate through a device word
-        if (!c->d_flag && hipMalloc(&c->d_flag, 256) != hipSuccess) { (void)hipGetLastError(); return RDHIP_ERR_HIP; }
         a.flag = c->d_flag;
     }
     switch (d.kind) {

@@ -175,7 +175,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     if (a.N == 0) return RDHIP_OK;
     const unsigned grid = (unsigned)((a.N + TILE - 1) / TILE);
     if (mode == 2) {
-        hipLaunchKernelGGL((implicit_midpoint_error_kernel<Mdl, T>), dim3(grid), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.dt, (T*)a.Y, (T*)a.J2, (T*)a.J);
+        hipLaunchKernelGGL((implicit_midpoint_error_kernel<Mdl, T>), dim3(grid), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J2, (T*)a.J);
         return hip_status(hipGetLastError());
     }
     constexpr size_t lds = ImplicitLds<Mdl, T>::BYTES;
@@ -191,11 +191,11 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     }
     if (mode == 3) {          // rollout: a.N trajectories of a.K knot points
         if (a.K == 0) return RDHIP_OK;
-        if (a.flag) hipLaunchKernelGGL((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
+        if (a.flag) hipLaunchKernelGGL((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_rollout_kernel<Mdl, T>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {

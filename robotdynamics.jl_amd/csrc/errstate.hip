@@ -315,7 +315,9 @@ __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long lo
     for (int pass = 0; pass < 2; ++pass) {
         const T* src = pass == 0 ? X + k0 * ldx : X0 + k0 * ldx0;
         T* dst = pass == 0 ? xa : xb;
-        const int total = nk * (pass == 0 ? ldx : ldx0);
+        // the header only promises ld >= n: the last state of the array may be followed by fewer than ld - n valid elements, so the
+        // staged span ends with the last knot point's n-th entry, not with its full ld-wide column
+        const int total = (nk - 1) * (pass == 0 ? ldx : ldx0) + d.n;
         for (int base = 0; base < total; base += 4 * NB) {
             T r[4];
 #pragma unroll

@@ -1,8 +1,11 @@
 // implicit.hpp -- DiscretizedDynamics{ImplicitMidpoint}: batched Newton solve and implicit-function-theorem Jacobian.
 //   reference: src/integration.jl:620-729 (the scheme, its dynamics_error and Jacobians), :422-463 (Newton solve, StaticReturn flavour),
 //              :517-538 (jacobian! by the implicit function theorem), :585-605 (defaults: 10 iterations, tolerance 1e-12)
-//   e(x2; z1) = x1 + h f((x1 + x2)/2, u1) - x2        J2 = [(h/2) A - I, 0]        J1 = [I + (h/2) A, h B]        x_next: e = 0
-//   discrete Jacobian = -J2[:, 1:n] \ J1,  [A B] = continuous Jacobian at (xmid, u1)
+//   e(x2; z1) = x1 + h f((x1 + x2)/2, u1, t + h/2) - x2        J2 = [(h/2) A - I, 0]        J1 = [I + (h/2) A, h B]        x_next: e = 0
+//   discrete Jacobian = -J2[:, 1:n] \ J1,  [A B] = continuous Jacobian at (xmid, u1, t)
+// Time arguments exactly as the reference passes them: the residual evaluates the dynamics at t + h/2 (src/integration.jl:640,659), its
+// Jacobians evaluate the continuous Jacobian at t (src/integration.jl:684,716).  For time-invariant models (all of the reference's) the two
+// evaluations are the same expression and the compiler merges them.
 // One lane owns one knot point; its n x n Newton matrix lives in LDS (lane-private, odd stride -> conflict-free), because n*n
 // doubles do not fit a lane's registers.  LU with partial pivoting like `lu`; right-hand sides stay in registers (compile-time
 // indices, row swaps by select).  Continuous Jacobian columns are matrix-free forward-dual JVPs of the model.  This kernel is
@@ -31,25 +34,26 @@ template <class Mdl, class T> struct ImplicitLds {
 template <class Mdl, class T> struct ImplicitOps {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU;
     using D = Dual<T, 1>;
-    // f(xm, u) and one column of the continuous Jacobian (direction e_c of z = [x; u])
-    template <int C> static RD_DEV void jcol(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T (&col)[NX], T (&f)[NX]) {
+    // one column of the continuous Jacobian at time tj (direction e_c of z = [x; u])
+    template <int C> static RD_DEV void jcol(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T (&col)[NX]) {
         D xd[NX], ud[NU], fd[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xd[i].v = xm[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
 #pragma unroll
         for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
-        m.f(xd, ud, fd);
+        model_f(m, xd, ud, tj, fd);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { col[i] = fd[i].d[0]; f[i] = fd[i].v; }
+        for (int i = 0; i < NX; ++i) col[i] = fd[i].d[0];
     }
-    // A2 = (h/2) A - I into the lane's LDS matrix (column-major), residual e = x1 + h f - x2
-    template <int C> static RD_DEV void fill_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T* A, T (&f)[NX]) {
+    // A2 = (h/2) A - I into the lane's LDS matrix (column-major); f = the dynamics at (xm, u, tm) for the residual e = x1 + h f - x2
+    template <int C> static RD_DEV void fill_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T tm, T h, T* A, T (&f)[NX]) {
+        if constexpr (C == 0) model_f(m, xm, u, tm, f);
         if constexpr (C < NX) {
             T col[NX];
-            jcol<C>(m, xm, u, col, f);
+            jcol<C>(m, xm, u, tj, col);
 #pragma unroll
             for (int i = 0; i < NX; ++i) A[i + C * NX] = col[i] * (h * T(0.5)) - ((i == C) ? T(1) : T(0));
-            fill_cols<C + 1>(m, xm, u, h, A, f);
+            fill_cols<C + 1>(m, xm, u, tj, tm, h, A, f);
         }
     }
     // in-place LU with partial pivoting of the lane's matrix; pivots into piv[0..NX).  Fully unrolled over the elimination step K: only
@@ -145,20 +149,19 @@ template <class Mdl, class T> struct ImplicitOps {
         }
     }
     // IFT columns: J[:, C] = -A2^{-1} J1[:, C],  J1 = [I + (h/2) A, h B]; groups of up to 4 columns per solve
-    template <int C, int G> static RD_DEV void ift_rhs(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T (&b)[G][NX]) {
+    template <int C, int G> static RD_DEV void ift_rhs(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, T (&b)[G][NX]) {
         if constexpr (C % 4 < G) {      // (C - C0) < G, groups start at multiples of 4
-            T f[NX];
-            jcol<C>(m, xm, u, b[C % 4], f);
+            jcol<C>(m, xm, u, tj, b[C % 4]);
 #pragma unroll
             for (int i = 0; i < NX; ++i) b[C % 4][i] = (C < NX) ? b[C % 4][i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : b[C % 4][i] * h;
-            if constexpr (C % 4 + 1 < G) ift_rhs<C + 1, G>(m, xm, u, h, b);
+            if constexpr (C % 4 + 1 < G) ift_rhs<C + 1, G>(m, xm, u, tj, h, b);
         }
     }
-    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, T* A, const int* piv, T* Jk, bool store) {
+    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, bool term, T* A, const int* piv, T* Jk, bool store) {
         if constexpr (C < NX + NU) {
             constexpr int G = (NX + NU - C) < 4 ? (NX + NU - C) : 4;
             T b[G][NX];
-            ift_rhs<C, G>(m, xm, u, h, b);
+            ift_rhs<C, G>(m, xm, u, tj, h, b);
             solve_multi<G>(A, piv, b);
             if (store) {
 #pragma unroll
@@ -168,7 +171,7 @@ template <class Mdl, class T> struct ImplicitOps {
                     for (int i = 0; i < NX; ++i) Jk[(C + g) * NX + i] = b[g][i] * sc;
                 }
             }
-            ift_cols<C + 4>(m, xm, u, h, term, A, piv, Jk, store);
+            ift_cols<C + 4>(m, xm, u, tj, h, term, A, piv, Jk, store);
         }
     }
 };
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
     const bool active = k < N;
     const long long kc = active ? k : N - 1;
     const double hd = dtt[kc];
-    const T h = (T)hd;
+    const T h = (T)hd, tj = (T)tt[kc], tm = tj + h * T(0.5);
     const bool term = is_terminal_dt(hd);
     T x1[NX], u[NU], xn[NX], xl[NX], xm[NX], f[NX], r[NX];
 #pragma unroll
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
         // residual and Newton matrix at the last tested iterate xl (recomputed, unchanged, for lanes that are already done)
 #pragma unroll
         for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
-        Ops::template fill_cols<0>(m, xm, u, h, A, f);
+        Ops::template fill_cols<0>(m, xm, u, tj, tm, h, A, f);
         T nr = T(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
@@ -226,9 +229,9 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
         // Jacobians at the last TESTED iterate (what the reference's cache holds when the loop exits)
 #pragma unroll
         for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
-        Ops::template fill_cols<0>(m, xm, u, h, A, f);
+        Ops::template fill_cols<0>(m, xm, u, tj, tm, h, A, f);
         Ops::lu(A, piv);
-        Ops::template ift_cols<0>(m, xm, u, h, term, A, piv, J + kc * NX * NZ, active);
+        Ops::template ift_cols<0>(m, xm, u, tj, h, term, A, piv, J + kc * NX * NZ, active);
     }
 }
 
@@ -242,13 +245,14 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
 template <class Mdl, class T> struct ImplicitRegOps {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU;
     using Ops = ImplicitOps<Mdl, T>;
-    template <int C> static RD_DEV void fill(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, T (&a)[NX][NX], T (&f)[NX]) {
+    template <int C> static RD_DEV void fill(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T tm, T h, T (&a)[NX][NX], T (&f)[NX]) {
+        if constexpr (C == 0) model_f(m, xm, u, tm, f);
         if constexpr (C < NX) {
             T col[NX];
-            Ops::template jcol<C>(m, xm, u, col, f);
+            Ops::template jcol<C>(m, xm, u, tj, col);
 #pragma unroll
             for (int i = 0; i < NX; ++i) a[i][C] = col[i] * (h * T(0.5)) - ((i == C) ? T(1) : T(0));
-            fill<C + 1>(m, xm, u, h, a, f);
+            fill<C + 1>(m, xm, u, tj, tm, h, a, f);
         }
     }
     // Small matrices (n <= 6: cartpole, double integrators, the linear test systems) carry partial pivoting in registers: the row exchange
@@ -309,7 +313,8 @@ template <class Mdl, class T> struct ImplicitRegOps {
         }
     }
     // one Newton solve from x1 (src/integration.jl:422-463): xn = solution, xl = last tested iterate; true if a row exchange was needed
-    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX]) {
+    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX]) {
+        const T tm = tj + h * T(0.5);
         T xm[NX], f[NX], r[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xn[i] = x1[i]; xl[i] = x1[i]; }
@@ -322,7 +327,7 @@ template <class Mdl, class T> struct ImplicitRegOps {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
             T a[NX][NX];
-            fill<0>(m, xm, u, h, a, f);
+            fill<0>(m, xm, u, tj, tm, h, a, f);
             T nr = T(0);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
@@ -344,11 +349,11 @@ template <class Mdl, class T> struct ImplicitRegOps {
     // 64 different cache lines (that was half of the kernel's time); transposed, one store instruction writes the columns of 64 / CW knot
     // points as runs of n consecutive values.  J0 = the wave's first Jacobian, nk = its number of valid knot points.
     static constexpr int CW = NX <= 8 ? 8 : 16;                      // lanes per knot point in the store sweep
-    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX],
+    template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX],
                                                  T* sb, T* J0, int nk) {
         if constexpr (C < NX + NU) {
-            T col[NX], f[NX];
-            Ops::template jcol<C>(m, xm, u, col, f);
+            T col[NX];
+            Ops::template jcol<C>(m, xm, u, tj, col);
 #pragma unroll
             for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
             solve(a, piv, col);
@@ -364,7 +369,7 @@ template <class Mdl, class T> struct ImplicitRegOps {
                 if (e < NX && kk < nk) J0[(size_t)kk * NX * (NX + NU) + C * NX + e] = sb[kk * NX + e];
             }
             wave_sync();
-            ift_cols<C + 1>(m, xm, u, h, term, a, piv, sb, J0, nk);
+            ift_cols<C + 1>(m, xm, u, tj, h, term, a, piv, sb, J0, nk);
         }
     }
 };
@@ -378,14 +383,14 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long
     const bool active = k < N;
     const long long kc = active ? k : N - 1;
     const double hd = dtt[kc];
-    const T h = (T)hd;
+    const T h = (T)hd, tj = (T)tt[kc];
     const bool term = is_terminal_dt(hd);
     T x1[NX], u[NU], xn[NX], xl[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x1[i] = Z[kc * NZ + i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[kc * NZ + NX + i];
-    bool need = R::newton(m, x1, u, h, newton_iters, tol, xn, xl);
+    bool need = R::newton(m, x1, u, tj, h, newton_iters, tol, xn, xl);
     if (active) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) Xn[k * NX + i] = xn[i];
@@ -396,17 +401,17 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long
 #pragma unroll
         for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
         int piv[NX];
-        R::template fill<0>(m, xm, u, h, a, f);
+        R::template fill<0>(m, xm, u, tj, tj + h * T(0.5), h, a, f);
         need = R::lu(a, piv) || need;
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_reg[];
         const long long k0 = (long long)blockIdx.x * TILE;
-        R::template ift_cols<0>(m, xm, u, h, term, a, piv, reinterpret_cast<T*>(smem_reg), J + k0 * NX * NZ, (int)((N - k0) < TILE ? (N - k0) : TILE));
+        R::template ift_cols<0>(m, xm, u, tj, h, term, a, piv, reinterpret_cast<T*>(smem_reg), J + k0 * NX * NZ, (int)((N - k0) < TILE ? (N - k0) : TILE));
     }
     if (need && flag) *flag = 1;
 }
 
 template <class Mdl, class T>
-__global__ void __launch_bounds__(TILE) implicit_rollout_reg_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ dtt,
+__global__ void __launch_bounds__(TILE) implicit_rollout_reg_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                                     const T* __restrict__ X0, int newton_iters, double tol, int* __restrict__ flag) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using R = ImplicitRegOps<Mdl, T>;
@@ -426,7 +431,7 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_reg_kernel(Mdl m, long 
         const double hd = dtt[jc * K + k - 1];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(hd) ? T(0) : Zj[(k - 1) * NZ + NX + i];
-        need = R::newton(m, x1, u, (T)hd, newton_iters, tol, xn, xl) || need;
+        need = R::newton(m, x1, u, (T)tt[jc * K + k - 1], (T)hd, newton_iters, tol, xn, xl) || need;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x1[i] = xn[i]; if (active) Zj[k * NZ + i] = xn[i]; }
     }
@@ -434,12 +439,13 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_reg_kernel(Mdl m, long 
 }
 
 template <class Mdl, class T, int C>
-RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&u)[Mdl::NU], const T (&x1)[Mdl::NX], const T (&x2)[Mdl::NX], T h, T* e, T* j2, T* j1) {
+RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&u)[Mdl::NU], const T (&x1)[Mdl::NX], const T (&x2)[Mdl::NX], T tj, T h, T* e, T* j2, T* j1) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     if constexpr (C < NX + NU) {
-        T col[NX], f[NX];
-        ImplicitOps<Mdl, T>::template jcol<C>(m, xm, u, col, f);
+        T col[NX];
+        ImplicitOps<Mdl, T>::template jcol<C>(m, xm, u, tj, col);
         if (C == 0 && e) {
+            T f[NX]; model_f(m, xm, u, tj + h * T(0.5), f);
 #pragma unroll
             for (int i = 0; i < NX; ++i) e[i] = x1[i] + h * f[i] - x2[i];
         }
@@ -449,14 +455,14 @@ RD_DEV void implicit_error_cols(const Mdl& m, const T (&xm)[Mdl::NX], const T (&
             if (C < NX) { if (j1) j1[C * NX + i] = a * T(0.5) + ((i == C) ? T(1) : T(0)); if (j2) j2[C * NX + i] = a * T(0.5) - ((i == C) ? T(1) : T(0)); }
             else { if (j1) j1[C * NX + i] = a; if (j2) j2[C * NX + i] = T(0); }
         }
-        implicit_error_cols<Mdl, T, C + 1>(m, xm, u, x1, x2, h, e, j2, j1);
+        implicit_error_cols<Mdl, T, C + 1>(m, xm, u, x1, x2, tj, h, e, j2, j1);
     }
 }
 
 // rollout!(sig, DiscretizedDynamics{ImplicitMidpoint}(model), Z, x0): one lane per trajectory, a Newton solve per step
 // (src/trajectories.jl:436-441 over src/integration.jl:422-463).  Z: (n+m) x K x M, states of knots 2..K overwritten in place.
 template <class Mdl, class T>
-__global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ dtt,
+__global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long K, long long M, T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                                 const T* __restrict__ X0, int newton_iters, double tol, const int* __restrict__ gate) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
@@ -480,7 +486,7 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long
     }
     for (long long k = 1; k < K; ++k) {
         const double hd = dtt[jc * K + k - 1];
-        const T h = (T)hd;
+        const T h = (T)hd, tj = (T)tt[jc * K + k - 1], tm = tj + h * T(0.5);
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(hd) ? T(0) : Zj[(k - 1) * NZ + NX + i];
 #pragma unroll
@@ -493,7 +499,7 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long
             }
 #pragma unroll
             for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xl[i]) * T(0.5);
-            Ops::template fill_cols<0>(m, xm, u, h, A, f);
+            Ops::template fill_cols<0>(m, xm, u, tj, tm, h, A, f);
             T nr = T(0);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { r[i] = x1[i] + h * f[i] - xl[i]; nr += r[i] * r[i]; }
@@ -513,13 +519,13 @@ __global__ void __launch_bounds__(TILE) implicit_rollout_kernel(Mdl m, long long
 
 // dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for the pairs (Z[k], Z[k+1]) (src/integration.jl:631-690)
 template <class Mdl, class T>
-__global__ void __launch_bounds__(TILE) implicit_midpoint_error_kernel(Mdl m, long long P, const T* __restrict__ Z, const double* __restrict__ dtt,
+__global__ void __launch_bounds__(TILE) implicit_midpoint_error_kernel(Mdl m, long long P, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                                        T* __restrict__ E, T* __restrict__ J2, T* __restrict__ J1) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     const long long k = (long long)blockIdx.x * TILE + threadIdx.x;
     if (k >= P) return;
     const double hd = dtt[k];
-    const T h = (T)hd;
+    const T h = (T)hd, tj = (T)tt[k];
     const bool term = is_terminal_dt(hd);
     T x1[NX], x2[NX], u[NU], xm[NX];
 #pragma unroll
@@ -527,11 +533,11 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_error_kernel(Mdl m, lo
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[k * NZ + NX + i];
     if (E && !J1 && !J2) {
-        T f[NX]; m.f(xm, u, f);
+        T f[NX]; model_f(m, xm, u, tj + h * T(0.5), f);
 #pragma unroll
         for (int i = 0; i < NX; ++i) E[k * NX + i] = x1[i] + h * f[i] - x2[i];
         return;
     }
-    implicit_error_cols<Mdl, T, 0>(m, xm, u, x1, x2, h, E ? E + k * NX : nullptr, J2 ? J2 + k * NX * NZ : nullptr, J1 ? J1 + k * NX * NZ : nullptr);
+    implicit_error_cols<Mdl, T, 0>(m, xm, u, x1, x2, tj, h, E ? E + k * NX : nullptr, J2 ? J2 + k * NX * NZ : nullptr, J1 ? J1 + k * NX * NZ : nullptr);
 }
 }  // namespace rd

@@ -4,8 +4,8 @@
 // `forces` / `moments`, src/rigidbody.jl:244-258).  Julia cannot be compiled for the GPU here, so a custom model is given as the
 // BODY of a HIP device function, written once on a generic scalar type S:
 //
-//     template <class S> __device__ void f(const S* x, const S* u, S* xdot) const   // p[] = the model's parameters (type T)
-//     { <body> }
+//     template <class S> __device__ void f(const S* x, const S* u, T t, S* xdot) const   // p[] = the model's parameters (type T),
+//     { <body> }                                                                         // t = the time the dynamics are evaluated at
 //
 // and the library JIT-compiles the same kernel templates the compiled-in models use (kernels.hpp, embedded at build time) for
 // that model with hipRTC: `S` becomes T for evaluation and Dual<T,K> for ForwardAD / the chain rule, so every rule (Euler, RK2,
@@ -37,7 +37,8 @@ struct JitModel {
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;        // key -> code object (device independent)
     std::map<std::string, std::string> lowered;
-    std::map<std::string, JitKernel> loaded;              // key@device -> loaded function
+    std::map<std::string, JitKernel> loaded;              // key@device -> loaded function (entries are never erased while the model lives: launches use them outside the lock)
+    int generation = 0;                                   // jit_balance re-keys the entries it replaces ("retired<generation>:..."): their modules stay loaded until the model is destroyed
     std::string err;
     std::vector<int> plan_wave;                           // column -> compute wave (after jit_balance); empty: contiguous ranges
     int plan_value_wave = 0;
@@ -60,7 +61,8 @@ static std::string program_source(const JitModel& M) {
       << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
       << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    static constexpr int NROT = " << M.rot_starts.size() << ";\n"
       << "    static constexpr int rot_start(int r) { " << rot_start_expr(M) << " }\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
-      << "    template <class S> RD_DEV void f(const S* x, const S* u, S* xdot) const {\n" << M.body << "\n    }\n};\n}\n";
+      // the body sits in an inner block: a body written for the time-invariant signature may declare its own `t`
+      << "    template <class S> RD_DEV void f(const S* x, const S* u, T t, S* xdot) const {\n        (void)t;\n        {\n" << M.body << "\n        }\n    }\n};\n}\n";
     return s.str();
 }
 static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
@@ -126,6 +128,8 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     return s.str();
 }
 
+static const char* jit_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize", "-DRDHIP_RTC=1"};
+
 // ---- optional on-disk cache of compiled kernels (RDHIP_CACHE_DIR): a solver process pays the 2-5 s per kernel once, not per run ----
 static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
@@ -138,6 +142,7 @@ static std::string cache_path(const std::string& src, const std::string& expr) {
     h = fnv1a(expr, h);
     for (int i = 0; i < rdhip_embedded_count; ++i) h = fnv1a(rdhip_embedded_sources[i], h);      // the kernel templates themselves
     h = fnv1a(std::to_string(HIP_VERSION), h);
+    for (const char* o : jit_opts) h = fnv1a(o, h);                                                  // the compile options
     char name[40]; snprintf(name, sizeof name, "/rdhip_%016llx.co", (unsigned long long)h);
     return std::string(dir) + name;
 }
@@ -177,8 +182,7 @@ static int jit_compile(JitModel& M, int op, int rule, int dtype, const std::stri
         M.err = "hiprtcCreateProgram failed"; return RDHIP_ERR_HIP;
     }
     hiprtcAddNameExpression(prog, expr.c_str());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize", "-DRDHIP_RTC=1"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof jit_opts / sizeof jit_opts[0]), jit_opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
         std::string log(ls, ' '); if (ls) hiprtcGetProgramLog(prog, &log[0]);
@@ -272,8 +276,17 @@ int jit_balance(void* h) {
     int vw = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[vw]) vw = i;
     M.plan_value_wave = vw;
     // kernels compiled with the old plan are stale
-    for (auto& kv : M.loaded) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
-    M.loaded.clear(); M.code.clear(); M.lowered.clear();
+    // (not unloaded here: jit_get hands out JitKernel pointers that are launched after the model lock is released, e.g. by the host threads
+    // of rdhip_jacobian_sharded; the stale entries are kept under a retired key and their modules are unloaded with the model)
+    ++M.generation;
+    std::vector<std::string> keys;
+    for (auto& kv : M.loaded) if (kv.first.compare(0, 7, "retired") != 0) keys.push_back(kv.first);
+    for (const std::string& k : keys) {          // re-key the map NODE (extract / insert keeps the JitKernel at its address)
+        auto nh = M.loaded.extract(k);
+        nh.key() = "retired" + std::to_string(M.generation) + ":" + k;
+        M.loaded.insert(std::move(nh));
+    }
+    M.code.clear(); M.lowered.clear();
     return RDHIP_OK;
 }
 
@@ -288,7 +301,7 @@ void* jit_model_create(int n, int m, const char* body, const char* preamble, con
 void jit_model_destroy(void* h) {
     JitModel* M = static_cast<JitModel*>(h);
     if (!M) return;
-    for (auto& kv : M->loaded) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    for (auto& kv : M->loaded) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);     // (retired entries included: they stay in `loaded` under a retired key)
     delete M;
 }
 const char* jit_last_error(void* h) { return static_cast<JitModel*>(h)->err.c_str(); }
@@ -374,7 +387,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     long long N = a.N, K = a.K; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* Y = a.Y; void* J = a.J; void* J2 = a.J2; const void* X0 = a.X0;
     int iters = a.newton_iters; double tol = a.newton_tol; void* nul = nullptr;
     const unsigned grid = (unsigned)(mode == 2 ? (N + 63) / 64 : (N + k->knots - 1) / k->knots);
-    if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
+    if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
     // n <= 14: the register kernel first (exact for n <= 6, where it pivots in registers); the LDS kernel behind it gated on the flag
     const int* gate = nullptr;
     if (a.flag && M.n <= 14) {
@@ -382,12 +395,12 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
         int* flag = a.flag;
         if (M.n > 6 && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
         const unsigned gr = (unsigned)((N + 63) / 64);
-        if (mode == 3) { if (K == 0) return RDHIP_OK; void* ar[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
+        if (mode == 3) { if (K == 0) return RDHIP_OK; void* ar[] = {fn.data(), &K, &N, &Z, &t, &dt, &X0, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
         else { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
         if (rc || M.n <= 6) return rc;
         gate = flag;
     }
-    if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &dt, &X0, &iters, &tol, &gate}; return launch(M, k, grid, a.stream, args); }
+    if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &t, &dt, &X0, &iters, &tol, &gate}; return launch(M, k, grid, a.stream, args); }
     void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &gate};
     return launch(M, k, grid, a.stream, args);
 }

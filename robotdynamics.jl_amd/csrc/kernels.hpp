@@ -785,13 +785,13 @@ template <class Fn, class T, class Plan> struct ChainBody {
     static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, RULE = Fn::RULE_ID;
     using D = Dual<T, 1>;
     // (A w + B wu) at stage point xs
-    static RD_DEV void jvp(const Fn& fn, const T (&xs)[NX], const T (&u)[NU], const T (&w)[NX], const T (&wu)[NU], T (&o)[NX]) {
+    static RD_DEV void jvp(const Fn& fn, const T (&xs)[NX], const T (&u)[NU], T ts, const T (&w)[NX], const T (&wu)[NU], T (&o)[NX]) {
         D xd[NX], ud[NU], fd[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xd[i].v = xs[i]; xd[i].d[0] = w[i]; }
 #pragma unroll
         for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = wu[i]; }
-        fn.m.f(xd, ud, fd);
+        model_f(fn.m, xd, ud, ts, fd);
 #pragma unroll
         for (int i = 0; i < NX; ++i) o[i] = fd[i].d[0];
     }
@@ -801,16 +801,16 @@ template <class Fn, class T, class Plan> struct ChainBody {
         // stage points (StaticReturn form of the reference: k_i = f(.) h)
         T x2[NX], x3[NX], x4[NX], k1[NX], k2[NX], k3[NX];
         if constexpr (RULE != RULE_CONTINUOUS && RULE != RULE_EULER) {
-            fn.m.f(fr.x, fr.u, k1);
+            model_f(fn.m, fr.x, fr.u, fr.t, k1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; x2[i] = fr.x[i] + k1[i] * T(0.5); }
             if constexpr (RULE == RULE_RK3 || RULE == RULE_RK4) {
-                fn.m.f(x2, fr.u, k2);
+                model_f(fn.m, x2, fr.u, fr.t + h * T(0.5), k2);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; x3[i] = (RULE == RULE_RK3) ? fr.x[i] - k1[i] + k2[i] * T(2) : fr.x[i] + k2[i] * T(0.5); }
             }
             if constexpr (RULE == RULE_RK4) {
-                fn.m.f(x3, fr.u, k3);
+                model_f(fn.m, x3, fr.u, fr.t + h * T(0.5), k3);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x4[i] = fr.x[i] + k3[i] * h;
             }
@@ -826,7 +826,7 @@ template <class Fn, class T, class Plan> struct ChainBody {
             for (int i = 0; i < NX; ++i) w[i] = (i == c) ? T(1) : T(0);
 #pragma unroll
             for (int i = 0; i < NU; ++i) wu[i] = (NX + i == c && !fr.term) ? T(1) : T(0);   // terminal knot point: control columns are zero
-            jvp(fn, fr.x, fr.u, w, wu, d1);
+            jvp(fn, fr.x, fr.u, fr.t, w, wu, d1);
             if constexpr (RULE == RULE_CONTINUOUS) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) col[i] = d1[i];
@@ -836,23 +836,23 @@ template <class Fn, class T, class Plan> struct ChainBody {
             } else {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { d1[i] = d1[i] * h; ws[i] = w[i] + d1[i] * T(0.5); }
-                jvp(fn, x2, fr.u, ws, wu, d2);
+                jvp(fn, x2, fr.u, fr.t + h * T(0.5), ws, wu, d2);
                 if constexpr (RULE == RULE_RK2) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) col[i] = w[i] + d2[i] * h;
                 } else if constexpr (RULE == RULE_RK3) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] - d1[i] + d2[i] * T(2); }
-                    jvp(fn, x3, fr.u, ws, wu, d3);
+                    jvp(fn, x3, fr.u, fr.t + h, ws, wu, d3);
 #pragma unroll
                     for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(4) + d3[i] * h) / T(6);
                 } else {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] + d2[i] * T(0.5); }
-                    jvp(fn, x3, fr.u, ws, wu, d3);
+                    jvp(fn, x3, fr.u, fr.t + h * T(0.5), ws, wu, d3);
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { d3[i] = d3[i] * h; ws[i] = w[i] + d3[i]; }
-                    jvp(fn, x4, fr.u, ws, wu, d4);
+                    jvp(fn, x4, fr.u, fr.t + h, ws, wu, d4);
 #pragma unroll
                     for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(2) + d3[i] * T(2) + d4[i] * h) / T(6);
                 }
@@ -885,7 +885,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
                 for (int i = 0; i < NX; ++i) w[i] = (i == C) ? T(1) : T(0);
 #pragma unroll
                 for (int i = 0; i < NU; ++i) wu[i] = (NX + i == C) ? (fr.term ? T(0) : T(1)) : T(0);
-                CB::jvp(fn, fr.x, fr.u, w, wu, d1);
+                CB::jvp(fn, fr.x, fr.u, fr.t, w, wu, d1);
                 if constexpr (RULE == RULE_CONTINUOUS) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) col[i] = d1[i];
@@ -895,23 +895,23 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
                 } else {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { d1[i] = d1[i] * h; ws[i] = w[i] + d1[i] * T(0.5); }
-                    CB::jvp(fn, x2, fr.u, ws, wu, d2);
+                    CB::jvp(fn, x2, fr.u, fr.t + h * T(0.5), ws, wu, d2);
                     if constexpr (RULE == RULE_RK2) {
 #pragma unroll
                         for (int i = 0; i < NX; ++i) col[i] = w[i] + d2[i] * h;
                     } else if constexpr (RULE == RULE_RK3) {
 #pragma unroll
                         for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] - d1[i] + d2[i] * T(2); }
-                        CB::jvp(fn, x3, fr.u, ws, wu, d3);
+                        CB::jvp(fn, x3, fr.u, fr.t + h, ws, wu, d3);
 #pragma unroll
                         for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(4) + d3[i] * h) / T(6);
                     } else {
 #pragma unroll
                         for (int i = 0; i < NX; ++i) { d2[i] = d2[i] * h; ws[i] = w[i] + d2[i] * T(0.5); }
-                        CB::jvp(fn, x3, fr.u, ws, wu, d3);
+                        CB::jvp(fn, x3, fr.u, fr.t + h * T(0.5), ws, wu, d3);
 #pragma unroll
                         for (int i = 0; i < NX; ++i) { d3[i] = d3[i] * h; ws[i] = w[i] + d3[i]; }
-                        CB::jvp(fn, x4, fr.u, ws, wu, d4);
+                        CB::jvp(fn, x4, fr.u, fr.t + h, ws, wu, d4);
 #pragma unroll
                         for (int i = 0; i < NX; ++i) col[i] = w[i] + (d1[i] + d2[i] * T(2) + d3[i] * T(2) + d4[i] * h) / T(6);
                     }
@@ -938,16 +938,16 @@ template <class Fn, class T, class Plan> struct ChainUnrolledBody {
 #pragma unroll
         for (int i = 0; i < NX; ++i) x2[i] = x3[i] = x4[i] = fr.x[i];
         if constexpr (RULE != RULE_CONTINUOUS && RULE != RULE_EULER) {
-            fn.m.f(fr.x, fr.u, k1);
+            model_f(fn.m, fr.x, fr.u, fr.t, k1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; x2[i] = fr.x[i] + k1[i] * T(0.5); }
             if constexpr (RULE == RULE_RK3 || RULE == RULE_RK4) {
-                fn.m.f(x2, fr.u, k2);
+                model_f(fn.m, x2, fr.u, fr.t + h * T(0.5), k2);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { k2[i] = k2[i] * h; x3[i] = (RULE == RULE_RK3) ? fr.x[i] - k1[i] + k2[i] * T(2) : fr.x[i] + k2[i] * T(0.5); }
             }
             if constexpr (RULE == RULE_RK4) {
-                fn.m.f(x3, fr.u, k3);
+                model_f(fn.m, x3, fr.u, fr.t + h * T(0.5), k3);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x4[i] = fr.x[i] + k3[i] * h;
             }

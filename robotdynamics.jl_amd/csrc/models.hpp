@@ -243,9 +243,17 @@ template <class T_> struct LieSatellite {
     }
 };
 
+// ---- dynamics(model, x, u, t) ---------------------------------------------------------------------------------
+// A model defines either the time-invariant form f(x, u, xdot) -- every model of the reference's examples/ and test/ does; the
+// time argument is then dropped exactly as `dynamics(model, x, u, t) = dynamics(model, x, u)` drops it (src/dynamics.jl:83) -- or the
+// time-dependent form f(x, u, t, xdot) with t a plain T (time is not differentiated: ForwardDiff.jacobian differentiates w.r.t. z only).
+template <class M, class S, class T> RD_DEV auto model_f_(const M& m, const S* x, const S* u, T t, S* xd, int) -> decltype(m.f(x, u, t, xd), void()) { m.f(x, u, t, xd); }
+template <class M, class S, class T> RD_DEV void model_f_(const M& m, const S* x, const S* u, T, S* xd, long) { m.f(x, u, xd); }
+template <class M, class S, class T> RD_DEV void model_f(const M& m, const S* x, const S* u, T t, S* xd) { model_f_(m, x, u, t, xd, 0); }
+
 // ---- DiscretizedDynamics{RULE}(model): `evaluate(fun, z)` -------------------------------------------------
 // RULE_CONTINUOUS evaluates the continuous model.  The explicit rules follow the StaticReturn `integrate`
-// methods (k_i = f(.) * h ; x + k1/2 ...), src/integration.jl:130-135 and :280-286.
+// methods (k_i = f(.) * h ; x + k1/2 ...), src/integration.jl:130-135 and :280-286, stage times t, t + h/2, t + h included.
 template <class Mdl, int RULE> struct Fun {
     using T = typename Mdl::T;
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, RULE_ID = RULE;
@@ -253,31 +261,31 @@ template <class Mdl, int RULE> struct Fun {
     // kernel also needs the state of the following knot point
     static constexpr int NCOLS = Mdl::NX + Mdl::NU, NVAL = Mdl::NX, NEXT = 0;
     Mdl m;
-    template <class S> RD_DEV void eval(const S* x, const S* u, T /*t*/, T h, S* y) const {
+    template <class S> RD_DEV void eval(const S* x, const S* u, T t, T h, S* y) const {
         if constexpr (RULE == RULE_CONTINUOUS) {
-            m.f(x, u, y);
+            model_f(m, x, u, t, y);
         } else if constexpr (RULE == RULE_EULER) {
-            S k1[NX]; m.f(x, u, k1);
+            S k1[NX]; model_f(m, x, u, t, k1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x[i] + k1[i] * h;
         } else if constexpr (RULE == RULE_RK2) {
-            S k[NX], xs[NX]; m.f(x, u, k);
+            S k[NX], xs[NX]; model_f(m, x, u, t, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xs[i] = x[i] + k[i] * (h * T(0.5));
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h * T(0.5), k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x[i] + k[i] * h;
         } else if constexpr (RULE == RULE_RK3) {
             // x + (k1 + 4 k2 + k3)/6 accumulated left to right as the stages finish (same summation order as
             // the reference expression, src/integration.jl:134); keeps only {k1, acc, k, xs} live.
             S k1[NX], k[NX], acc[NX], xs[NX];
-            m.f(x, u, k1);
+            model_f(m, x, u, t, k1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x[i] + k1[i] * T(0.5); }
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h * T(0.5), k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = k1[i] + k[i] * T(4); xs[i] = x[i] - k1[i] + k[i] * T(2); }
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x[i] + (acc[i] + k[i] * h) * T(1.0 / 6.0);
         } else {
@@ -286,16 +294,16 @@ template <class Mdl, int RULE> struct Fun {
             // per tangent direction (differs from the literal order by rounding only); live set {acc, k, xs}
             S k[NX], acc[NX], xs[NX];
             const T h2 = h * T(0.5), h6 = h * T(1.0 / 6.0);
-            m.f(x, u, k);
+            model_f(m, x, u, t, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = x[i] + k[i] * h2; }
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h2, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { acc[i] = acc[i] + k[i] * T(2); xs[i] = x[i] + k[i] * h2; }
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h2, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { acc[i] = acc[i] + k[i] * T(2); xs[i] = x[i] + k[i] * h; }
-            m.f(xs, u, k);
+            model_f(m, xs, u, t + h, k);
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = x[i] + (acc[i] + k[i]) * h6;
         }

@@ -632,8 +632,10 @@ class CustomModel(ContinuousDynamics):
             "xdot[0] = x[1];"
             "xdot[1] = (u[0] - x[1] * p[2]) / (p[1] * p[1]) - sin_(x[0]) * (p[0] / p[1]);")
 
-    `x`, `u`, `xdot` are arrays of S, `p[i]` are the parameters (type T = float/double); use sin_, cos_, sqrt_, max0_ and the
-    arithmetic operators (they are defined for T and for forward duals, csrc/scalar.hpp).  The library JIT-compiles its kernel
+    `x`, `u`, `xdot` are arrays of S, `p[i]` are the parameters (type T = float/double), `t` (type T) is the time the dynamics are
+    evaluated at -- `dynamics(model, x, u, t)`: the knot point's time, or the stage times t, t + h/2, t + h inside the Runge-Kutta rules
+    (src/integration.jl:130-135,280-286); use sin_, cos_, sqrt_, max0_ and the arithmetic operators (they are defined for T and for
+    forward duals, csrc/scalar.hpp).  The library JIT-compiles its kernel
     templates for this model with hipRTC on first use (a few seconds per (operation, rule, dtype)), after which every operator
     of the compiled-in models works: dynamics, discrete_dynamics, jacobian! with ForwardAD / FiniteDifference / UserDefined,
     rollout!, dynamics_error, and -- with `liestate=(R, P)` as in LieState{R,P} -- the error-state operators."""
@@ -1568,6 +1570,22 @@ def propagate_dynamics_(sig, model, z2, z1):
     return None
 
 
+def _check_stack(data3, t2, dt2, nz):
+    """The dict form {"data", "t", "dt"} of a trajectory stack goes straight to the C ABI, which reads t / dt as `const double*` and
+    indexes `data` as a dense slab: enforce what PackedTrajectory enforces (float64 times, C-contiguous arrays of matching shapes)."""
+    if len(data3.shape) != 3 or data3.shape[2] != nz:
+        raise ValueError(f"trajectory stack: data must be (.., .., n+m = {nz}), got {tuple(data3.shape)}")
+    _dense(data3, tuple(data3.shape), "Z.data")
+    lead = tuple(data3.shape[:2])
+    for name, a in (("Z.t", t2), ("Z.dt", dt2)):
+        if _is_torch(a) != _is_torch(data3) and not (isinstance(a, np.ndarray) and isinstance(data3, np.ndarray)):
+            raise ValueError(f"{name}: must be the same kind of array as Z.data")
+        is64 = (a.dtype == torch.float64) if _is_torch(a) else (getattr(a, "dtype", None) == np.float64)
+        if not is64:
+            raise ValueError(f"{name}: times are always float64 (KnotPoint.t / .dt are Float64, src/knotpoint.jl:150-151), got {getattr(a, 'dtype', type(a))}")
+        _dense(a, lead, name)
+
+
 def rollout_(sig, model, Z, x0=None):
     """rollout!(sig, model, Z, x0): src/trajectories.jl:436-441.  Z is ONE PackedTrajectory (K knots) or a list /
     (M, K, n+m) stack of trajectories that share the kernel launch (sequential in k, parallel over trajectories)."""
@@ -1580,9 +1598,8 @@ def rollout_(sig, model, Z, x0=None):
         data3, t2, dt2 = Z.data, Z.t, Z.dt
     else:                       # {"data": (M, K, n+m), "t": (M, K), "dt": (M, K)}
         data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
+        _check_stack(data3, t2, dt2, state_dim(model) + control_dim(model))
         M, K = data3.shape[0], data3.shape[1]
-        if data3.shape[2] != state_dim(model) + control_dim(model):
-            raise ValueError("trajectory stack has the wrong knot-point length")
     x0a = x0
     if x0a is not None and not _is_torch(x0a):
         x0a = np.ascontiguousarray(np.asarray(x0a, dtype=data3.dtype if isinstance(data3, np.ndarray) else np.float64).reshape(M, -1))
@@ -1614,8 +1631,7 @@ def rollout_jacobian_(sig, diff, model, J, Z, x0=None, time_major=False):
         raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
     data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
     n, m = state_dim(model), control_dim(model)
-    if len(data3.shape) != 3 or data3.shape[2] != n + m or tuple(t2.shape) != tuple(data3.shape[:2]) or tuple(dt2.shape) != tuple(data3.shape[:2]):
-        raise ValueError("trajectory stack: data (.., .., n+m) with t, dt of the leading two dimensions")
+    _check_stack(data3, t2, dt2, n + m)
     K, M = (data3.shape[0], data3.shape[1]) if time_major else (data3.shape[1], data3.shape[0])
     x0a = x0
     if x0a is not None and not _is_torch(x0a):

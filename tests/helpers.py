@@ -51,4 +51,4 @@ def rand_rigid(rng, N, m, ulo=0.0, uhi=1.0):
     X = np.concatenate([rng.random((N, 3)), q, rng.random((N, 6))], axis=1)
     return np.concatenate([X, ulo + (uhi - ulo) * rng.random((N, m))], axis=1)
 
-from examples.custom_models import CARTPOLE_SRC, SATELLITE_SRC  # noqa: E402,F401
+from examples.custom_models import CARTPOLE_SRC, SATELLITE_SRC, TV_PENDULUM_SRC, TV_SATELLITE_SRC  # noqa: E402,F401

@@ -744,6 +744,72 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     np.testing.assert_allclose(host(stack["data"]), O.cartpole().rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
 
 
+def test_time_dependent_dynamics_receive_the_stage_times():
+    """dynamics(model, x, u, t): the time argument reaches every evaluation the way the reference passes it -- the knot point's t for the
+    continuous model, t / t + h/2 / t + h inside Euler, RK2, RK3, RK4 (src/integration.jl:73-83,130-135,280-286) and in the chain rule's
+    stage Jacobians (:149-177,:302-337), t + h/2 in the implicit-midpoint residual and t in its Jacobian (:640,:684).  The reference's own
+    models are time-invariant, so the check runs two explicitly time-dependent user-defined (hipRTC) models against the oracle's twins;
+    n + m = 3 takes the all-columns-per-lane kernels, n + m = 19 the split-role compile-time-column ones."""
+    rng = np.random.default_rng(77)
+    pend = RD.CustomModel(2, 1, H.TV_PENDULUM_SRC, params=(9.81, 2.0, 3.0, 0.1))
+    sat = RD.CustomModel(13, 6, H.TV_SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0, 0.7, 0.4, 2.5), liestate=(RD.QuatRotation, (3, 6)))
+    for model, om, Zn in ((pend, O.tv_pendulum(), rng.random((200, 3))), (sat, O.tv_satellite(), H.rand_rigid(rng, 150, 6))):
+        N = Zn.shape[0]
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        t, dt = 0.3 + np.arange(N) * 0.13, np.full(N, 0.07); dt[-1] = 0.0
+        Z = traj(model, Zn, t, dt, "cuda")
+        ref = om.dynamics(Zn, t, dt)
+        assert np.abs(ref - om.dynamics(Zn, 0 * t, dt)).max() > 1e-2             # the case does depend on t
+        np.testing.assert_allclose(host(RD.dynamics(model, Z)), ref, rtol=0, atol=TOL)
+        for Q, rule in ((RD.Euler, O.EULER), (RD.RK2, O.RK2), (RD.RK3, O.RK3), (RD.RK4, O.RK4)):
+            dm = RD.DiscretizedDynamics(model, Q)
+            np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), om.discrete_dynamics(rule, Zn, t, dt), rtol=0, atol=TOL)
+            J = RD.alloc_jacobians(dm, N, Z.data)
+            Y = torch.empty((N, n), dtype=torch.float64, device="cuda")
+            Jo, Yo = om.jacobian(rule, O.FORWARD_AD, Zn, t, dt)
+            for diff, tol in ((RD.ForwardAD(), TOL), (RD.UserDefined(), TOL), (RD.FiniteDifference(), 1e-6)):
+                J.fill_(3.0)
+                RD.jacobian_(RD.StaticReturn(), diff, dm, J, Y, Z)
+                np.testing.assert_allclose(host(J), Jo, rtol=0, atol=tol * max(1.0, np.abs(Jo).max()))
+                np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), om.dynamics_error(O.RK4, Zn, t, dt), rtol=0, atol=TOL)
+        if model is sat:                                                            # fused error-state expansion with a time-dependent model
+            E = RD.alloc_error_expansions(dm, N, Z.data)
+            RD.error_expansion_(dm, E, None, Z)
+            np.testing.assert_allclose(host(E), om.error_expansion(O.RK4, Zn, t, dt)[0], rtol=0, atol=TOL * 10)
+        # ImplicitMidpoint: Newton solve, IFT Jacobian, dynamics error and its Jacobians
+        dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+        Ji = RD.alloc_jacobians(dmi, N, Z.data)
+        Yi = torch.empty((N, n), dtype=torch.float64, device="cuda")
+        RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, Ji, Yi, Z)
+        Xo, Jio, _ = om.implicit_midpoint(Zn, t, dt)
+        np.testing.assert_allclose(host(Yi), Xo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(host(Ji), Jio, rtol=0, atol=1e-8 * max(1.0, np.abs(Jio).max()))
+        np.testing.assert_allclose(host(RD.discrete_dynamics(dmi, Z)), Xo, rtol=0, atol=1e-9)
+        Eo, J2o, J1o = om.implicit_midpoint_error(Zn, t, dt)
+        np.testing.assert_allclose(host(RD.dynamics_error(dmi, Z)), Eo, rtol=0, atol=TOL)
+        J2 = RD.alloc_jacobians(dmi, N - 1, Z.data); J1 = RD.alloc_jacobians(dmi, N - 1, Z.data)
+        RD.dynamics_error_jacobian_(RD.StaticReturn(), RD.ForwardAD(), dmi, J2, J1, None, None, Z)
+        np.testing.assert_allclose(host(J2), J2o, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(J1), J1o, rtol=0, atol=TOL)
+        # rollout: knot k advances with ITS time stamp
+        M, K = 7, 25
+        data = (rng.random((M, K, n + m)) if n == 2 else H.rand_rigid(rng, M * K, m).reshape(M, K, n + m))
+        tt = 0.2 + np.tile(np.arange(K) * 0.05, (M, 1)) + np.arange(M)[:, None] * 0.31
+        dd = np.full((M, K), 0.05)
+        for Q, rule in ((RD.RK4, O.RK4), (RD.RK3, O.RK3)):
+            stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+            RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(model, Q), stack)
+            np.testing.assert_allclose(host(stack["data"]), om.rollout(rule, data, tt, dd), rtol=0, atol=TOL)
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+        RD.rollout_(RD.StaticReturn(), dmi, stack)                                  # implicit rollout: a Newton solve per step at that step's time
+        Zr = data.copy()
+        for k in range(K - 1):
+            Zr[:, k + 1, :n] = om.implicit_midpoint(Zr[:, k, :], tt[:, k], dd[:, k], want_jacobian=False)[0]
+        np.testing.assert_allclose(host(stack["data"]), Zr, rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("name", ["cartpole", "satellite_world", "body_body", "satfull_world", "quadrotor_world", "satpair", "liesat"])
 @pytest.mark.parametrize("where", ["host", "cuda"])
 def test_golden_error_expansion_and_dynamics_error(name, where):

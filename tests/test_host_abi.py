@@ -246,6 +246,19 @@ def test_custom_model_jit_compiles_without_a_gpu():
     pair.precompile("error_expansion", RD.RK3, np.float32)   # two rotations (state indices 0 and 7)
     with pytest.raises(ValueError):
         RD.dims(RD.CustomModel(8, 3, "xdot[0] = u[0];", liestate=(RD.QuatRotation, (3, 0))))     # LieState length 7 != n
+    # time-dependent dynamics: `t` is available in the body (dynamics(model, x, u, t)); a body written for the time-invariant signature that
+    # declares its own `t` still compiles (it shadows the argument); every kernel family takes the time through
+    tv = RD.CustomModel(2, 1, H.TV_PENDULUM_SRC, params=(9.81, 2.0, 3.0, 0.1))
+    for what, rule in (("evaluate", RD.RK4), ("ForwardAD", RD.RK3), ("UserDefined", RD.RK4), ("FiniteDifference", RD.RK2), ("rollout", RD.RK4)):
+        tv.precompile(what, rule)
+    for op in (7, 8, 9, 10, 13, 14, 15):                                        # the ImplicitMidpoint kernels (LDS and register forms)
+        RD.lib().rdhip_model_precompile(tv._handle, op, 4, 0) == 0 or pytest.fail(RD.lib().rdhip_last_error(None).decode())
+    tvs = RD.CustomModel(13, 6, H.TV_SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0, 0.7, 0.4, 2.5), liestate=(RD.QuatRotation, (3, 6)))
+    tvs.precompile("ForwardAD", RD.RK4)
+    tvs.precompile("error_expansion", RD.RK4)
+    RD.CustomModel(2, 1, "const T t = p[0]; xdot[0] = x[1] * t; xdot[1] = u[0];", params=(2.0,)).precompile("evaluate", RD.RK4)
+    with pytest.raises(NotImplementedError):                                      # LieDesc tables hold 4 rotations
+        RD.dims(RD.CustomModel(16, 1, "xdot[0] = u[0];", liestate=(RD.MRP, (0, 0, 0, 0, 0, 1))))
 
 
 def test_jit_disk_cache_is_opt_in_and_survives_corruption(tmp_path, monkeypatch):
