@@ -171,6 +171,17 @@ int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, 
 int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                    const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);
 
+/* rdhip_jacobian over `nbatch` INDEPENDENT packed trajectories (different arrays; the per-knot loops of nbatch TrajectoryOptimization problems
+ * or multiple-shooting segments: `for p in problems, k in 1:N[p]; jacobian!(sig, diff, model, J[p][k], y, Z[p][k]); end`, src/functionbase.jl:242)
+ * in ONE kernel launch: N[b], Z[b], t[b], dt[b], J[b], Y[b] are the arguments rdhip_jacobian would take for batch b (Y or any Y[b] may be NULL).
+ * A trajectory of a few thousand knot points is launch-bound on its own; enumerated together by the same persistent tile loop, 16 x 4 096 knot
+ * points cost what one 65 536-knot batch costs.  The tables N / Z / t / dt / J / Y themselves are HOST arrays of nbatch entries (they travel in
+ * the kernel arguments and are not retained); memspace describes the data pointers inside them.  Fused for ForwardAD on the compiled-in models
+ * with device pointers (16-byte aligned J / Y for n + m > 10); every other combination runs the batches one rdhip_jacobian call at a time with
+ * the same results.  Batches must not overlap. */
+int rdhip_jacobian_multi(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, int nbatch, const long long* N,
+                         const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace);
+
 /* dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2) (src/discrete_dynamics.jl:134-135; in-place :146-156) for
  * the N-1 consecutive knot-point pairs (z1, z2) = (Z[k], Z[k+1]) of a packed trajectory: E[:, k] = f(z_k) - x_{k+1}, k = 0..N-2.
  * E: n x (N-1).  N < 2 is a no-op. */
@@ -250,6 +261,39 @@ int rdhip_shard_range(long long N, int nshards, int i, long long* begin, long lo
 int rdhip_jacobian_sharded(rdhip_ctx* const* ctxs, int nctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                            const void* Z, const double* t, const double* dt, void* J, void* Y);
 int rdhip_memcpy_peer(rdhip_ctx* dst_ctx, void* dst, rdhip_ctx* src_ctx, const void* src, unsigned long long bytes);
+
+/* ---- the one exchange: stacking device-resident result shards over RCCL / xGMI -------------------------------------------------------
+ * Evaluation never communicates (knot points are independent: rank r of P owns block rdhip_shard_range(N, P, r)); a caller that needs the
+ * STACKED Jacobians in one place pays this step.  A communicator has one rank per GPU and is driven either by ONE process
+ * (rdhip_comm_create: ranks 0..n-1 = the given contexts, ncclCommInitAll; the layout of a Julia host) or by one process per GPU
+ * (rdhip_comm_create_rank: rank 0 draws rdhip_comm_unique_id, the application hands the 128 bytes to the other processes -- MPI, a file,
+ * torch.distributed's store -- and every process joins with its own context; ncclCommInitRank).  librccl is dlopen()ed on first use
+ * (RDHIP_RCCL_LIB overrides the name); a 1-rank communicator never loads it.
+ *
+ * rdhip_gather(comm, mode, root, shard, bytes, out): `bytes[r]`, r = 0..nranks-1, is the shard size of EVERY rank (all processes pass the same
+ * table); `shard[l]` / `out[l]`, l = 0..nlocal-1, are the device buffers of the ranks this process drives (rdhip_comm_rank maps l to its rank).
+ * The stack is the concatenation of the shards in rank order.  RDHIP_GATHER_ROOT: out[l] of rank `root` receives it (other entries are ignored) --
+ * grouped ncclSend / ncclRecv, every shard on its own xGMI link into the root (RCCL has no gather primitive; a ring would serialise on single
+ * links); RDHIP_GATHER_ALL: every rank's out[l] receives it (ncclAllGather for equal shards, grouped send / recv otherwise); RDHIP_GATHER_NONE:
+ * no-op (results stay sharded for a sharded consumer).  Asynchronous: ordered on each rank's context stream behind the kernels that produce
+ * the shard; synchronise the receiving context(s) before reading.  A shard that already sits at its place inside out[l] is not copied.
+ * rdhip_jacobian_sharded_gather / rdhip_errstate_jacobian_sharded_gather = the per-rank device-memory call on each local rank's block
+ * (Z[l], t[l], dt[l], J[l], Y[l] / X[l], G[l] are that BLOCK's arrays, N is the TOTAL knot count) followed by rdhip_gather of J / G. */
+#define RDHIP_COMM_ID_BYTES 128
+typedef enum { RDHIP_GATHER_NONE = 0, RDHIP_GATHER_ROOT = 1, RDHIP_GATHER_ALL = 2 } rdhip_gather_mode;
+typedef struct rdhip_comm rdhip_comm;
+int rdhip_comm_create(rdhip_ctx* const* ctxs, int n, rdhip_comm** out);
+int rdhip_comm_unique_id(char id[RDHIP_COMM_ID_BYTES]);
+int rdhip_comm_create_rank(rdhip_ctx* ctx, int nranks, int rank, const char id[RDHIP_COMM_ID_BYTES], rdhip_comm** out);
+int rdhip_comm_destroy(rdhip_comm* comm);
+int rdhip_comm_size(const rdhip_comm* comm, int* nranks, int* nlocal);
+int rdhip_comm_rank(const rdhip_comm* comm, int local, int* rank, rdhip_ctx** ctx);
+int rdhip_gather(rdhip_comm* comm, int mode, int root, const void* const* shard, const unsigned long long* bytes, void* const* out);
+int rdhip_jacobian_sharded_gather(rdhip_comm* comm, const rdhip_model* model, int rule, int diff, int dtype, long long N,
+                                  const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y,
+                                  int gather, int root, void* const* Jstack);
+int rdhip_errstate_jacobian_sharded_gather(rdhip_comm* comm, const rdhip_model* model, int dtype, long long N, const void* const* X, int ldx, int clear,
+                                           void* const* G, int gather, int root, void* const* Gstack);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,10 @@ static int fail(rdhip_ctx* ctx, int code, const char* fmt, ...) {
 #define HIP_TRY(ctx, call)                                                                             \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RDHIP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// for comm.hip (the RCCL exchange lives in its own translation unit)
+int rdhip_ctx_device_(const rdhip_ctx* c) { return c->device; }
+void rdhip_ctx_set_error_(rdhip_ctx* c, const char* msg) { if (c) c->err = msg; g_err = msg; }
+
 static int rot_params(int rot) { return rot == RDHIP_ROT_QUAT ? 4 : 3; }   // src/liestate.jl:42-46
 
 static void build_lie(rdhip_model* M) {
@@ -460,6 +464,46 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
     if (implicit && !a.Y && N > 0) { a.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }     // the Newton solution has to land somewhere
     const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
+
+// jacobian! over several independent packed trajectories in one launch.  TrajectoryOptimization-sized problems hold 101 ... 4 096 knot points
+// per trajectory (examples/cartpole.jl:46): one such batch is launch-bound (9 MB of output takes 1.2 us at 8 TB/s, a launch ~8 us), sixteen of
+// them enumerated by one persistent tile loop are one bandwidth-regime launch.
+int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, int nbatch, const long long* N,
+                         const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace) {
+    const char* what = "rdhip_jacobian_multi";
+    int rc = check_common(c, M, dtype, 0, memspace); if (rc) return rc;
+    if (nbatch < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative nbatch", what);
+    if (nbatch == 0) return RDHIP_OK;
+    if (!N || !Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL table", what);
+    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
+    for (int b = 0; b < nbatch; ++b) {
+        if (N[b] < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has negative N", what, b);
+        if (N[b] > 0 && (!Z[b] || !t[b] || !dt[b] || !J[b])) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has a NULL data pointer", what, b);
+    }
+    rc = check_rotation(c, M); if (rc) return rc;
+    const ModelDesc& d = M->d;
+    bool fused = memspace == RDHIP_DEVICE && rule != RDHIP_IMPLICIT_MIDPOINT && d.kind != RDHIP_MODEL_CUSTOM;
+    for (int b0 = 0; fused && b0 < nbatch; b0 += 32) {          // the kernel-argument table holds 32 batches: more go out in groups
+        MultiDesc md{}; md.nb = 0;
+        for (int b = b0; b < nbatch && b < b0 + 32; ++b) {
+            if (N[b] == 0) continue;
+            const int i = md.nb++;
+            md.N[i] = N[b]; md.Z[i] = Z[b]; md.t[i] = t[b]; md.dt[i] = dt[b]; md.J[i] = J[b]; md.Y[i] = Y ? Y[b] : nullptr;
+        }
+        if (md.nb == 0) continue;
+        LaunchArgs a{}; a.stream = c->stream; a.multi = &md;
+        const int k = family_jacobian(d, rule, diff, dtype, a);
+        if (k == RDHIP_ERR_UNSUPPORTED && b0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff) or unaligned outputs
+        if (k) return kernel_status(c, k, what);
+    }
+    if (fused) return RDHIP_OK;
+    for (int b = 0; b < nbatch; ++b) {                            // same results, one call per batch
+        rc = rdhip_jacobian(c, M, rule, diff, dtype, N[b], Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, memspace);
+        if (rc) return rc;
+    }
+    return RDHIP_OK;
 }
 
 // dynamics_error / dynamics_error_jacobian!: the discrete dynamics (Jacobian) of the first N-1 knot points, minus the next state

@@ -27,6 +27,40 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t lds) {
 }
 
 
+// compute units and LDS per compute unit of the current device, from the runtime (a CPX / NPS-partitioned MI355X reports 32 CUs per
+// partition, not 256: the persistent grids are sized from this, never from a constant); cached per device ordinal
+struct DevInfo { int cus; size_t lds_per_cu; };
+inline DevInfo dev_info() {
+    static std::mutex mu;
+    static DevInfo cache[64];
+    static bool have[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DevInfo{256, 160 * 1024};
+    const int slot = dev & 63;
+    std::lock_guard<std::mutex> g(mu);
+    if (!have[slot]) {
+        int cus = 0, lds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        // (the library is gfx950-only and a gfx950 CU has 160 KiB of LDS; some runtimes report the 64 KiB per-workgroup default here)
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds < 160 * 1024) lds = 160 * 1024;
+        (void)hipGetLastError();
+        cache[slot] = DevInfo{cus, (size_t)lds};
+        have[slot] = true;
+    }
+    return cache[slot];
+}
+// persistent grid for the tile kernels: as many workgroups as fit on the chip at once (LDS- and wave-limited), never more than tiles
+inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
+    const DevInfo di = dev_info();
+    const int by_lds = (int)(di.lds_per_cu / (lds_bytes ? lds_bytes : 1));
+    const int by_waves = 2048 / threads;
+    int per_cu = by_lds < by_waves ? by_lds : by_waves;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const long long g = (long long)di.cus * per_cu;
+    return (unsigned)(ntiles < g ? ntiles : g);
+}
+
 struct ModelDesc {
     int kind, rot, frame;
     int n, m, e;
@@ -37,6 +71,13 @@ struct ModelDesc {
     void* jit;         // RDHIP_MODEL_CUSTOM: the hipRTC plug-in object (jit.hip)
     int newton_iters;  // ImplicitNewtonCache defaults (src/integration.jl:599-600): 10 iterations, tolerance 1e-12
     double newton_tol;
+};
+
+// rdhip_jacobian_multi: up to 32 independent packed trajectories for ONE launch (kernels.hpp MultiBatch)
+struct MultiDesc {
+    int nb;
+    long long N[32];
+    const void* Z[32]; const double* t[32]; const double* dt[32]; void* J[32]; void* Y[32];
 };
 
 struct LaunchArgs {
@@ -54,6 +95,8 @@ struct LaunchArgs {
     double newton_tol;
     int time_major;     // rollout: knot k of trajectory j at k*M + j instead of j*K + k
     int* flag;          // implicit rules: device word of the context ("a row exchange was needed"); NULL = LDS kernels only
+    const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
+                              // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED and the caller loops over the batches
 };
 
 // per-family entry points (one translation unit each so they compile in parallel)

@@ -27,16 +27,7 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }
-// persistent grid for the tile kernels: as many workgroups as fit on the chip at once (LDS-limited), never more than tiles
-inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
-    const int by_lds = (int)(160 * 1024 / lds_bytes);
-    const int by_waves = 2048 / threads;
-    int per_cu = by_lds < by_waves ? by_lds : by_waves;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    const long long g = 256LL * per_cu;
-    return (unsigned)(ntiles < g ? ntiles : g);
-}
+// (tile_grid: common.hpp -- persistent grids are sized from the device's reported CU count and LDS size)
 
 template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
     constexpr size_t lds = JacLds<Fn, T, Plan>::BYTES;
@@ -61,6 +52,55 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// host MultiDesc -> the kernel-argument table (tile prefix sums); returns the total number of tiles
+template <class T> long long fill_multi(const MultiDesc& md, MultiBatch<T>& mb) {
+    mb.nb = md.nb;
+    long long acc = 0;
+    for (int b = 0; b < MULTI_MAXB; ++b) {
+        const bool live = b < md.nb;
+        mb.tile0[b] = acc;
+        mb.N[b] = live ? md.N[b] : 0;
+        mb.Z[b] = live ? (const T*)md.Z[b] : nullptr; mb.t[b] = live ? md.t[b] : nullptr; mb.dt[b] = live ? md.dt[b] : nullptr;
+        mb.J[b] = live ? (T*)md.J[b] : nullptr; mb.Y[b] = live ? (T*)md.Y[b] : nullptr;
+        if (live) acc += (md.N[b] + TILE - 1) / TILE;
+    }
+    mb.tile0[MULTI_MAXB] = acc;
+    for (int b = md.nb; b <= MULTI_MAXB; ++b) mb.tile0[b] = acc;
+    return acc;
+}
+inline bool multi_aligned16(const MultiDesc& md) {
+    for (int b = 0; b < md.nb; ++b) if (!aligned16(md.J[b]) || !aligned16(md.Y[b])) return false;
+    return true;
+}
+// several packed trajectories, one launch: the ForwardAD kernels only (the path BASELINE's small-batch configs take)
+template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff, const LaunchArgs& a) {
+    using Fn = Fun<Mdl, RULE>;
+    using T = typename Fn::T;
+    constexpr int NZ = Fn::NX + Fn::NU;
+    if (diff != RDHIP_FORWARD_AD) return RDHIP_ERR_UNSUPPORTED;
+    Fn fn{m};
+    MultiBatch<T> mb;
+    const long long ntiles = fill_multi<T>(*a.multi, mb);
+    if (ntiles == 0) return RDHIP_OK;
+    if constexpr (NZ <= 10) {
+        constexpr size_t lds = SmallLds<Fn, T>::BYTES;
+        auto kern = jac_ad_small_multi_kernel<Fn, T>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, mb);
+        return hip_status(hipGetLastError());
+    } else if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
+        using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+        constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+        if (!multi_aligned16(*a.multi)) return RDHIP_ERR_UNSUPPORTED;
+        constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
+        auto kern = jac_ad_split_multi_kernel<Fn, T, Plan, NC>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+        constexpr int threads = (Plan::NG + NC) * TILE;
+        hipLaunchKernelGGL(kern, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, mb);
+        return hip_status(hipGetLastError());
+    } else return RDHIP_ERR_UNSUPPORTED;
+}
+
 template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const LaunchArgs& a) {
     using Fn = Fun<Mdl, RULE>;
     using T = typename Fn::T;
@@ -68,6 +108,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     using DefPlan = ContiguousPlan<NZ, (NZ >= 4 ? 4 : NZ)>;     // compact kernels: 4 waves per tile, one chunk
     // run-time-column bodies also go through the split-role loop when the output tile is big enough to be worth dedicated copy waves
     constexpr bool split_fits = NZ > 10 && SplitLds<Fn, T, DefPlan, 4>::BYTES <= 160 * 1024;
+    if (a.multi) return launch_jacobian_multi<Mdl, RULE>(m, diff, a);
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
     if (diff == RDHIP_FORWARD_AD) {

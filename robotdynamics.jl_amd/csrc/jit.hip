@@ -353,11 +353,7 @@ int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
     const long long ntiles = (N + 63) / 64;
     unsigned grid;
     if (k->small) grid = (unsigned)((ntiles + 3) / 4);
-    else {   // persistent tile loop: as many workgroups as fit at once, never more than tiles (dispatch.hpp tile_grid)
-        int per_cu = (int)(160 * 1024 / (k->lds ? k->lds : 1)); const int by_waves = 2048 / k->block;
-        if (per_cu > by_waves) per_cu = by_waves; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
-        const long long g = 256LL * per_cu; grid = (unsigned)(ntiles < g ? ntiles : g);
-    }
+    else grid = tile_grid(k->lds, k->block, ntiles);   // persistent tile loop: as many workgroups as fit at once, never more than tiles
     return launch(M, k, grid, a.stream, args);
 }
 
@@ -371,10 +367,7 @@ int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a) {
     long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* E = a.J; void* Y = a.Y;
     void* args[] = {fn.data(), &N, &Z, &t, &dt, &E, &Y};
     const long long ntiles = (N + 63) / 64;
-    int per_cu = (int)(160 * 1024 / (k->lds ? k->lds : 1)); const int by_waves = 2048 / k->block;
-    if (per_cu > by_waves) per_cu = by_waves; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
-    const long long g = 256LL * per_cu;
-    return launch(M, k, (unsigned)(ntiles < g ? ntiles : g), a.stream, args);
+    return launch(M, k, tile_grid(k->lds, k->block, ntiles), a.stream, args);
 }
 
 // DiscretizedDynamics{ImplicitMidpoint}(custom model): mode as in dispatch.hpp launch_implicit

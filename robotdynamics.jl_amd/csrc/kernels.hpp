@@ -429,12 +429,40 @@ template <class Fn, class T, class Plan, int NC> struct SplitLds {
     static_assert(J_ELEMS * sizeof(T) % 16 == 0 && Y_ELEMS * sizeof(T) % 16 == 0, "tile slabs must be multiples of 16 bytes");
 };
 
-template <class Fn, class T, class Plan, int NC, class Body>
-RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                           T* __restrict__ J, T* __restrict__ Y) {
-    // N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
+// ---- where a tile lives ---------------------------------------------------------------------------------------------
+// The tile loops walk GLOBAL tile indices; a batch descriptor maps one to the arrays it belongs to.  SingleBatch: one packed trajectory
+// (rdhip_jacobian).  MultiBatch: up to MAXB independent packed trajectories -- different arrays, e.g. 16 trajectories of 4 096 knot points
+// -- enumerated back to back by the same persistent loop, so that many small batches cost one bandwidth-regime launch instead of one
+// launch-bound kernel each (rdhip_jacobian_multi).  The table travels in the kernel arguments: no device-side table to keep alive, and a
+// captured graph node carries it.  Everything here is wave-uniform (scalar loads / SALU).
+template <class T> struct TileRef {
+    const T* Z; const double* t; const double* dt; T* J; T* Y;
+    long long N;      // knot points of the batch the tile belongs to
+    long long k0;     // first knot point of the tile inside that batch
+};
+template <class T> struct SingleBatch {
+    long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
+    RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
+    RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
+};
+constexpr int MULTI_MAXB = 32;
+template <class T> struct MultiBatch {
+    int nb;
+    long long tile0[MULTI_MAXB + 1];       // first global tile of batch b; tile0[nb] = total
+    long long N[MULTI_MAXB];
+    const T* Z[MULTI_MAXB]; const double* t[MULTI_MAXB]; const double* dt[MULTI_MAXB]; T* J[MULTI_MAXB]; T* Y[MULTI_MAXB];
+    RD_DEV long long ntiles() const { return tile0[nb]; }
+    RD_DEV TileRef<T> at(long long tile) const {
+        int b = 0;
+        while (b + 1 < nb && tile >= tile0[b + 1]) ++b;
+        return TileRef<T>{Z[b], t[b], dt[b], J[b], Y[b], N[b], (tile - tile0[b]) * TILE};
+    }
+};
+
+template <class Fn, class T, class Plan, int NC, class Body, class BT>
+RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
+    // per batch: N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
-    const long long NIN = N + Fn::NEXT;
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -444,7 +472,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
     T* zs = reinterpret_cast<T*>(smem + L::J_BYTES + L::Y_BYTES);
     double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long ntiles = (N + TILE - 1) / TILE;
+    const long long ntiles = bt.ntiles();
     // tile schedule of this workgroup: tile, tile + tstep, ... < tend
 #if defined(RD_TILE_MAP) && RD_TILE_MAP == 1     // tuning: a contiguous block of tiles per workgroup
     const long long tpw = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -468,17 +496,18 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         fr.row = jt + lane * OW;
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
-        fr.want_y = (Y != nullptr);
+        TileRef<T> cur = bt.at(tile);
         {   // first tile: all of a thread's loads are issued before any is waited for (a load -> wait -> LDS-write loop costs one memory
             // round trip per pass: five of them in front of the first arithmetic of the kernel)
-            const long long k0 = tile * TILE;
+            const long long k0 = cur.k0, N = cur.N, NIN = N + Fn::NEXT;
+            const T* __restrict__ Z = cur.Z;
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
             const int nin = (int)((NIN - k0) < TIN ? (NIN - k0) : TIN);
             T z0[ZPT]; double t0;
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[(e < nin * NZ) ? k0 * NZ + e : 0]; }
             {
-                const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+                const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 const int idx = threadIdx.x & (TILE - 1);
                 t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
             }
@@ -488,17 +517,20 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         }
         __syncthreads();                                   // barrier 0
         for (; tile < tend; tile += tstep) {
-            const long long k0 = tile * TILE;
-            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            const int nk = (int)((cur.N - cur.k0) < TILE ? (cur.N - cur.k0) : TILE);
+            fr.want_y = (cur.Y != nullptr);
             const long long nxt = tile + tstep;
-            const long long k1 = nxt * TILE;
-            const int nk1 = (nxt < tend) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
-            const int nin1 = (nxt < tend) ? (int)((NIN - k1) < TIN ? (NIN - k1) : TIN) : 0;
+            const bool more = nxt < tend;
+            const TileRef<T> nx = bt.at(more ? nxt : tile);   // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
+            const long long k1 = nx.k0;
+            const T* __restrict__ Z = nx.Z;
+            const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
+            const int nin1 = more ? (int)((nx.N + Fn::NEXT - k1) < TIN ? (nx.N + Fn::NEXT - k1) : TIN) : 0;
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nin1 * NZ) ? k1 * NZ + e : 0]; }
             {
-                const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+                const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 const int idx = threadIdx.x & (TILE - 1);
                 tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
             }
@@ -514,6 +546,7 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
             __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
+            cur = nx;
         }
     } else {
         // =========================== copy waves ==============================
@@ -523,8 +556,10 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
         __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
         __syncthreads();                                   // barrier 0
         for (; tile < tend; tile += tstep) {
-            const long long k0 = tile * TILE;
-            const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+            const TileRef<T> cur = bt.at(tile);
+            const long long k0 = cur.k0;
+            const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
+            T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
             V4 jv[L::JPL], yv[L::YPL];
             __syncthreads();                               // barrier A
 #pragma unroll
@@ -565,7 +600,12 @@ RD_DEV void jac_split_loop(const Fn& fn, long long N, const T* __restrict__ Z, c
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+}
+// the same kernel over several independent packed trajectories (rdhip_jacobian_multi)
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_multi_kernel(Fn fn, MultiBatch<T> mb) {
+    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, mb);
 }
 
 // ---- error-state expansion: [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k] fused into the Jacobian kernel ----------------------
@@ -664,7 +704,7 @@ template <class Fn, class T, class Plan> struct ErrUnrolledBody {
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_errexp_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                    const double* __restrict__ dtt, T* __restrict__ E, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, E, Y);
+    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, E, Y});
 }
 
 // ---- small models (n + m <= 10): ONE wave owns 64 knot points and ALL Jacobian columns ---------------------------------
@@ -679,9 +719,8 @@ template <class Fn, class T> struct SmallLds {
     static constexpr size_t WAVE_ELEMS = (size_t)TILE * RS;
     static constexpr size_t BYTES = 4 * WAVE_ELEMS * sizeof(T);
 };
-template <class Fn, class T>
-__global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+template <class Fn, class T, class BT>
+RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, JN = NY * NZ;
     using L = SmallLds<Fn, T>;
     using D = Dual<T, NZ>;
@@ -690,8 +729,11 @@ __global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     T* lds = reinterpret_cast<T*>(smem) + wave * L::WAVE_ELEMS;
     const long long tile = (long long)blockIdx.x * 4 + wave;
-    const long long k0 = tile * TILE;
-    if (k0 >= N) return;
+    if (tile >= bt.ntiles()) return;
+    const TileRef<T> ref = bt.at(tile);
+    const long long k0 = ref.k0, N = ref.N;
+    const T* __restrict__ Z = ref.Z; const double* __restrict__ tt = ref.t; const double* __restrict__ dtt = ref.dt;
+    T* __restrict__ J = ref.J; T* __restrict__ Y = ref.Y;
     const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
     const int kl = lane < nk ? lane : nk - 1;
     // stage z: lane-contiguous loads of the tile's nk*NZ values -> LDS -> one knot point per lane
@@ -734,6 +776,15 @@ __global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long
         for (int e = lane; e < nk * NY; e += TILE) { const int r = e / NY; Yt[e] = lds[r * L::RS + JN + (e - r * NY)]; }
     }
 }
+template <class Fn, class T>
+__global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_ad_small_body<Fn, T>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+}
+template <class Fn, class T>
+__global__ void __launch_bounds__(4 * TILE) jac_ad_small_multi_kernel(Fn fn, MultiBatch<T> mb) {     // rdhip_jacobian_multi
+    jac_ad_small_body<Fn, T>(fn, mb);
+}
 
 // ---- ForwardAD, run-time column loop (compact code for the long tail of model x rule combinations) -----------
 template <class Fn, class T, class Plan> struct AdLoopBody {
@@ -765,7 +816,7 @@ template <class Fn, class T, class Plan> struct AdLoopBody {
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_loop_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                     const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
@@ -958,7 +1009,7 @@ template <class Fn, class T, class Plan> struct ChainUnrolledBody {
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_chain_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                   const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
@@ -997,7 +1048,7 @@ template <class Fn, class T, class Plan> struct FdBody {
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,

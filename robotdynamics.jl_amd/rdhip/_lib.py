@@ -22,6 +22,8 @@ FORWARD_AD, FINITE_DIFF, USER_DEFINED = range(3)
 F64, F32 = range(2)
 DEVICE, HOST = range(2)
 STREAM_OWN, STREAM_BORROW = range(2)
+GATHER_NONE, GATHER_ROOT, GATHER_ALL = range(3)
+COMM_ID_BYTES = 128
 
 
 class RdhipError(RuntimeError):
@@ -70,6 +72,7 @@ _SIGS = {
     "rdhip_dynamics": (C.c_int, [_P, _P, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_discrete_dynamics": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
+    "rdhip_jacobian_multi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_int]),
     "rdhip_dynamics_error": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_dynamics_error_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_error_expansion": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
@@ -83,6 +86,15 @@ _SIGS = {
     "rdhip_shard_range": (C.c_int, [_LL, C.c_int, C.c_int, C.POINTER(_LL), C.POINTER(_LL)]),
     "rdhip_jacobian_sharded": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P]),
     "rdhip_memcpy_peer": (C.c_int, [_P, _P, _P, _P, C.c_ulonglong]),
+    "rdhip_comm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "rdhip_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rdhip_comm_create_rank": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.POINTER(_P)]),
+    "rdhip_comm_destroy": (C.c_int, [_P]),
+    "rdhip_comm_size": (C.c_int, [_P, _IP, _IP]),
+    "rdhip_comm_rank": (C.c_int, [_P, C.c_int, _IP, C.POINTER(_P)]),
+    "rdhip_gather": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_ulonglong), C.POINTER(_P)]),
+    "rdhip_jacobian_sharded_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P)]),
+    "rdhip_errstate_jacobian_sharded_gather": (C.c_int, [_P, _P, C.c_int, _LL, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P)]),
     "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_rollout_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
 }

@@ -1345,6 +1345,72 @@ def prepare_jacobian(sig, diff, fun, J, y, Z):
     return PreparedJacobian(sig, diff, fun, J, y, Z)
 
 
+class PreparedJacobianMulti:
+    """jacobian!(sig, diff, fun, Js[p], ys[p], Zs[p]) for several INDEPENDENT packed trajectories in ONE kernel launch (rdhip_jacobian_multi):
+    what `for p in problems, k in 1:N; jacobian!(sig, diff, model, J[p][k], y, Z[p][k]); end` does for the per-knot loops of several
+    TrajectoryOptimization problems / shooting segments (src/functionbase.jl:242).  A trajectory of a few thousand knot points is launch-bound
+    on its own; sixteen 4 096-knot trajectories enumerated by one persistent tile loop cost what one 65 536-knot batch costs.  Argument
+    checking happens once, calling the object re-issues the launch (array contents may change, their memory may not)."""
+
+    def __init__(self, sig, diff, fun, Js, ys, Zs):
+        if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+            raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+        model, rule = _model_rule(fun)
+        if rule == L.IMPLICIT_MIDPOINT:
+            if not isinstance(diff, ImplicitFunctionTheorem):
+                raise ValueError(f"Must call jacobian! on an implicit model with the ImplicitFunctionTheorem diff method. Got {type(diff).__name__}.")
+            diff = diff.diff
+        elif isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
+        Zs, Js = list(Zs), list(Js)
+        ys = [None] * len(Zs) if ys is None else list(ys)
+        if not (len(Zs) == len(Js) == len(ys)):
+            raise ValueError("Js, ys and Zs must list one entry per trajectory")
+        nb = len(Zs)
+        args, dtype = [], None
+        Ns = (C.c_longlong * max(nb, 1))()
+        tabs = [(C.c_void_p * max(nb, 1))() for _ in range(5)]
+        for b, (Z, J, y) in enumerate(zip(Zs, Js, ys)):
+            if not isinstance(Z, PackedTrajectory):
+                raise TypeError("every trajectory must be a PackedTrajectory")
+            n, m = _check_traj(fun, Z)
+            N = len(Z)
+            _dense(J, (N, n, n + m), f"Js[{b}]", transposed_last2=True)
+            az, at, adt = _Arg(Z.data, f"Zs[{b}].data"), _Arg(Z.t, f"Zs[{b}].t"), _Arg(Z.dt, f"Zs[{b}].dt")
+            dtype = az.dtype if dtype is None else dtype
+            if az.dtype != dtype:
+                raise ValueError("all trajectories must share one dtype")
+            aj, ay = _Arg(J, f"Js[{b}]", dtype), _Arg(y, f"ys[{b}]", dtype)
+            if y is not None:
+                _dense(y, (N, n), f"ys[{b}]")
+            args += [az, at, adt, aj, ay]
+            Ns[b] = N
+            for tab, a in zip(tabs, (az, at, adt, aj, ay)):
+                tab[b] = a.ptr
+        ctx, space = _resolve_ctx(args) if args else (None, L.HOST)
+        self._keep = (fun, model, Js, ys, Zs, Ns, tabs)
+        self._space, self._dev, self._ctx, self._nb = space, (args[0].device if args else None), ctx, nb
+        self._args = (model._handle, rule, diff.code, dtype if dtype is not None else L.F64, nb, Ns, *tabs, space)
+
+    def __call__(self):
+        if self._nb == 0:
+            return
+        ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
+        rc = L.lib().rdhip_jacobian_multi(ctx.handle, *self._args)
+        if rc:
+            L.check(rc, ctx.handle)
+
+
+def prepare_jacobian_multi(sig, diff, fun, Js, ys, Zs):
+    return PreparedJacobianMulti(sig, diff, fun, Js, ys, Zs)
+
+
+def jacobian_multi_(sig, diff, fun, Js, ys, Zs):
+    """One launch for the Jacobians of several independent packed trajectories: see PreparedJacobianMulti."""
+    PreparedJacobianMulti(sig, diff, fun, Js, ys, Zs)()
+    return None
+
+
 def discrete_jacobian_(Q, J, model, z):
     """v0.3 discrete_jacobian!(Q, D, model, z) == jacobian!(sig, ForwardAD(), DiscretizedDynamics{Q}(model), D, y, z)."""
     fun = DiscretizedDynamics(model, Q)

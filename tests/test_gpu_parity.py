@@ -744,6 +744,107 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     np.testing.assert_allclose(host(stack["data"]), O.cartpole().rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
 
 
+def test_baseline_config_sizes_c1_c2():
+    """BASELINE.json configs[0] and configs[1] at their exact sizes.  C1: Cartpole (n=4, m=1), RK3 discrete_dynamics + discrete Jacobian on ONE
+    trajectory of 101 knot points (examples/cartpole.jl:46: dt = 0.1; restated with the v0.4 calls), through the v0.3 spellings
+    too.  C2: Cartpole batched RK4 discrete Jacobian, 4 096 knot points, fp64."""
+    rng = np.random.default_rng(1)
+    model, om = RD.Cartpole(), O.cartpole()
+    # C1
+    N = 101
+    Zn = rng.random((N, 5)); t = np.arange(N) * 0.1; dt = np.full(N, 0.1); dt[-1] = 0.0
+    for where in ("host", "cuda"):
+        Z = traj(model, Zn, t, dt, "cuda" if where == "cuda" else None)
+        dm = RD.DiscretizedDynamics[RD.RK3](model)
+        np.testing.assert_allclose(host(RD.discrete_dynamics(dm, Z)), om.discrete_dynamics(O.RK3, Zn, t, dt), rtol=0, atol=TOL)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        y = RD.evaluate(dm, Z) * 0
+        RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, y, Z)
+        Jo, Yo = om.jacobian(O.RK3, O.FORWARD_AD, Zn, t, dt)
+        np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(y), Yo, rtol=0, atol=TOL)
+        J3 = RD.alloc_jacobians(dm, N, Z.data)
+        RD.discrete_jacobian_(RD.RK3, J3, model, Z)                                  # v0.3: discrete_jacobian!(RK3, D, model, Z)
+        np.testing.assert_allclose(host(J3), Jo, rtol=0, atol=TOL)
+        z0 = RD.KnotPoint(Zn[0, :4], Zn[0, 4:], 0.0, 0.1)                            # the per-knot call of the reference on the same knot point
+        np.testing.assert_allclose(RD.discrete_dynamics(dm, z0), om.discrete_dynamics(O.RK3, Zn[:1], t[:1], dt[:1])[0], rtol=0, atol=TOL)
+    # C2
+    N = 4096
+    rng = np.random.default_rng(2)
+    Zn = rng.random((N, 5)); t = np.arange(N) * 0.1; dt = np.full(N, 0.1)
+    Z = traj(model, Zn, t, dt, "cuda")
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    J = RD.alloc_jacobians(dm, N, Z.data)
+    Y = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+
+
+def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
+    """rdhip_jacobian_multi: several independent packed trajectories (different arrays, ragged lengths) through ONE persistent tile loop must
+    give exactly what one rdhip_jacobian call per trajectory gives -- and both must match the oracle.  Covers the split-role kernel (satellite,
+    quadrotor), the all-columns-per-lane kernel (cartpole), > 32 trajectories (several table-sized launches), empty trajectories, optional
+    f(z) outputs, and the combinations without a fused kernel (FiniteDifference, implicit rule, host memory), which run batch by batch."""
+    rng = np.random.default_rng(123)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    cases = ((RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6), [4096, 101, 64, 1, 65, 0, 777]),
+             (RD.Quadrotor(), O.quadrotor(), lambda N: H.rand_rigid(rng, N, 4, 0.6, 1.9), [130, 63]),
+             (RD.Cartpole(), O.cartpole(), lambda N: rng.random((N, 5)), [101] * 40 + [4096, 1, 0, 65]))
+    for model, om, gen, sizes in cases:
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        for Q, rule in ((RD.RK4, O.RK4), (RD.RK3, O.RK3)):
+            dm = RD.DiscretizedDynamics(model, Q)
+            Zn = [gen(N) for N in sizes]
+            ts = [0.1 * b + np.arange(N) * 0.05 for b, N in enumerate(sizes)]
+            dts = [np.full(N, 0.05) for N in sizes]
+            for d in dts:
+                if len(d):
+                    d[-1] = 0.0                                                   # every trajectory ends in a terminal knot point
+            Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
+            Js = [RD.alloc_jacobians(dm, N, Zs[0].data).fill_(7.0) for N in sizes]
+            Ys = [torch.full((N, n), 7.0, dtype=torch.float64, device="cuda") if b % 3 else None for b, N in enumerate(sizes)]
+            RD.jacobian_multi_(sig, AD, dm, Js, Ys, Zs)
+            for b, N in enumerate(sizes):
+                if N == 0:
+                    continue
+                Jo, Yo = om.jacobian(rule, O.FORWARD_AD, Zn[b], ts[b], dts[b])
+                np.testing.assert_allclose(host(Js[b]), Jo, rtol=0, atol=TOL)
+                if Ys[b] is not None:
+                    np.testing.assert_allclose(host(Ys[b]), Yo, rtol=0, atol=TOL)
+                J1 = RD.alloc_jacobians(dm, N, Zs[b].data)
+                RD.jacobian_(sig, AD, dm, J1, None, Zs[b])
+                assert torch.equal(J1, Js[b])                                      # bit-identical to the single-batch launch
+    # no fused kernel: FiniteDifference, ImplicitMidpoint, host arrays, unaligned slabs -> batch by batch, same answers
+    model, om = RD.Satellite(), O.satellite()
+    sizes = [70, 33]
+    Zn = [H.rand_rigid(rng, N, 6) for N in sizes]; ts = [np.arange(N) * 0.05 for N in sizes]; dts = [np.full(N, 0.05) for N in sizes]
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
+    Js = [RD.alloc_jacobians(dm, N, Zs[0].data) for N in sizes]
+    RD.jacobian_multi_(sig, RD.FiniteDifference(), dm, Js, None, Zs)
+    for b in range(2):
+        np.testing.assert_allclose(host(Js[b]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[b], ts[b], dts[b])[0], rtol=0, atol=1e-6)
+    dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    Ys = [torch.empty((N, 13), dtype=torch.float64, device="cuda") for N in sizes]
+    RD.jacobian_multi_(sig, RD.ImplicitFunctionTheorem(AD), dmi, Js, Ys, Zs)
+    for b in range(2):
+        Xo, Jio, _ = om.implicit_midpoint(Zn[b], ts[b], dts[b])
+        np.testing.assert_allclose(host(Ys[b]), Xo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(host(Js[b]), Jio, rtol=0, atol=1e-8 * max(1.0, np.abs(Jio).max()))
+    Zh = [traj(model, z, t, d) for z, t, d in zip(Zn, ts, dts)]
+    Jh = [RD.alloc_jacobians(dm, N, Zh[0].data) for N in sizes]
+    RD.jacobian_multi_(sig, AD, dm, Jh, None, Zh)
+    for b in range(2):
+        np.testing.assert_allclose(host(Jh[b]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[b], ts[b], dts[b])[0], rtol=0, atol=TOL)
+    buf = torch.zeros(sizes[0] * 247 + 1, dtype=torch.float64, device="cuda")
+    Ju = [buf[1:].view(sizes[0], 19, 13).transpose(1, 2), Js[1]]                  # 8-byte aligned slab: the fused kernel copies 16-byte units
+    RD.jacobian_multi_(sig, AD, dm, Ju, None, Zs)
+    np.testing.assert_allclose(host(Ju[0]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[0], ts[0], dts[0])[0], rtol=0, atol=TOL)
+    assert float(buf[0]) == 0.0
+
+
 def test_time_dependent_dynamics_receive_the_stage_times():
     """dynamics(model, x, u, t): the time argument reaches every evaluation the way the reference passes it -- the knot point's t for the
     continuous model, t / t + h/2 / t + h inside Euler, RK2, RK3, RK4 (src/integration.jl:73-83,130-135,280-286) and in the chain rule's

@@ -211,6 +211,25 @@ def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
              {"trajectories": M, "knots": K})
 
 
+def multi_case(name, model, gen, nbatch, per, rule, dtype, reps):
+    """`nbatch` independent trajectories of `per` knot points (separate arrays): (a) one rdhip_jacobian call each, (b) ONE rdhip_jacobian_multi launch."""
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    fun = RD.DiscretizedDynamics(model, rule)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    Zs = [RD.PackedTrajectory(n, m, gen(per).astype(dtype), np.arange(per) * 0.1, np.full(per, 0.1)).to(DEV) for _ in range(nbatch)]
+    nb = nbuf_for(nbatch * per * n * (n + m) * T)
+    Js = [[RD.alloc_jacobians(fun, per, Zs[0].data) for _ in range(nbatch)] for _ in range(nb)]
+    Ys = [[torch.empty((per, n), dtype=Zs[0].data.dtype, device=DEV) for _ in range(nbatch)] for _ in range(nb)]
+    alg = nbatch * per * ((n + m) * T + 16 + n * (n + m) * T + n * T)
+    singles = [[RD.prepare_jacobian(sig, AD, fun, Js[k][b], Ys[k][b], Zs[b]) for b in range(nbatch)] for k in range(nb)]
+    us = timed(lambda i: [c() for c in singles[i % nb]], reps)
+    emit(name + f": {nbatch} separate launches", nbatch * per, "f64" if T == 8 else "f32", us, alg, {"batches": nbatch, "knots_per_batch": per})
+    fused = [RD.prepare_jacobian_multi(sig, AD, fun, Js[k], Ys[k], Zs) for k in range(nb)]
+    us = timed(lambda i: fused[i % nb](), reps)
+    emit(name + ": ONE launch (rdhip_jacobian_multi)", nbatch * per, "f64" if T == 8 else "f32", us, alg, {"batches": nbatch, "knots_per_batch": per})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true", help="also run the N sweep 2^12 .. 2^22 for C2/C3")
@@ -230,6 +249,27 @@ def main():
         jac_case("satellite pair (n=14, m=6) RK3 jacobian ForwardAD", pair, Zp, RD.RK3, AD, f64, a.reps)
         jac_case("satellite pair (n=14, m=6) continuous jacobian ForwardAD", pair, Zp, None, AD, f64, a.reps)
         errexp_case("satellite pair RK4 error-state expansion fused", pair, Zp, RD.RK4, f64, a.reps)
+        return
+    if a.only in ("multi", ""):
+        multi_case("16 x 4096 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 16, 4096, RD.RK4, f64, a.reps)
+        multi_case("64 x 1024 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 64, 1024, RD.RK4, f64, a.reps)
+        multi_case("32 x 101 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 32, 101, RD.RK4, f64, a.reps)
+        multi_case("16 x 4096 cartpole RK4 jacobian ForwardAD (C2 x 16)", cart, lambda N: rng.random((N, 5)), 16, 4096, RD.RK4, f64, a.reps)
+        if a.only == "multi":
+            return
+    if a.only == "implicit":
+        Zs = rigid_inputs(65536, 6, rng)
+        dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
+        Zi = RD.PackedTrajectory(13, 6, Zs, np.arange(65536) * 0.1, np.full(65536, 0.1)).to(DEV)
+        Xi = torch.empty((65536, 13), dtype=torch.float64, device=DEV)
+        us = timed(lambda i: RD.evaluate_(dmi, Xi, Zi), 10, warm=2)
+        emit("satellite ImplicitMidpoint discrete_dynamics (Newton)", 65536, "f64", us, 65536 * (19 * 8 + 16 + 13 * 8))
+        Ji = RD.alloc_jacobians(dmi, 65536, Zi.data)
+        ift = RD.ImplicitFunctionTheorem(RD.ForwardAD())
+        us = timed(lambda i: RD.jacobian_(RD.StaticReturn(), ift, dmi, Ji, Xi, Zi), 10, warm=2)
+        emit("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", 65536, "f64", us, 65536 * 2248)
+        jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
+        jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
         return
     if a.only == "rolljac":
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
