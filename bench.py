@@ -7,9 +7,13 @@ Satellite RigidBody{QuatRotation}, n=13, m=6, RK4 dynamics + Jacobian, 65 536 kn
 writes the 13x19 Jacobian and x_{k+1} of every knot point.  Inputs are resident in HBM before the timed region.
 Outputs rotate over 4 buffers (4 x 136 MB > the 256 MiB Infinity Cache) so steps do not rewrite cache-resident lines.
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), every rank owns 65 536 knot points
-(weak scaling), no data-path collective in the timed region; the optional gather of the stacked Jacobians over xGMI
-is timed separately (`--gather all|root`) and reported beside the kernel-only figure.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL, for the launch / barrier / max-over-ranks control path),
+every rank owns 65 536 knot points (weak scaling), no data-path collective in the timed region; the gather of the stacked
+Jacobians over xGMI goes through the library's own RCCL exchange (C ABI rdhip_comm_create_rank / rdhip_gather: grouped
+send / recv into the root, or all-gather), is timed separately (`--gather all|root`) and reported beside the kernel-only
+figure with bytes per rank and GB/s.  Extra objects in the same JSON line (never `value`): `extras` = SURVEY 8(d)'s secondary
+metrics (discrete-dynamics evaluations/s, error-state Jacobians/s, each with its roofline fraction), `small_batches_fused` =
+16 independent 4 096-knot trajectories in one rdhip_jacobian_multi launch (the north-star's N = 4 096 regime).
 
   python bench.py --gpus 1 --steps 50 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 bench.py --gpus 8
@@ -89,6 +93,73 @@ def cpu_baseline(Zn, t, dt):
             "single_thread_value": v_one, "thread_scan": scan, "host_cpus": os.cpu_count(), "usable_cores": cores}
 
 
+def _timed_us(fn, reps, warm=20):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def secondary_metrics(dev, reps):
+    """SURVEY 8(d) secondary metrics on rank 0's GPU, HIP-event timed back-to-back launches, bare C-ABI calls: RK4 discrete_dynamics evaluations/s
+    (C3's other half, 65 536 satellite knot points), error-state Jacobians/s (C4's per-GPU kernel, Quadrotor, 262 144 knot points, dense G), and
+    the N = 4 096 regime: 16 independent 4 096-knot satellite trajectories as 16 launches and as ONE rdhip_jacobian_multi launch."""
+    from rdhip import _lib as L
+    lib = L.lib()
+    ctx = L.context_for(dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    sat, quad = RD.Satellite(), RD.Quadrotor()
+    out = {}
+    # discrete dynamics
+    N = N_PER_GPU
+    Zn, t, dt = synthetic_inputs(N, 11)
+    Z = RD.PackedTrajectory(NX, NU, Zn, t, dt).to(dev)
+    Xs = [torch.empty((N, NX), dtype=torch.float64, device=dev) for _ in range(4)]
+    RD.evaluate_(RD.DiscretizedDynamics(sat, RD.RK4), Xs[0], Z)
+    zp, tp, dp = Z.data.data_ptr(), Z.t.data_ptr(), Z.dt.data_ptr()
+    us = _timed_us(lambda i: lib.rdhip_discrete_dynamics(ctx.handle, sat._handle, L.RK4, L.F64, N, zp, tp, dp, Xs[i % 4].data_ptr(), L.DEVICE), reps)
+    b = NZ * 8 + 16 + NX * 8
+    out["discrete_dynamics_rk4_satellite"] = {"knot_points": N, "value": N / (us * 1e-6), "unit": "evaluations/s", "us_per_launch": us, "bytes_per_knot": b,
+                                              "frac_of_hbm_peak": N * b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    # error-state Jacobians (C4 kernel)
+    Nq = 262144
+    rng = np.random.default_rng(4)
+    q = rng.standard_normal((Nq, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    X = torch.as_tensor(np.concatenate([rng.random((Nq, 3)), q, rng.random((Nq, 6))], axis=1)).to(dev)
+    Gs = [RD.alloc_errstate_jacobians(quad, Nq, X) for _ in range(2)]
+    RD.errstate_jacobian_(quad, Gs[0], X, clear=True)
+    us = _timed_us(lambda i: lib.rdhip_errstate_jacobian(ctx.handle, quad._handle, L.F64, Nq, X.data_ptr(), 13, 1, Gs[i % 2].data_ptr(), L.DEVICE), max(20, reps // 4))
+    b = 13 * 8 + 13 * 12 * 8
+    out["errstate_jacobian_quadrotor"] = {"knot_points": Nq, "value": Nq / (us * 1e-6), "unit": "error-state Jacobians/s", "us_per_launch": us, "bytes_per_knot": b,
+                                          "frac_of_hbm_peak": Nq * b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    # 16 x 4096: separate launches vs one fused launch
+    nbt, per = 16, 4096
+    dm = RD.DiscretizedDynamics(sat, RD.RK4)
+    Zs = []
+    for k in range(nbt):
+        zn, tt, dd = synthetic_inputs(per, 100 + k)
+        Zs.append(RD.PackedTrajectory(NX, NU, zn, tt, dd).to(dev))
+    Js = [[RD.alloc_jacobians(dm, per, Zs[0].data) for _ in range(nbt)] for _ in range(NBUF)]
+    Ys = [[torch.empty((per, NX), dtype=torch.float64, device=dev) for _ in range(nbt)] for _ in range(NBUF)]
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    singles = [[RD.prepare_jacobian(sig, AD, dm, Js[k][j], Ys[k][j], Zs[j]) for j in range(nbt)] for k in range(NBUF)]
+    fused = [RD.prepare_jacobian_multi(sig, AD, dm, Js[k], Ys[k], Zs) for k in range(NBUF)]
+    us_sep = _timed_us(lambda i: [c() for c in singles[i % NBUF]], max(10, reps // 10), warm=3)
+    us_one = _timed_us(lambda i: fused[i % NBUF](), reps)
+    tot = nbt * per
+    small = {"workload": f"{nbt} independent Satellite trajectories x {per} knot points (separate arrays), RK4 ForwardAD Jacobian + x_next, fp64",
+             "one_launch_us": us_one, "value": tot / (us_one * 1e-6), "unit": "knot-point Jacobians/s",
+             "frac_of_hbm_peak": tot * BYTES_PER_KNOT / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBS,
+             "separate_launches_us": us_sep, "separate_frac_of_hbm_peak": tot * BYTES_PER_KNOT / (us_sep * 1e-6) / 1e9 / HBM_PEAK_GBS,
+             "entry_point": "rdhip_jacobian_multi"}
+    return out, small
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +167,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--gather", choices=["none", "all", "root"], default="all", help="also time the RCCL exchange of the stacked Jacobians (N>1 only; reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics / fused small batches (extra objects, never `value`)")
+    ap.add_argument("--extras-reps", type=int, default=200)
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="sustained load (the same launches, untimed) before the W warm-up steps: clocks and TLBs settle over ~100 ms, "
                          "a short W alone measures the ramp (0.62 instead of 0.65-0.68 of the roofline)")
@@ -209,22 +282,63 @@ def main():
                       "note": "independent batches round-robin on several streams; not the contract's `value`"}
 
     gather = None
-    if world > 1 and args.gather != "none" and args.backend == "nccl":
+    if world > 1 and args.gather != "none":
+        # the stacked Jacobians on the root (or everywhere) through the library's own exchange: rdhip_comm_create_rank + rdhip_gather
+        # (RCCL grouped send / recv or all-gather over xGMI); torch.distributed only carried the 128-byte RCCL id
         try:
             reps = 5
-            P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)     # warm (dense (N, n+m, n) slabs)
+            shard_bytes = N * NX * NZ * 8
+            comm = P.Comm.from_torch_distributed(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream)
+            receives = args.gather == "all" or rank == 0
+            stack = torch.empty(world * shard_bytes // 8 if receives else 1, dtype=torch.float64, device=dev)
+            sizes = [shard_bytes] * world
+
+            def exchange(i):
+                comm.gather(args.gather, [Js[i % NBUF]], sizes, [stack], root=0)
+            exchange(0)                                      # warm (connection set-up)
             torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
             g0 = _time.perf_counter()
             for i in range(reps):
-                step(i)
-                P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
+                exchange(i)
             torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-            gl = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
+            g_only = torch.tensor([_time.perf_counter() - g0], dtype=torch.float64, device=red_dev)
+            g1 = _time.perf_counter()
+            for i in range(reps):
+                step(i)
+                exchange(i)
+            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            gl = torch.tensor([_time.perf_counter() - g1], dtype=torch.float64, device=red_dev)
             dist.all_reduce(gl, op=dist.ReduceOp.MAX)
-            gather = {"mode": args.gather, "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps,
-                      "bytes_per_rank": N * NX * NZ * 8}
+            dist.all_reduce(g_only, op=dist.ReduceOp.MAX)
+            ok = True
+            if receives:                                     # the stack's own block must be this rank's shard
+                mine = stack[rank * (shard_bytes // 8): rank * (shard_bytes // 8) + 64]
+                ok = bool(torch.equal(mine, torch.as_strided(Js[(reps - 1) % NBUF], (64,), (1,))))
+            gms = 1e3 * float(g_only.item()) / reps
+            gather = {"mode": args.gather, "path": "rdhip_gather (C ABI, RCCL grouped send/recv or all-gather)", "bytes_per_rank": shard_bytes,
+                      "gather_ms": gms, "root_ingest_GBps": (world - 1) * shard_bytes / (gms * 1e-3) / 1e9,
+                      "value_with_gather": world * N * reps / float(gl.item()), "ms_per_step_with_gather": 1e3 * float(gl.item()) / reps, "own_block_ok": ok}
+            comm.close()
         except Exception as e:                               # the exchange is an extra: never lose the bench line over it
             gather = {"mode": args.gather, "error": f"{type(e).__name__}: {e}"[:300]}
+            if args.backend == "nccl":                       # second choice: the torch.distributed form of the same exchange
+                try:
+                    P.gather_stacked(Js[0].transpose(1, 2), world * N, args.gather)
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    g0 = _time.perf_counter()
+                    for i in range(3):
+                        P.gather_stacked(Js[i % NBUF].transpose(1, 2), world * N, args.gather)
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    gather["torch_distributed_gather_ms"] = 1e3 * (_time.perf_counter() - g0) / 3
+                except Exception as e2:
+                    gather["torch_distributed_error"] = f"{type(e2).__name__}: {e2}"[:200]
+
+    extras = small = None
+    if rank == 0 and not args.no_extras:
+        try:
+            extras, small = secondary_metrics(dev, args.extras_reps)
+        except Exception as e:
+            extras = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
@@ -249,6 +363,10 @@ def main():
         }
         if gather:
             out["gather"] = gather
+        if extras:
+            out["extras"] = extras
+        if small:
+            out["small_batches_fused"] = small
         if overlapped:
             out["independent_batches_multi_stream"] = overlapped
         if not args.no_cpu_baseline and world == 1:

@@ -70,3 +70,73 @@ def gather_stacked(local, N, mode="root", root=0, group=None):
                 w.wait()
         return None
     raise ValueError(f"unknown gather mode {mode!r}")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The native exchange (C ABI: rdhip_comm_*, rdhip_gather): RCCL driven by librdhip itself, no torch.distributed in the data path.  This is
+# the path a Julia host takes; torch tensors are used here only as device buffers.
+# ------------------------------------------------------------------------------------------------------------------------------------
+class Comm:
+    """One rank per GPU.  Comm.local(devices): ONE process drives all ranks (rdhip_comm_create, ncclCommInitAll).
+    Comm.from_torch_distributed(): one process per GPU; rank 0 draws the RCCL unique id and torch.distributed only carries those 128 bytes
+    (rdhip_comm_unique_id / rdhip_comm_create_rank)."""
+
+    def __init__(self, handle, ctxs, ranks, nranks):
+        self.handle, self.ctxs, self.ranks, self.nranks = handle, ctxs, ranks, nranks
+
+    @classmethod
+    def local(cls, devices):
+        import ctypes as C
+        from . import _lib as L
+        ctxs = [L.Context(int(d)) for d in devices]
+        arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        h = C.c_void_p()
+        L.check(L.lib().rdhip_comm_create(arr, len(ctxs), C.byref(h)))
+        return cls(h, ctxs, list(range(len(ctxs))), len(ctxs))
+
+    @classmethod
+    def from_torch_distributed(cls, device, stream=None, group=None):
+        import ctypes as C
+        from . import _lib as L
+        world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        ident = C.create_string_buffer(L.COMM_ID_BYTES)
+        if world > 1:
+            box = [None]
+            if rank == 0:
+                L.check(L.lib().rdhip_comm_unique_id(ident))
+                box[0] = ident.raw
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
+        ctx = L.Context(int(device), stream)
+        h = C.c_void_p()
+        L.check(L.lib().rdhip_comm_create_rank(ctx.handle, world, rank, ident, C.byref(h)), ctx.handle)
+        return cls(h, [ctx], [rank], world)
+
+    def gather(self, mode, shards, nbytes, outs, root=0):
+        """rdhip_gather: `shards` / `outs` = one device tensor (or None) per LOCAL rank, `nbytes` = shard size in bytes of EVERY rank.
+        Asynchronous on each rank's context stream; call synchronize() before reading `outs`."""
+        import ctypes as C
+        from . import _lib as L
+        code = {"none": L.GATHER_NONE, "root": L.GATHER_ROOT, "all": L.GATHER_ALL}[mode]
+        nl = len(self.ctxs)
+        sh = (C.c_void_p * nl)(*[(s.data_ptr() if s is not None else None) for s in shards])
+        ou = (C.c_void_p * nl)(*[(o.data_ptr() if o is not None else None) for o in outs])
+        nb = (C.c_ulonglong * self.nranks)(*[int(b) for b in nbytes])
+        L.check(L.lib().rdhip_gather(self.handle, code, int(root), sh, nb, ou), self.ctxs[0].handle)
+
+    def synchronize(self):
+        for c in self.ctxs:
+            c.synchronize()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            from . import _lib as L
+            L.lib().rdhip_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

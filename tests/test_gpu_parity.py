@@ -744,6 +744,75 @@ def test_custom_models_jit_match_the_compiled_in_ones():
     np.testing.assert_allclose(host(stack["data"]), O.cartpole().rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
 
 
+def test_native_gather_c4_shape_on_the_local_ranks():
+    """BASELINE configs[3] in the shape the C ABI serves it: Quadrotor errstate_jacobian! on per-rank blocks of knot points, then the stacked G
+    through the library's own RCCL exchange (rdhip_comm_create / rdhip_errstate_jacobian_sharded_gather / rdhip_gather) -- no torch.distributed
+    in the data path.  The test box has one GPU, so the communicator has one rank per visible device (a 1-rank communicator degenerates to the
+    in-stack placement of the local shard and never loads librccl; the driver's 8-GPU node runs the same code with 8 ranks)."""
+    import ctypes as C
+    from rdhip import _lib as L
+    from rdhip import parallel as P
+    ndev = min(RD.device_count(), 8)
+    comm = P.Comm.local(range(ndev))
+    nr, nl = C.c_int(), C.c_int()
+    L.check(L.lib().rdhip_comm_size(comm.handle, C.byref(nr), C.byref(nl)))
+    assert (nr.value, nl.value) == (ndev, ndev)
+    rng = np.random.default_rng(4)
+    model, om = RD.Quadrotor(), O.quadrotor()
+    N = 4099                                                        # ragged: the last block is short
+    Zn = H.rand_rigid(rng, N, 4, 0.6, 1.9)
+    Xn = np.ascontiguousarray(Zn[:, :13])
+    Go = om.errstate_jacobian(Xn)
+    blocks = [P.shard_range(N, r, ndev) for r in range(ndev)]
+    for mode, code in (("root", L.GATHER_ROOT), ("all", L.GATHER_ALL), ("none", L.GATHER_NONE)):
+        Xs, Gs, stacks = [], [], []
+        for r, (lo, hi) in enumerate(blocks):
+            dev = f"cuda:{r}"
+            Xs.append(torch.as_tensor(Xn[lo:hi]).to(dev))
+            Gs.append(torch.full((hi - lo, 12, 13), 7.0, dtype=torch.float64, device=dev))
+            stacks.append(torch.full((N, 12, 13), 7.0, dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()
+        arr = lambda ts: (C.c_void_p * ndev)(*[t.data_ptr() for t in ts])      # noqa: E731
+        rc = L.lib().rdhip_errstate_jacobian_sharded_gather(comm.handle, model._handle, L.F64, N, arr(Xs), 13, 1, arr(Gs), code, 0, arr(stacks))
+        L.check(rc, comm.ctxs[0].handle)
+        comm.synchronize()
+        for r, (lo, hi) in enumerate(blocks):                       # every rank holds its own block
+            np.testing.assert_allclose(host(Gs[r]).transpose(0, 2, 1), Go[lo:hi], rtol=0, atol=TOL)
+        for r in range(ndev):
+            got = host(stacks[r]).transpose(0, 2, 1)
+            if mode == "none" or (mode == "root" and r != 0):
+                assert np.all(got == 7.0)                           # untouched
+            else:
+                np.testing.assert_allclose(got, Go, rtol=0, atol=TOL)
+    # Jacobian shards computed IN PLACE inside the root's stack: no copy for the root's own block
+    sat, osat = RD.Satellite(), O.satellite()
+    dm = RD.DiscretizedDynamics(sat, RD.RK4)
+    Zn = H.rand_rigid(rng, N, 6); t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    Jo, _ = osat.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    Zs, ts, dts, Js = [], [], [], []
+    stack0 = torch.zeros((N, 19, 13), dtype=torch.float64, device="cuda:0")
+    for r, (lo, hi) in enumerate(blocks):
+        dev = f"cuda:{r}"
+        Zs.append(torch.as_tensor(Zn[lo:hi]).to(dev)); ts.append(torch.as_tensor(t[lo:hi]).to(dev)); dts.append(torch.as_tensor(dt[lo:hi]).to(dev))
+        Js.append(stack0[lo:hi] if r == 0 else torch.zeros((hi - lo, 19, 13), dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    stacks = [stack0] + [torch.zeros(1, dtype=torch.float64, device=f"cuda:{r}") for r in range(1, ndev)]
+    rc = L.lib().rdhip_jacobian_sharded_gather(comm.handle, sat._handle, L.RK4, L.FORWARD_AD, L.F64, N, arr(Zs), arr(ts), arr(dts), arr(Js), None, L.GATHER_ROOT, 0, arr(stacks))
+    L.check(rc, comm.ctxs[0].handle)
+    comm.synchronize()
+    np.testing.assert_allclose(host(stack0).transpose(0, 2, 1), Jo, rtol=0, atol=TOL)
+    # the per-process form with one rank: rdhip_comm_create_rank(ctx, 1, 0, id)
+    c1 = P.Comm.from_torch_distributed(0)
+    out = torch.zeros(16, dtype=torch.float64, device="cuda:0")
+    src = torch.arange(16, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    c1.gather("all", [src], [16 * 8], [out])
+    c1.synchronize()
+    assert torch.equal(out, src)
+    with pytest.raises(ValueError):
+        c1.gather("root", [src], [16 * 8], [out], root=3)
+
+
 def test_baseline_config_sizes_c1_c2():
     """BASELINE.json configs[0] and configs[1] at their exact sizes.  C1: Cartpole (n=4, m=1), RK3 discrete_dynamics + discrete Jacobian on ONE
     trajectory of 101 knot points (examples/cartpole.jl:46: dt = 0.1; restated with the v0.4 calls), through the v0.3 spellings
