@@ -2,7 +2,9 @@
 #pragma once
 #include "common.hpp"
 #include <cstdint>
+#include <cstdlib>
 #include "kernels.hpp"
+#include "cascade.hpp"
 #include "implicit.hpp"
 
 namespace rd {
@@ -24,6 +26,20 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
     const unsigned grid = (unsigned)((a.N + 63) / 64);
     const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
+    using Cas = Cascade<decltype(Fn::m)>;
+    if constexpr (Cas::NB > 1) {
+        // one wavefront per cascade block + an IO wavefront (cascade.hpp): the latency chain of a step shrinks to the longest block's
+        static const char* mode = getenv("RDHIP_ROLLOUT");             // tuning switch: "plain" forces the one-lane-per-trajectory kernel
+        const bool plain = mode && mode[0] == 'p';
+        if (!plain && a.K < (1LL << 26) && a.N < (1LL << 26)) {            // (the IO wave's per-lane offsets are 32-bit)
+            constexpr int R = 4;
+            constexpr size_t lds = CascadeLds<Fn, Cas, R>::BYTES;
+            auto kern = rollout_cascade_kernel<Fn, T, Cas, R>;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3((Cas::NB + 1) * TILE), lds, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+            return hip_status(hipGetLastError());
+        }
+    }
     hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }

@@ -10,6 +10,7 @@
 namespace rd {
 
 constexpr int TILE = 64;   // knot points per wave = wave width on gfx950
+constexpr int ROLLOUT_PREFETCH = 4;   // rollout kernels: inputs are requested this many steps ahead
 
 template <class T> RD_DEV T sqrt_eps();
 template <> RD_DEV double sqrt_eps<double>() { return 1.4901161193847656e-08; }   // sqrt(eps(Float64))
@@ -110,45 +111,58 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     T x[NX], u[NU], y[NX];
-    long long ip = j * sj;                                    // the knot point that is advanced
+    const long long ip = j * sj;                              // knot 0 of this trajectory
     {
         const T* xs = X0 ? X0 + j * NX : Z + ip * NZ;
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xs[i];
     }
-    // The controls / times of the NEXT step are loaded before this step's arithmetic and the new state is stored after it: the loads are
-    // older than the stores, so waiting for them (one vmcnt counter for both on gfx950) does not wait for the stores just issued, and the
-    // stores of a step drain under the next step's arithmetic.  The chain is then bound by the fp64 latency of one RK step, not by memory
-    // (measured: 1.6 -> 1.05 us per RK4 step of the satellite, 0.74 with the next point).  The initial state is written AFTER the first prefetch (also when it was
-    // read from Z itself) so that the loop is entered with the same "loads, then NX stores" queue its back edge has: the compiler's
-    // waitcnt at the loop header then lets the stores stay in flight instead of draining them every step.
     if (K < 2) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) Z[ip * NZ + i] = x[i];
         return;
     }
-    T un[NU]; double hn = dtt[ip], tn = tt[ip];
+    // The controls / times of knot k + D are requested while step k is computed, and the new state is stored after the arithmetic:
+    //  * a rollout streams through memory it has never touched, so every request is an HBM miss; with a distance of ONE step the chain ran at
+    //    the memory latency (0.7-1.0 us per step for every model, the cartpole as slow as the satellite), D = ROLLOUT_PREFETCH steps hide it;
+    //  * the requests are older than the stores that follow them, so waiting for one (one vmcnt counter for both on gfx950) does not wait
+    //    for the stores just issued, and the stores of a step drain under the following steps' arithmetic;
+    //  * the initial state is written AFTER the first requests (also when it was read from Z itself) so that the loop is entered with the
+    //    same "loads, then NX stores" queue its back edge has: the compiler's waitcnt at the loop header then lets the stores stay in flight.
+    // The D slots live in registers (the loop is unrolled D-fold, the slot index is a constant).
+    constexpr int D = ROLLOUT_PREFETCH;
+    const long long last = K - 1, nsteps = K - 1;
+    T un[D][NU]; double hn[D], tn[D];
+    auto fetch = [&](int d, long long knot) {                  // knot <= K - 1: inside the trajectory, read unconditionally
+        const long long idx = ip + knot * sk;
+        hn[d] = dtt[idx]; tn[d] = tt[idx];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) un[i] = Z[ip * NZ + NX + i];
+        for (int i = 0; i < NU; ++i) un[d][i] = Z[idx * NZ + NX + i];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, d < last ? d : last);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) Z[ip * NZ + i] = x[i];
     __builtin_amdgcn_sched_barrier(0);
-    for (long long k = 1; k < K; ++k) {
-        const double h = hn; const T tk = (T)tn;
+    auto step = [&](long long k, int d) {                      // x_k -> x_{k+1}, inputs in slot d
+        const double h = hn[d]; const T tk = (T)tn[d];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(h) ? T(0) : un[i];
-        const long long inext = ip + sk;                      // knot k <= K-1: inside the trajectory, its inputs are read unconditionally
-        hn = dtt[inext]; tn = tt[inext];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) un[i] = Z[inext * NZ + NX + i];
+        for (int i = 0; i < NU; ++i) u[i] = is_terminal_dt(h) ? T(0) : un[d][i];
+        fetch(d, k + D < last ? k + D : last);
         __builtin_amdgcn_sched_barrier(0);                    // keep the loads above the arithmetic
         fn.eval(x, u, tk, (T)h, y);
-        T* Zk = Z + inext * NZ;
+        T* Zk = Z + (ip + (k + 1) * sk) * NZ;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x[i] = y[i]; Zk[i] = y[i]; }
-        ip = inext;
+    };
+    long long k = 0;
+    for (; k + D <= nsteps; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(k + d, d);
     }
+#pragma unroll
+    for (int d = 0; d + 1 < D; ++d) if (k + d < nsteps) step(k + d, d);      // at most D - 1 steps are left
 }
 
 // ------------------------------------------------------------------------------------------------------------

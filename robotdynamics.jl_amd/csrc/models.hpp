@@ -189,6 +189,17 @@ template <class T_, int WRENCH, bool BODY, bool DIAGJ = false> struct RigidBody 
 };
 inline bool host_is_diag3(const double* A) { return A[1] == 0 && A[2] == 0 && A[3] == 0 && A[5] == 0 && A[6] == 0 && A[7] == 0; }
 
+// ---- cascade structure of a model's dynamics (used by rollout_cascade_kernel, kernels.hpp) --------------------------------
+// A partition of the state into NB ordered blocks such that the time derivative of block b depends only on blocks 0..b (and on u, t).
+// A rigid body has one: the angular velocity drives itself (Euler's equation), the attitude follows from it (kinematics), the linear
+// motion follows from both (src/rigidbody.jl:213-236: xdot = [v or q*v ; kinematics(q, w) ; F/m (- w x v) ; J \ (tau - w x J w)], with
+// the wrench a function of q and u in every compiled-in rigid body).  NB = 0: no such structure declared (the plain rollout kernel).
+template <class Mdl> struct Cascade { static constexpr int NB = 0; static constexpr int block_of(int) { return 0; } };
+template <class T, int WRENCH, bool BODY, bool DIAGJ> struct Cascade<RigidBody<T, WRENCH, BODY, DIAGJ>> {
+    static constexpr int NB = 3;
+    static constexpr int block_of(int i) { return i >= 10 ? 0 : (i >= 3 && i < 7) ? 1 : 2; }       // w | q | r, v
+};
+
 // SatellitePair: x = [q1(4) w1(3) q2(4) w2(3)], u = [u1(3) u2(3)]
 template <class T_> struct SatellitePair {
     using T = T_;
@@ -309,6 +320,64 @@ template <class Mdl, int RULE> struct Fun {
         }
     }
 };
+
+// The same explicit rules with a hook on every stage point: `hk.template at<S>(xs)` sees (and may overwrite) the point at which stage S
+// evaluates the model.  rollout_cascade_kernel uses it to splice in the components other wavefronts own; the formulas are those of
+// Fun::eval above, operation for operation.
+template <int RULE> constexpr int rule_stages() { return RULE == RULE_EULER ? 1 : RULE == RULE_RK2 ? 2 : RULE == RULE_RK3 ? 3 : 4; }
+template <int RULE, class Mdl, class T, class Hook>
+RD_DEV void rk_hooked(const Mdl& m, const T (&x)[Mdl::NX], const T* u, T t, T h, T (&y)[Mdl::NX], Hook& hk) {
+    constexpr int NX = Mdl::NX;
+    static_assert(RULE == RULE_EULER || RULE == RULE_RK2 || RULE == RULE_RK3 || RULE == RULE_RK4, "explicit rules only");
+    T x0[NX], xs[NX], k[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0[i] = x[i];
+    hk.template at<0>(x0);
+    if constexpr (RULE == RULE_EULER) {
+        model_f(m, x0, u, t, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + k[i] * h;
+    } else if constexpr (RULE == RULE_RK2) {
+        model_f(m, x0, u, t, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[i] = x0[i] + k[i] * (h * T(0.5));
+        hk.template at<1>(xs);
+        model_f(m, xs, u, t + h * T(0.5), k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + k[i] * h;
+    } else if constexpr (RULE == RULE_RK3) {
+        T k1[NX], acc[NX];
+        model_f(m, x0, u, t, k1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k1[i] = k1[i] * h; xs[i] = x0[i] + k1[i] * T(0.5); }
+        hk.template at<1>(xs);
+        model_f(m, xs, u, t + h * T(0.5), k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k[i] = k[i] * h; acc[i] = k1[i] + k[i] * T(4); xs[i] = x0[i] - k1[i] + k[i] * T(2); }
+        hk.template at<2>(xs);
+        model_f(m, xs, u, t + h, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + (acc[i] + k[i] * h) * T(1.0 / 6.0);
+    } else {
+        T acc[NX];
+        const T h2 = h * T(0.5), h6 = h * T(1.0 / 6.0);
+        model_f(m, x0, u, t, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = x0[i] + k[i] * h2; }
+        hk.template at<1>(xs);
+        model_f(m, xs, u, t + h2, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = acc[i] + k[i] * T(2); xs[i] = x0[i] + k[i] * h2; }
+        hk.template at<2>(xs);
+        model_f(m, xs, u, t + h2, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = acc[i] + k[i] * T(2); xs[i] = x0[i] + k[i] * h; }
+        hk.template at<3>(xs);
+        model_f(m, xs, u, t + h, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x0[i] + (acc[i] + k[i]) * h6;
+    }
+}
 
 // ---- error-state layout of a LieState{QuatRotation,P} model (src/liestate.jl:75-131) at compile time --------------------
 // error index e <-> either a vector state index, or (rotation r, component j of its 3-vector)

@@ -1153,6 +1153,48 @@ def test_rollout_matches_oracle_and_is_idempotent():
     np.testing.assert_allclose(Zt.data, ref1[0], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("shape", [(64, 9), (130, 6), (37, 14), (200, 3), (64, 2), (5, 1), (256, 41)])
+@pytest.mark.parametrize("variant", ["satellite_world_rk4", "satellite_body_rk3", "satellite_fullJ_rk2", "quadrotor_world_rk4", "quadrotor_body_euler",
+                                     "satellite_world_rk4_f32"])
+def test_cascade_rollout_shapes_layouts_and_rules(variant, shape):
+    """The rigid bodies' rollout kernel (one wavefront per cascade block w | q | r,v plus an IO wavefront, csrc/cascade.hpp) against the oracle's
+    sequential rollout: whole and ragged 64-trajectory groups, step counts that are / are not multiples of the IO chunk (4), one and two
+    knots, knot-contiguous and time-major stacks, every explicit rule, world- and body-frame velocities, diagonal and full inertia, a
+    terminal knot point with dt = 0 in the middle of the data (its control reads as zero), with and without a separate x0."""
+    M, K = shape
+    rng = np.random.default_rng(1000 + 7 * M + K)
+    body = "_body_" in variant
+    if variant.startswith("satellite"):
+        Jm = np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]]) if "fullJ" in variant else np.diag([2.0, 3.0, 1.0])
+        model, om, mctl = RD.Satellite(mass=2.0, J=Jm, bodyframe=body), O.satellite(2.0, Jm, O.FRAME_BODY if body else O.FRAME_WORLD), 6
+    else:
+        model, om, mctl = RD.Quadrotor(bodyframe=body), O.quadrotor(O.FRAME_BODY if body else O.FRAME_WORLD), 4
+    rule, orule = {"rk4": (RD.RK4, O.RK4), "rk3": (RD.RK3, O.RK3), "rk2": (RD.RK2, O.RK2), "euler": (RD.Euler, O.EULER)}[variant.split("_")[2]]
+    f32 = variant.endswith("_f32")
+    dm = RD.DiscretizedDynamics(model, rule)
+    data = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
+    t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy()
+    dt = np.full((M, K), 0.02)
+    if K > 4:
+        dt[::3, K // 2] = 0.0                              # terminal-style knots inside some trajectories: x_{k+1} = x_k + 0 * f, control ignored
+    x0 = data[:, 0, :13].copy(); x0[:, 7:] *= 0.5
+    for tm in (False, True):
+        for with_x0 in (False, True):
+            ref = om.rollout(orule, data, t, dt, X0=x0 if with_x0 else None)
+            order = (1, 0, 2) if tm else (0, 1, 2)
+            cast = (lambda a: a.astype(np.float32)) if f32 else (lambda a: a)
+            stack = {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(order)))).cuda(),
+                     "t": torch.as_tensor(np.ascontiguousarray(t.T if tm else t)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T if tm else dt)).cuda()}
+            J = RD.alloc_jacobians(dm, K * M, stack["data"])
+            RD.rollout_jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, stack, torch.as_tensor(cast(x0)).cuda() if with_x0 else None, time_major=tm)
+            got = host(stack["data"]).astype(np.float64)
+            got = got.transpose(order) if tm else got
+            if f32:
+                np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+            else:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
+
+
 @pytest.mark.parametrize("case", ["satellite_tm_large", "satellite_traj_major", "cartpole_tm_large", "quadrotor_tm_host", "custom_tm_large",
                                   "satellite_implicit_traj_major"])
 def test_rollout_then_jacobians_in_one_call(case):

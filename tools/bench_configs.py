@@ -271,6 +271,17 @@ def main():
         jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
         jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
         return
+    if a.only == "rollout":
+        rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+        rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        rollout_case("quadrotor RK4 rollout fp64 4096 traj x 101 knots", quad, 4096, 101, RD.RK4, f64, 10, rng)
+        rollout_case("satellite RK3 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK3, f64, 10, rng)
+        rollout_case("satellite RK4 rollout fp64 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 10, rng)
+        rollout_case("satellite RK4 rollout fp64 65536 traj x 32 knots", sat, 65536, 32, RD.RK4, f64, 10, rng)
+        rollout_case("satellite RK4 rollout fp64 262144 traj x 16 knots", sat, 262144, 16, RD.RK4, f64, 5, rng)
+        rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
+        rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        return
     if a.only == "rolljac":
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
