@@ -361,6 +361,87 @@ RD_DEV void cascade_io_wave(long long K, long long M, T* __restrict__ Z, const d
     }
 }
 
+// ---- FiniteDifference along the cascade ---------------------------------------------------------------------------------------------
+// Forward differences evaluate the discrete dynamics 1 + (n+m) times per knot point (src/jacobian_gen.jl:643-685, FiniteDiff's forward
+// default).  Perturbing component c leaves every block UPSTREAM of c's block bit-for-bit unchanged -- those rows of the column are exact
+// zeros in the reference as well -- so the perturbed evaluation only integrates the blocks from c's block downwards, reading the upstream
+// blocks' stage points from the base evaluation (kept in registers: 4 stages x 7 components for a rigid body).  Columns are compile-time
+// constants, the model's dynamics function is instantiated per column class and the untouched rows fold away: 4 400 instead of 6 200 fp64
+// instructions per satellite knot point, the base evaluation included (a position or velocity column costs the r,v block alone).
+template <class Fn, class Cas> struct FdBaseHook {             // base evaluation: remember the stage points of the blocks that have a downstream
+    using T = typename Fn::T;
+    static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
+    T (&S)[NS][NX];
+    template <int St> RD_DEV void at(T (&xs)[NX]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) if (Cas::block_of(i) < Cas::NB - 1) S[St][i] = xs[i];
+    }
+};
+template <class Fn, class Cas, int B> struct FdColHook {        // perturbed evaluation from block B downwards
+    using T = typename Fn::T;
+    static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
+    const T (&S)[NS][NX];
+    template <int St> RD_DEV void at(T (&xs)[NX]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) if (Cas::block_of(i) < B) xs[i] = S[St][i];
+    }
+};
+template <class Fn, class T, class Plan, class Cas, int G, int C> struct FdCascadeCols {
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NS = rule_stages<Fn::RULE_ID>();
+    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&f0)[NX], const T (&S)[NS][NX]) {
+        if constexpr (C < NZ) {
+            if constexpr (Plan::wave_of(C) == G) {
+                constexpr int B = C < NX ? Cas::block_of(C) : Cas::control_block(C - NX);
+                T x1[NX], u1[NU], y1[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x1[i] = fr.x[i];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) u1[i] = fr.u[i];
+                T eps;
+                if constexpr (C < NX) { eps = fd_step<T>(fr.x[C]); x1[C] = x1[C] + eps; }
+                else { eps = fd_step<T>(fr.u[C - NX]); if (!fr.term) u1[C - NX] = u1[C - NX] + eps; }     // a terminal knot point evaluates f with u = 0 throughout
+                // (opaque copies: without them the compiler merges sub-expressions ACROSS columns -- every column starts from the same point --
+                // and the merged values stay live through the whole column sequence: 217 spilled registers)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(x1[i]));
+#pragma unroll
+                for (int i = 0; i < NU; ++i) asm volatile("" : "+v"(u1[i]));
+                FdColHook<Fn, Cas, B> hk{S};
+                rk_hooked<Fn::RULE_ID>(fn.m, x1, u1, fr.t, fr.h, y1, hk);
+                const T inv = T(1) / eps;                     // one division per column (the quotient differs from (f1-f0)/eps by <= 1 ulp)
+                T col[NY];
+#pragma unroll
+                for (int i = 0; i < NY; ++i) col[i] = (Cas::block_of(i) < B) ? T(0) : (y1[i] - f0[i]) * inv;
+                fr.put_at(C, col);
+                __builtin_amdgcn_sched_barrier(0);          // finish this column before the next one starts: interleaved columns spill
+            }
+            FdCascadeCols<Fn, T, Plan, Cas, G, C + 1>::run(fn, fr, f0, S);
+        }
+    }
+};
+template <class Fn, class T, class Plan, class Cas> struct FdCascadeBody {
+    static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
+    template <int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&f0)[NX], const T (&S)[NS][NX]) {
+        if constexpr (G < Plan::NG) {
+            if (fr.g == G) FdCascadeCols<Fn, T, Plan, Cas, G, 0>::run(fn, fr, f0, S);
+            else waves<G + 1>(fn, fr, f0, S);
+        }
+    }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
+        T f0[NX], S[NS][NX];
+        FdBaseHook<Fn, Cas> hb{S};
+        rk_hooked<Fn::RULE_ID>(fn.m, fr.x, fr.u, fr.t, fr.h, f0, hb);
+        if (fr.g == Plan::value_wave && fr.want_y) fr.put_value(Fn::NX + Fn::NU, f0);
+        waves<0>(fn, fr, f0, S);
+    }
+};
+template <class Fn, class T, class Plan, class Cas, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_cascade_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                                 const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    jac_split_loop<Fn, T, Plan, NC, FdCascadeBody<Fn, T, Plan, Cas>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+}
+
 template <class Fn, class T, class Cas, int R, int B> struct CascadeWaves {
     static RD_DEV void run(int wave, const Fn& fn, long long K, long long M, long long sj, long long sk, T* Z, const double* tt, const double* dtt,
                            const T* X0, int nfull) {

@@ -14,6 +14,9 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_
 // which (model, rule) pairs get the compile-time-column ForwardAD kernel (big code, structural sparsity folded)
 template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; static constexpr int NC = 0; using Plan = void; };
 
+// cost-balanced column plan of the cascade FiniteDifference kernel (defined next to the model's other plans)
+template <class Mdl> struct FdPlanOf { static constexpr bool value = false; using Plan = void; };
+
 template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
     if (a.N == 0) return RDHIP_OK;
@@ -151,6 +154,11 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             return launch_jac_kernel<Fn, T, DefPlan>(jac_ad_loop_kernel<Fn, T, DefPlan>, fn, a);
         }
     } else if (diff == RDHIP_FINITE_DIFF) {
+        // models with a cascade structure and a column plan: perturbed evaluations integrate only the blocks a column can change (cascade.hpp)
+        if constexpr (RULE != RULE_CONTINUOUS && Cascade<Mdl>::NB > 1 && FdPlanOf<Mdl>::value) {
+            using Plan = typename FdPlanOf<Mdl>::Plan;
+            if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, fn, a);
+        }
         if constexpr (split_fits)
             if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, fn, a);
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);

@@ -20,6 +20,13 @@ using QuadErrPlan = TablePlan<16, 4, 0, /*r*/ 0, 0, 0, /*phi*/ 0, 0, 1, /*v*/ 0,
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { using Plan = SatErrPlan; };
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { using Plan = QuadErrPlan; };
 
+// FiniteDifference along the cascade: a column costs the blocks it can change -- r, v, uF: the r,v block (~141 fp64 instructions of an RK4
+// step); q: q + r,v (~231); w, tau and the quadrotor's rotors: everything (~312).  Four waves of ~1030-1190 (compiled counts).
+using SatFdPlan = TablePlan<19, 4, 3, /*r*/ 3, 3, 0, /*q*/ 2, 2, 2, 2, /*v*/ 3, 3, 3, /*w*/ 0, 0, 0, /*uF*/ 3, 3, 3, /*tau*/ 1, 1, 1>;
+using QuadFdPlan = TablePlan<17, 4, 3, /*r*/ 3, 0, 0, /*q*/ 2, 2, 2, 2, /*v*/ 3, 3, 3, /*w*/ 0, 0, 0, /*u*/ 1, 1, 1, 3>;
+template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>> { static constexpr bool value = true; using Plan = SatFdPlan; };
+template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>> { static constexpr bool value = true; using Plan = QuadFdPlan; };
+
 #define RD_RIGID_VARIANT_DECL(name)                                                                       \
     int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                     \
     int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);                   \

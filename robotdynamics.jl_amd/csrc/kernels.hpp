@@ -1027,6 +1027,11 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_chain_split_kernel
 }
 
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
+template <class T> RD_DEV T fd_step(T zc) {             // eps_j = max(sqrt(eps) |z_j|, sqrt(eps))
+    const T se = sqrt_eps<T>();
+    const T az = zc < T(0) ? -zc : zc;
+    return (se * az > se) ? se * az : se;
+}
 template <class Fn, class T, class Plan> struct FdBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
         constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG;

@@ -194,10 +194,13 @@ inline bool host_is_diag3(const double* A) { return A[1] == 0 && A[2] == 0 && A[
 // A rigid body has one: the angular velocity drives itself (Euler's equation), the attitude follows from it (kinematics), the linear
 // motion follows from both (src/rigidbody.jl:213-236: xdot = [v or q*v ; kinematics(q, w) ; F/m (- w x v) ; J \ (tau - w x J w)], with
 // the wrench a function of q and u in every compiled-in rigid body).  NB = 0: no such structure declared (the plain rollout kernel).
-template <class Mdl> struct Cascade { static constexpr int NB = 0; static constexpr int block_of(int) { return 0; } };
+// control_block(j): the first block whose derivative reads control j (a satellite's thrust only enters the linear acceleration, its torque
+// Euler's equation; a rotor of the quadrotor produces both).
+template <class Mdl> struct Cascade { static constexpr int NB = 0; static constexpr int block_of(int) { return 0; } static constexpr int control_block(int) { return 0; } };
 template <class T, int WRENCH, bool BODY, bool DIAGJ> struct Cascade<RigidBody<T, WRENCH, BODY, DIAGJ>> {
     static constexpr int NB = 3;
     static constexpr int block_of(int i) { return i >= 10 ? 0 : (i >= 3 && i < 7) ? 1 : 2; }       // w | q | r, v
+    static constexpr int control_block(int j) { return (WRENCH == WRENCH_SATELLITE && j < 3) ? 2 : 0; }
 };
 
 // SatellitePair: x = [q1(4) w1(3) q2(4) w2(3)], u = [u1(3) u2(3)]
