@@ -98,7 +98,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) { if (c->own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); else c->stream = (hipStream_t)stream; }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc(&c->d_flag, 256);
+    if (e == hipSuccess) e = hipMalloc(&c->d_flag, (size_t)(1 + IMPLICIT_FLAG_WORDS) * sizeof(int));
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }

@@ -61,6 +61,9 @@ inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
     return (unsigned)(ntiles < g ? ntiles : g);
 }
 
+// implicit kernels: flag words of a context (word 0: whole batch; words 1 .. : one per 64-knot tile)
+constexpr long long IMPLICIT_FLAG_WORDS = 1 << 20;
+
 struct ModelDesc {
     int kind, rot, frame;
     int n, m, e;

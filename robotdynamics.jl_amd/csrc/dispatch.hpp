@@ -245,13 +245,17 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     }
     constexpr size_t lds = ImplicitLds<Mdl, T>::BYTES;
     static_assert(lds <= 160 * 1024, "Newton matrices do not fit the LDS of a CU");
-    const unsigned gridn = (unsigned)((a.N + ImplicitLds<Mdl, T>::KP - 1) / ImplicitLds<Mdl, T>::KP);     // Newton kernels: KP knot points per wave
-    // modes 0, 1, 3: the register kernel first; the LDS kernel (real row exchanges) behind it, gated on the flag the first one raises
+    const long long nblk = (a.N + ImplicitLds<Mdl, T>::KP - 1) / ImplicitLds<Mdl, T>::KP;               // Newton kernels: KP knot points per wave
+    const unsigned gridn = tile_grid(lds, TILE, nblk);                                                    // persistent
+    // modes 0, 1, 3: the register kernel first; the LDS kernel (real row exchanges) behind it, gated on the flags the first one raises
     const int* gate = nullptr;
     const unsigned gridr = (unsigned)((a.N + TILE - 1) / TILE);
     constexpr bool reg_is_exact = ImplicitRegOps<Mdl, T>::PIVOT;     // small models pivot in registers: no second pass
+    // one flag word per 64-knot tile when the context has enough of them (written unconditionally by the register kernel: no memset)
+    const int tile_flags = (mode != 3 && (long long)gridr <= IMPLICIT_FLAG_WORDS) ? 1 : 0;
+    constexpr size_t lds_reg = ImplicitRegOps<Mdl, T>::LDS_BYTES;
     if (a.flag && !reg_is_exact) {
-        if (hipMemsetAsync(a.flag, 0, sizeof(int), a.stream) != hipSuccess) return RDHIP_ERR_HIP;
+        if (!tile_flags && hipMemsetAsync(a.flag, 0, sizeof(int), a.stream) != hipSuccess) return RDHIP_ERR_HIP;
         gate = a.flag;
     }
     if (mode == 3) {          // rollout: a.N trajectories of a.K knot points
@@ -260,21 +264,21 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_rollout_kernel<Mdl, T>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {
-        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), TILE * Mdl::NX * sizeof(T), a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag);
+        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
     } else {
-        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag);
+        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, false>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, gate);
+        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, gate, tile_flags);
     }
     return hip_status(hipGetLastError());
 }

@@ -176,19 +176,40 @@ template <class Mdl, class T> struct ImplicitOps {
     }
 };
 
+// gate == NULL: every block of KP knot points is solved.  gate != NULL (second pass behind the register kernel): tile_flags = 0 -> the whole
+// batch iff gate[0] is set; tile_flags = 1 -> only the blocks that overlap a 64-knot tile whose word gate[1 + tile] the register kernel raised
+// (a row exchange somewhere no longer sends the whole batch through this 12x slower kernel).  Persistent grid: with nothing raised the pass
+// costs a launch of <= one workgroup per CU, not a sweep of N / KP workgroups with 93 KB of LDS each.
 template <class Mdl, class T, bool WANT_J>
 __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate) {
+                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate, int tile_flags) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (gate && *gate == 0) return;                                      // second pass behind the register kernel: only if a row exchange was needed
-    if (threadIdx.x >= L::KP) return;                                    // lanes without a matrix slot stay idle
+    if (gate && !tile_flags && *gate == 0) return;                       // second pass behind the register kernel: only if a row exchange was needed
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
     int* piv = reinterpret_cast<int*>(smem + (size_t)L::KP * L::RSA * sizeof(T)) + lane * 16;
-    const long long k = (long long)blockIdx.x * L::KP + lane;
+    const long long nblk = (N + L::KP - 1) / L::KP;
+    for (long long base = blockIdx.x; base < nblk; base += (long long)TILE * gridDim.x) {
+    // the workgroup's next 64 blocks are base + l * gridDim.x: lane l looks at the tile words of block l, ONE memory round trip decides all of them
+    unsigned long long todo = ~0ull;
+    if (gate && tile_flags) {
+        const long long b = base + (long long)lane * gridDim.x;
+        int raised = 0;
+        if (b < nblk) {
+            const long long first = b * L::KP, lastk = (first + L::KP < N ? first + L::KP : N) - 1;
+            raised = gate[1 + first / TILE] | gate[1 + lastk / TILE];
+        }
+        todo = __ballot(raised != 0);
+    }
+    for (int l = 0; l < TILE; ++l) {
+    const long long blk = base + (long long)l * gridDim.x;
+    if (blk >= nblk) break;
+    if (!((todo >> l) & 1)) continue;
+    if (threadIdx.x >= L::KP) continue;                                  // lanes without a matrix slot stay idle
+    const long long k = blk * L::KP + lane;
     const bool active = k < N;
     const long long kc = active ? k : N - 1;
     const double hd = dtt[kc];
@@ -232,6 +253,8 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
         Ops::template fill_cols<0>(m, xm, u, tj, tm, h, A, f);
         Ops::lu(A, piv);
         Ops::template ift_cols<0>(m, xm, u, tj, h, term, A, piv, J + kc * NX * NZ, active);
+    }
+    }
     }
 }
 
@@ -344,39 +367,67 @@ template <class Mdl, class T> struct ImplicitRegOps {
         return need;
     }
     // IFT columns with the register factors: J[:, C] = -A2^{-1} J1[:, C]
-    // Every finished column goes through a wave-private LDS buffer (64 x n values) so that the global stores are coalesced: a lane owns a
-    // knot point, i.e. its column entries sit n(n+m) values apart from its neighbour's -- written directly, every store instruction touches
-    // 64 different cache lines (that was half of the kernel's time); transposed, one store instruction writes the columns of 64 / CW knot
-    // points as runs of n consecutive values.  J0 = the wave's first Jacobian, nk = its number of valid knot points.
-    static constexpr int CW = NX <= 8 ? 8 : 16;                      // lanes per knot point in the store sweep
+    // Finished columns go through a wave-private LDS buffer, CG = 4 columns at a time, so that the global stores are coalesced: a lane owns
+    // a knot point, i.e. its column entries sit n(n+m) values apart from its neighbour's -- written directly, every store instruction touches
+    // 64 different cache lines.  Transposed, a knot point's CG columns are one run of CG n consecutive values (416 B for a rigid body) and a
+    // store instruction writes 16 B per lane over 2-3 such runs (with one column per sweep and 8 B per lane the kernel issued 304 store
+    // instructions per tile over 104-B runs, half of its time; now 130).  Rows are only sizeof(T)-aligned: the 16-B stores may be misaligned
+    // by 8 B, which gfx950 global memory accepts.  J0 = the wave's first Jacobian, nk = its number of valid knot points.
+    static constexpr int CG = 4;                                      // columns per LDS group
+    static constexpr int RS = (CG * NX) | 1;                          // lane stride of the group buffer (odd: conflict-free lane-strided writes)
+    static constexpr size_t LDS_BYTES = (size_t)TILE * RS * sizeof(T);
     template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX],
                                                  T* sb, T* J0, int nk) {
         if constexpr (C < NX + NU) {
-            T col[NX];
-            Ops::template jcol<C>(m, xm, u, tj, col);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) col[i] = (C < NX) ? col[i] * (h * T(0.5)) + ((i == C) ? T(1) : T(0)) : col[i] * h;
-            solve(a, piv, col);
-            const T sc = (C >= NX && term) ? T(0) : T(-1);           // control columns of a terminal knot point are zero
+            constexpr int G = (NX + NU - C) < CG ? (NX + NU - C) : CG;       // columns of this group
             const int lane = threadIdx.x;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sb[lane * NX + i] = col[i] * sc;
+            group_col<C, 0, G>(m, xm, u, tj, h, term, a, piv, sb + lane * RS);
             wave_sync();
-            const int e = lane % CW, kq = lane / CW;
+            // sweep: knot point kk's run of G*NX values starts at J0 + kk * NX * (NX + NU) + C * NX; V values (16 bytes) per lane
+            constexpr int V = 16 / (int)sizeof(T), RUN = G * NX, UNITS = RUN / V, TAIL = RUN - UNITS * V;
+            typedef T VT __attribute__((ext_vector_type(16 / sizeof(T)), aligned(sizeof(T))));
+            constexpr int NIT = (TILE * UNITS + TILE - 1) / TILE;
 #pragma unroll
-            for (int it = 0; it < CW; ++it) {                        // TILE / (TILE / CW) sweeps of TILE / CW knot points
-                const int kk = it * (TILE / CW) + kq;
-                if (e < NX && kk < nk) J0[(size_t)kk * NX * (NX + NU) + C * NX + e] = sb[kk * NX + e];
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * TILE + lane, kk = e / UNITS, un = e - kk * UNITS;
+                if (kk < nk) {
+                    VT v;
+#pragma unroll
+                    for (int q = 0; q < V; ++q) v[q] = sb[kk * RS + un * V + q];
+                    *reinterpret_cast<VT*>(J0 + (size_t)kk * NX * (NX + NU) + C * NX + un * V) = v;
+                }
+            }
+            if constexpr (TAIL > 0) {                                 // the values behind the last whole 16-byte unit of every run
+                for (int e = lane; e < nk * TAIL; e += TILE) {
+                    const int kk = e / TAIL, q = e - kk * TAIL;
+                    J0[(size_t)kk * NX * (NX + NU) + C * NX + UNITS * V + q] = sb[kk * RS + UNITS * V + q];
+                }
             }
             wave_sync();
-            ift_cols<C + 1>(m, xm, u, tj, h, term, a, piv, sb, J0, nk);
+            ift_cols<C + G>(m, xm, u, tj, h, term, a, piv, sb, J0, nk);
+        }
+    }
+    // column C + g of the group into the lane's row of the buffer (compile-time recursion over g)
+    template <int C, int g, int G> static RD_DEV void group_col(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, bool term, const T (&a)[NX][NX],
+                                                                const int (&piv)[NX], T* row) {
+        if constexpr (g < G) {
+            T col[NX];
+            Ops::template jcol<C + g>(m, xm, u, tj, col);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) col[i] = (C + g < NX) ? col[i] * (h * T(0.5)) + ((i == C + g) ? T(1) : T(0)) : col[i] * h;
+            solve(a, piv, col);
+            const T sc = (C + g >= NX && term) ? T(0) : T(-1);       // control columns of a terminal knot point are zero
+#pragma unroll
+            for (int i = 0; i < NX; ++i) row[g * NX + i] = col[i] * sc;
+            __builtin_amdgcn_sched_barrier(0);                    // one column at a time: interleaved columns cost the second wave per SIMD
+            group_col<C, g + 1, G>(m, xm, u, tj, h, term, a, piv, row);
         }
     }
 };
 
 template <class Mdl, class T, bool WANT_J>
-__global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                                                     T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, int* __restrict__ flag) {
+__global__ void __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(2))) implicit_midpoint_reg_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                                                     T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, int* __restrict__ flag, int tile_flags) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using R = ImplicitRegOps<Mdl, T>;
     const long long k = (long long)blockIdx.x * TILE + threadIdx.x;
@@ -407,7 +458,12 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_reg_kernel(Mdl m, long
         const long long k0 = (long long)blockIdx.x * TILE;
         R::template ift_cols<0>(m, xm, u, tj, h, term, a, piv, reinterpret_cast<T*>(smem_reg), J + k0 * NX * NZ, (int)((N - k0) < TILE ? (N - k0) : TILE));
     }
-    if (need && flag) *flag = 1;
+    // "partial pivoting would have exchanged rows": per 64-knot tile (word 1 + tile, written unconditionally: no memset in front of the
+    // launch) or, for batches with more tiles than the context holds words for, the single word 0 (cleared by the host)
+    if (flag) {
+        if (tile_flags) { const bool any = __any(need); if (threadIdx.x == 0) flag[1 + blockIdx.x] = any ? 1 : 0; }
+        else if (need) *flag = 1;
+    }
 }
 
 template <class Mdl, class T>

@@ -219,7 +219,7 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ny * ts; }
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
@@ -379,23 +379,25 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N, K = a.K; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* Y = a.Y; void* J = a.J; void* J2 = a.J2; const void* X0 = a.X0;
     int iters = a.newton_iters; double tol = a.newton_tol; void* nul = nullptr;
-    const unsigned grid = (unsigned)(mode == 2 ? (N + 63) / 64 : (N + k->knots - 1) / k->knots);
+    const long long nblk = (N + k->knots - 1) / k->knots;
+    const unsigned grid = (unsigned)(mode == 2 ? (N + 63) / 64 : nblk);
     if (mode == 2) { void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, &J2, &J}; return launch(M, k, grid, a.stream, args); }
-    // n <= 14: the register kernel first (exact for n <= 6, where it pivots in registers); the LDS kernel behind it gated on the flag
+    // n <= 14: the register kernel first (exact for n <= 6, where it pivots in registers); the LDS kernel behind it gated on the flags
     const int* gate = nullptr;
+    const unsigned gr = (unsigned)((N + 63) / 64);
+    int tile_flags = (mode != 3 && (long long)gr <= IMPLICIT_FLAG_WORDS) ? 1 : 0;      // one word per 64-knot tile, written unconditionally
     if (a.flag && M.n <= 14) {
         JitKernel* kr; rc = jit_get(M, mode == 0 ? JOP_IMPLICIT_X_REG : mode == 1 ? JOP_IMPLICIT_J_REG : JOP_IMPLICIT_ROLLOUT_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
         int* flag = a.flag;
-        if (M.n > 6 && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
-        const unsigned gr = (unsigned)((N + 63) / 64);
+        if (M.n > 6 && !tile_flags && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
         if (mode == 3) { if (K == 0) return RDHIP_OK; void* ar[] = {fn.data(), &K, &N, &Z, &t, &dt, &X0, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
-        else { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &flag}; rc = launch(M, kr, gr, a.stream, ar); }
+        else { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &flag, &tile_flags}; rc = launch(M, kr, gr, a.stream, ar); }
         if (rc || M.n <= 6) return rc;
         gate = flag;
     }
     if (mode == 3) { if (K == 0) return RDHIP_OK; void* args[] = {fn.data(), &K, &N, &Z, &t, &dt, &X0, &iters, &tol, &gate}; return launch(M, k, grid, a.stream, args); }
-    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &gate};
-    return launch(M, k, grid, a.stream, args);
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, mode == 1 ? (void*)&J : (void*)&nul, &iters, &tol, &gate, &tile_flags};
+    return launch(M, k, tile_grid(k->lds, 64, nblk), a.stream, args);
 }
 
 }  // namespace rd
