@@ -137,9 +137,27 @@ def secondary_metrics(dev, reps):
     b = 13 * 8 + 13 * 12 * 8
     out["errstate_jacobian_quadrotor"] = {"knot_points": Nq, "value": Nq / (us * 1e-6), "unit": "error-state Jacobians/s", "us_per_launch": us, "bytes_per_knot": b,
                                           "frac_of_hbm_peak": Nq * b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    # the other diff methods / rules on the headline batch (same bytes per knot point as the headline kernel)
+    dm = RD.DiscretizedDynamics(sat, RD.RK4)
+    dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
+    Jx = [RD.alloc_jacobians(dm, N, Z.data) for _ in range(NBUF)]
+    for key, fun, diff in (("jacobian_finite_difference_rk4_satellite", dm, RD.FiniteDifference()),
+                           ("jacobian_implicit_midpoint_ift_satellite", dmi, RD.ImplicitFunctionTheorem(RD.ForwardAD()))):
+        calls = [RD.prepare_jacobian(RD.StaticReturn(), diff, fun, Jx[k], Xs[k], Z) for k in range(NBUF)]
+        us = _timed_us(lambda i: calls[i % NBUF](), max(20, reps // 4))
+        out[key] = {"knot_points": N, "value": N / (us * 1e-6), "unit": "knot-point Jacobians/s", "us_per_launch": us, "bytes_per_knot": BYTES_PER_KNOT,
+                    "frac_of_hbm_peak": N * BYTES_PER_KNOT / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    del Jx
+    # rollout!: one GPU's share of C5's satellite half, 512 trajectories x 256 knot points, fp32 -- a latency chain, not a stream
+    Mr, Kr = 512, 256
+    zr, _, _ = synthetic_inputs(Mr * Kr, 12)
+    stack = {"data": torch.as_tensor(zr.astype(np.float32).reshape(Mr, Kr, NZ)).to(dev), "t": torch.as_tensor(np.tile(np.arange(Kr) * 0.01, (Mr, 1))).to(dev),
+             "dt": torch.full((Mr, Kr), 0.01, dtype=torch.float64, device=dev)}
+    us = _timed_us(lambda i: RD.rollout_(RD.StaticReturn(), dm, stack), 20, warm=2)
+    out["rollout_rk4_satellite_fp32"] = {"trajectories": Mr, "knot_points_per_trajectory": Kr, "value": Mr * (Kr - 1) / (us * 1e-6), "unit": "simulated steps/s",
+                                         "us_per_launch": us, "us_per_step": us / (Kr - 1)}
     # 16 x 4096: separate launches vs one fused launch
     nbt, per = 16, 4096
-    dm = RD.DiscretizedDynamics(sat, RD.RK4)
     Zs = []
     for k in range(nbt):
         zn, tt, dd = synthetic_inputs(per, 100 + k)

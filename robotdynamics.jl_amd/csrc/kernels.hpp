@@ -487,19 +487,21 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
     double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = bt.ntiles();
-    // tile schedule of this workgroup: tile, tile + tstep, ... < tend
-#if defined(RD_TILE_MAP) && RD_TILE_MAP == 1     // tuning: a contiguous block of tiles per workgroup
-    const long long tpw = (ntiles + gridDim.x - 1) / gridDim.x;
-    long long tile = blockIdx.x * tpw;
-    const long long tend = (tile + tpw < ntiles) ? tile + tpw : ntiles, tstep = 1;
-#elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: a contiguous range of tiles per XCD (blockIdx % 8), strided inside it
-    const long long ntx = (ntiles + 7) / 8, xcd = blockIdx.x % 8;
-    long long tile = xcd * ntx + blockIdx.x / 8;
-    const long long tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles, tstep = gridDim.x / 8;
+    // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): when the
+    // grid is a multiple of 8, every XCD walks its OWN contiguous eighth of the tiles, strided over its workgroups -- each XCD's L2 and
+    // address-translation caches then see one sequential stream instead of every 8th slab of the whole output (measured against the plain
+    // `tile = blockIdx, step = gridDim` order: +2 % at 1 M knot points, +4 % at 2-4 M, level at 65 536; a contiguous range per WORKGROUP
+    // instead costs 5-9 %).
+    long long tile, tend, tstep;
+#if defined(RD_TILE_MAP) && RD_TILE_MAP == 0     // tuning: the plain order
+    if (false) {
 #else
-    long long tile = blockIdx.x;
-    const long long tend = ntiles, tstep = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
 #endif
+        const long long ntx = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+        tile = xcd * ntx + (blockIdx.x >> 3);
+        tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = gridDim.x >> 3;
+    } else { tile = blockIdx.x; tend = ntiles; tstep = gridDim.x; }
     if (tile >= tend) return;
 
     if (wave < NG) {

@@ -1320,6 +1320,12 @@ class PreparedJacobian:
         if not isinstance(Z, PackedTrajectory):
             raise TypeError("PreparedJacobian needs a PackedTrajectory")
         model, rule = _model_rule(fun)
+        if rule == L.IMPLICIT_MIDPOINT:                      # src/integration.jl:517-538: implicit rules differentiate through the implicit function theorem
+            if not isinstance(diff, ImplicitFunctionTheorem):
+                raise ValueError(f"Must call jacobian! on an implicit model with the ImplicitFunctionTheorem diff method. Got {type(diff).__name__}.")
+            diff = diff.diff
+        elif isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
         n, m = _check_traj(fun, Z)
         N = len(Z)
         _dense(J, (N, n, n + m), "J", transposed_last2=True)

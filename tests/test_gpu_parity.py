@@ -211,6 +211,14 @@ def test_prepared_jacobian_matches_the_checked_call():
     assert torch.equal(J1, J2) and torch.equal(Y1, Y2)
     with pytest.raises(ValueError):
         RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dm, J2[:, :, :5], Y2, Z)
+    # implicit rules: the diff method is the implicit function theorem, for the prepared call as for the checked one
+    dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    ift = RD.ImplicitFunctionTheorem(RD.ForwardAD())
+    RD.jacobian_(RD.StaticReturn(), ift, dmi, J1, Y1, Z)
+    RD.prepare_jacobian(RD.StaticReturn(), ift, dmi, J2, Y2, Z)()
+    assert torch.equal(J1, J2) and torch.equal(Y1, Y2)
+    with pytest.raises(ValueError):
+        RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dmi, J2, Y2, Z)
 
 
 def test_degenerate_batch_sizes_of_the_pair_operators():
