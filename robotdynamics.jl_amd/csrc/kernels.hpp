@@ -487,16 +487,19 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
     double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = bt.ntiles();
-    // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): when the
-    // grid is a multiple of 8, every XCD walks its OWN contiguous eighth of the tiles, strided over its workgroups -- each XCD's L2 and
-    // address-translation caches then see one sequential stream instead of every 8th slab of the whole output (measured against the plain
-    // `tile = blockIdx, step = gridDim` order: +2 % at 1 M knot points, +4 % at 2-4 M, level at 65 536; a contiguous range per WORKGROUP
-    // instead costs 5-9 %).
+    // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  For long
+    // launches (>= 64 tiles per workgroup, i.e. from ~1 M knot points on a whole chip) every XCD walks its OWN contiguous eighth of the tiles,
+    // strided over its workgroups: each XCD's L2 and address-translation caches then see one sequential stream instead of every 8th slab of a
+    // multi-GB output (measured against the plain `tile = blockIdx, step = gridDim` order: 0.67 -> 0.72-0.77 of the HBM peak at 2-4 M knot
+    // points, +2 % at 1 M).  Short launches keep the plain order: with a handful of tiles per workgroup the XCD ranges cost 1-4 % (and 15 % for
+    // 64 fused batches of 1 024 knot points); a contiguous range per WORKGROUP costs 5-9 % at every size.
     long long tile, tend, tstep;
 #if defined(RD_TILE_MAP) && RD_TILE_MAP == 0     // tuning: the plain order
     if (false) {
-#else
+#elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: XCD ranges at every size
     if ((gridDim.x & 7) == 0) {
+#else
+    if ((gridDim.x & 7) == 0 && ntiles >= 64 * (long long)gridDim.x) {
 #endif
         const long long ntx = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
         tile = xcd * ntx + (blockIdx.x >> 3);
