@@ -412,6 +412,12 @@ template <class Fn, class T, class Plan, class Cas, int G, int C> struct FdCasca
                 T col[NY];
 #pragma unroll
                 for (int i = 0; i < NY; ++i) col[i] = (Cas::block_of(i) < B) ? T(0) : (y1[i] - f0[i]) * inv;
+                if constexpr (C >= NX) {                     // control columns of a terminal knot point: f does not see u, the column is exactly zero
+                    if (fr.term) {
+#pragma unroll
+                        for (int i = 0; i < NY; ++i) col[i] = T(0);
+                    }
+                }
                 fr.put_at(C, col);
                 __builtin_amdgcn_sched_barrier(0);          // finish this column before the next one starts: interleaved columns spill
             }

@@ -1161,6 +1161,43 @@ def test_rollout_matches_oracle_and_is_idempotent():
     np.testing.assert_allclose(Zt.data, ref1[0], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("variant", ["satellite_world", "satellite_body", "satellite_fullJ_world", "quadrotor_world", "quadrotor_body"])
+def test_cascade_finite_difference_matches_the_full_evaluation(variant):
+    """FiniteDifference for the rigid bodies integrates, per column, only the cascade blocks the perturbed component can change (csrc/cascade.hpp).
+    It must reproduce forward differences with full evaluations -- the oracle's, src/jacobian_gen.jl:643-685 -- for every explicit rule, both
+    velocity frames, diagonal and full inertia, a terminal knot point (zero control columns) and a ragged last tile; blocks a column cannot
+    reach are exact zeros in both; and it stays within the reference's 1e-6 of the exact Jacobian (test/integration_tests.jl:14)."""
+    rng = np.random.default_rng(77)
+    body = variant.endswith("_body")
+    if variant.startswith("satellite"):
+        Jm = np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]]) if "fullJ" in variant else np.diag([2.0, 3.0, 1.0])
+        model, om, mctl = RD.Satellite(mass=2.0, J=Jm, bodyframe=body), O.satellite(2.0, Jm, O.FRAME_BODY if body else O.FRAME_WORLD), 6
+    else:
+        model, om, mctl = RD.Quadrotor(bodyframe=body), O.quadrotor(O.FRAME_BODY if body else O.FRAME_WORLD), 4
+    N = 64 * 3 + 17
+    Zn = H.rand_rigid(rng, N, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    dt[-1] = 0.0
+    dt[70] = 0.0
+    for rule, orule in ((RD.Euler, O.EULER), (RD.RK2, O.RK2), (RD.RK3, O.RK3), (RD.RK4, O.RK4)):
+        dm = RD.DiscretizedDynamics(model, rule)
+        Z = traj(model, Zn, t, dt, "cuda")
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+        RD.jacobian_(RD.StaticReturn(), RD.FiniteDifference(), dm, J, Y, Z)
+        Jfd, Yo = om.jacobian(orule, O.FINITE_DIFF, Zn, t, dt)
+        Jex, _ = om.jacobian(orule, O.FORWARD_AD, Zn, t, dt)
+        Jg = host(J)
+        np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        # same differences up to the rounding of two evaluation orders (FMA contraction, sincos_, reciprocals) divided by eps = 2^-26 max(1,|x|):
+        # a few ulps of |y| <= 4 (quadrotor: gravity in v) is 3e-7
+        np.testing.assert_allclose(Jg, Jfd, rtol=0, atol=4e-7)
+        np.testing.assert_allclose(Jg, Jex, rtol=0, atol=1e-6)
+        # blocks a column cannot reach are exact zeros, like the full evaluation: w and q rows of the r, v columns; control columns of terminal knots
+        assert np.all(Jg[:, 3:7, 0:3] == 0.0) and np.all(Jg[:, 10:13, 0:3] == 0.0) and np.all(Jg[:, 3:7, 7:10] == 0.0) and np.all(Jg[:, 10:13, 7:10] == 0.0)
+        assert np.all(Jg[-1][:, 13:] == 0.0) and np.all(Jg[70][:, 13:] == 0.0)
+
+
 @pytest.mark.parametrize("shape", [(64, 9), (130, 6), (37, 14), (200, 3), (64, 2), (5, 1), (256, 41)])
 @pytest.mark.parametrize("variant", ["satellite_world_rk4", "satellite_body_rk3", "satellite_fullJ_rk2", "quadrotor_world_rk4", "quadrotor_body_euler",
                                      "satellite_world_rk4_f32"])
