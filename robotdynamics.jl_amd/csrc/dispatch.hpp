@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.hpp"
 #include "cascade.hpp"
 #include "implicit.hpp"
@@ -13,6 +14,11 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_
 
 // which (model, rule) pairs get the compile-time-column ForwardAD kernel (big code, structural sparsity folded)
 template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; static constexpr int NC = 0; using Plan = void; };
+
+// column plan of the implicit-function-theorem tile kernel: the model's ForwardAD plan if it has one (the per-column costs have the same
+// ordering: a column costs what it can reach downstream), contiguous ranges otherwise
+template <class Mdl, class = void> struct IftPlanOf { using Plan = ContiguousPlan<Mdl::NX + Mdl::NU, 4>; };
+template <class Mdl> struct IftPlanOf<Mdl, typename std::enable_if<UnrollPolicy<Mdl, RULE_RK4>::value>::type> { using Plan = typename UnrollPolicy<Mdl, RULE_RK4>::Plan; };
 
 // cost-balanced column plan of the cascade FiniteDifference kernel (defined next to the model's other plans)
 template <class Mdl> struct FdPlanOf { static constexpr bool value = false; using Plan = void; };
@@ -66,6 +72,18 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
     hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    return hip_status(hipGetLastError());
+}
+
+// the same loop for kernels without a separate f(z) output (signature ..., J)
+template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel_j(K kernel, const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (e != hipSuccess) return RDHIP_ERR_HIP;
+    const long long ntiles = (a.N + TILE - 1) / TILE;
+    constexpr int threads = (Plan::NG + NC) * TILE;
+    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J);
     return hip_status(hipGetLastError());
 }
 
@@ -268,6 +286,25 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {
+        // models whose Jacobian tile fits the split-role loop: Newton solve (register kernel), then the IFT Jacobian as whole-line tile stores
+        // (implicit_ift_split_kernel), then the exact LDS kernel for the tiles either of them flagged
+        constexpr int NZ = Mdl::NX + Mdl::NU;
+        using IFn = IftFun<Mdl>;
+        using IPlan = typename IftPlanOf<Mdl>::Plan;
+        if constexpr (!reg_is_exact && NZ > 10 && SplitLds<IFn, T, IPlan, 4>::BYTES <= 160 * 1024) {
+            static const char* ift_mode = getenv("RDHIP_IFT");             // tuning switch: "reg" keeps the one-kernel register path
+            if (a.flag && aligned16(a.J) && !(ift_mode && ift_mode[0] == 'r')) {
+                hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
+                LaunchArgs b = a;
+                b.Y = nullptr;
+                const int rc = launch_split_kernel_j<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, (const T*)a.Y, a.flag, tile_flags}, b);
+                if (rc) return rc;
+                auto kern = implicit_midpoint_kernel<Mdl, T, true>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
+                return hip_status(hipGetLastError());
+            }
+        }
         if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;

@@ -336,7 +336,8 @@ template <class Mdl, class T> struct ImplicitRegOps {
         }
     }
     // one Newton solve from x1 (src/integration.jl:422-463): xn = solution, xl = last tested iterate; true if a row exchange was needed
-    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX]) {
+    // (*unconv = the lane left the loop at the iteration limit, i.e. xn is one update past the last tested iterate xl)
+    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX], bool* unconv = nullptr) {
         const T tm = tj + h * T(0.5);
         T xm[NX], f[NX], r[NX];
 #pragma unroll
@@ -364,6 +365,7 @@ template <class Mdl, class T> struct ImplicitRegOps {
                 for (int i = 0; i < NX; ++i) xn[i] = xl[i] - r[i];
             }
         }
+        if (unconv) *unconv = !done;
         return need;
     }
     // IFT columns with the register factors: J[:, C] = -A2^{-1} J1[:, C]
@@ -441,7 +443,11 @@ __global__ void __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(2))) 
     for (int i = 0; i < NX; ++i) x1[i] = Z[kc * NZ + i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : Z[kc * NZ + NX + i];
-    bool need = R::newton(m, x1, u, tj, h, newton_iters, tol, xn, xl);
+    bool unconv = false;
+    bool need = R::newton(m, x1, u, tj, h, newton_iters, tol, xn, xl, &unconv);
+    // tile_flags bit 1 (set when implicit_ift_split_kernel follows, which linearises about Xn): a lane that stopped at the iteration limit has
+    // xn != its last tested iterate -- where the reference's Jacobian is taken -- so its tile goes to the exact kernel as well
+    if (!WANT_J && (tile_flags & 2)) need = need || unconv;
     if (active) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) Xn[k * NX + i] = xn[i];
@@ -461,9 +467,89 @@ __global__ void __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(2))) 
     // "partial pivoting would have exchanged rows": per 64-knot tile (word 1 + tile, written unconditionally: no memset in front of the
     // launch) or, for batches with more tiles than the context holds words for, the single word 0 (cleared by the host)
     if (flag) {
-        if (tile_flags) { const bool any = __any(need); if (threadIdx.x == 0) flag[1 + blockIdx.x] = any ? 1 : 0; }
+        if (tile_flags & 1) { const bool any = __any(need); if (threadIdx.x == 0) flag[1 + blockIdx.x] = any ? 1 : 0; }
         else if (need) *flag = 1;
     }
+}
+
+// ---- implicit-function-theorem Jacobian as a split-role tile kernel ------------------------------------------------------------------
+// The register kernel above stores a lane's columns in 416-byte pieces of a 1 976-byte slab, five visits per slab spread over the kernel:
+// every visit leaves partially written 128-byte lines behind.  While the output still sits in the Infinity Cache from an earlier call that
+// goes unnoticed (36 us for 65 536 satellite knot points); written to memory that is not cached -- outputs rotated over four 136 MB buffers --
+// the same kernel takes 59 us (L2 -> fabric traffic is 1.11x the algorithmic bytes either way; the partial lines pay at the memory side).
+// So for models whose tile fits, the Jacobian goes through the flagship's loop instead (kernels.hpp jac_split_loop): the Newton solve runs
+// first as implicit_midpoint_reg_kernel<.., false> (x_next to Y), then this kernel -- four compute waves per 64-knot tile, every one
+// factorising (h/2) A - I at the midpoint itself (compile-time sparse, without row exchanges: cheap next to the solves) and solving its own
+// share of the columns; copy waves write the finished tile as whole lines.  State columns use  -A2^{-1} (I + (h/2) A) = -I - 2 A2^{-1}
+// (A2 = (h/2) A - I): the right-hand side is a unit vector, no second Jacobian-vector product.  x_next reaches the lanes as the loop's
+// lane-private auxiliary input, one tile ahead.  A lane whose factorisation would have exchanged rows raises its tile's flag word like the
+// register kernel does and the LDS kernel behind recomputes that tile.
+template <class Mdl> struct IftFun {
+    using T = typename Mdl::T;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, NCOLS = Mdl::NX + Mdl::NU, NVAL = Mdl::NX, NEXT = 0, NAUX = Mdl::NX;
+    Mdl m;
+    const T* xn;         // the Newton solutions (n x N)
+    int* flag;           // word 0, or word 1 + tile with tile_flags
+    int tile_flags;
+    RD_DEV const T* aux_ptr() const { return xn; }
+};
+template <class Fn, class T, class Plan, int G, int C> struct IftCols {
+    using Mdl = decltype(Fn::m);
+    using R = ImplicitRegOps<Mdl, T>;
+    static constexpr int NX = Fn::NX, NU = Fn::NU;
+    static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&xm)[NX], const T (&a)[NX][NX], const int (&piv)[NX]) {
+        if constexpr (C < NX + NU) {
+            if constexpr (Plan::wave_of(C) == G) {
+                T col[NX];
+                if constexpr (C < NX) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = (i == C) ? T(1) : T(0);
+                    R::solve(a, piv, col);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = col[i] * T(-2) - ((i == C) ? T(1) : T(0));
+                } else {
+                    ImplicitOps<Mdl, T>::template jcol<C>(fn.m, xm, fr.u, fr.t, col);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = col[i] * fr.h;
+                    R::solve(a, piv, col);
+                    const T sc = fr.term ? T(0) : T(-1);             // control columns of a terminal knot point are zero
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) col[i] = col[i] * sc;
+                }
+                fr.put_at(C, col);
+                __builtin_amdgcn_sched_barrier(0);                    // one column at a time (register pressure next to the factors)
+            }
+            IftCols<Fn, T, Plan, G, C + 1>::run(fn, fr, xm, a, piv);
+        }
+    }
+};
+template <class Fn, class T, class Plan> struct IftBody {
+    using Mdl = decltype(Fn::m);
+    using R = ImplicitRegOps<Mdl, T>;
+    static constexpr int NX = Fn::NX, NU = Fn::NU;
+    template <int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&xm)[NX], const T (&a)[NX][NX], const int (&piv)[NX]) {
+        if constexpr (G < Plan::NG) {
+            if (fr.g == G) IftCols<Fn, T, Plan, G, 0>::run(fn, fr, xm, a, piv);
+            else waves<G + 1>(fn, fr, xm, a, piv);
+        }
+    }
+    template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
+        T xm[NX], f[NX], a[NX][NX];
+        int piv[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xm[i] = (fr.x[i] + fr.aux[i]) * T(0.5);
+        R::template fill<0>(fn.m, xm, fr.u, fr.t, fr.t + fr.h * T(0.5), fr.h, a, f);
+        const bool need = R::lu(a, piv);
+        if (fr.g == 0 && fn.flag) {                                  // every compute wave factorises the same matrices: one of them reports
+            if (__any(need) && (threadIdx.x & 63) == 0) fn.flag[fn.tile_flags ? 1 + fr.tile : 0] = 1;
+        }
+        waves<0>(fn, fr, xm, a, piv);
+    }
+};
+template <class Fn, class T, class Plan, int NC>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE) implicit_ift_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                                     const double* __restrict__ dtt, T* __restrict__ J) {
+    jac_split_loop<Fn, T, Plan, NC, IftBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, nullptr});
 }
 
 template <class Mdl, class T>

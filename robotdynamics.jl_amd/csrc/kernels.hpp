@@ -208,10 +208,17 @@ template <class Fn, class T, class Plan> struct JacLds {
     static constexpr size_t BYTES = (OUT_ELEMS + Z_ELEMS) * sizeof(T) + 2 * TILE * sizeof(double);
 };
 
+// a function object may ask for NAUX extra lane-private inputs per knot point (read from fn.aux_ptr()[k * NAUX + i] one tile ahead by the
+// split-role loop and handed to the body in fr.aux): the implicit-function-theorem kernel reads the Newton solution this way (implicit.hpp)
+template <class Fn, class = void> struct AuxOf { static constexpr int N = 0; };
+template <class Fn> struct AuxOf<Fn, decltype((void)Fn::NAUX)> { static constexpr int N = Fn::NAUX; };
+
 template <class Fn, class T> struct JacFrame {
-    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NVAL = Fn::NVAL;
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NVAL = Fn::NVAL, NA = AuxOf<Fn>::N;
     const T* zs;     // the staged input tile (bodies with Fn::NEXT read the following knot point from it)
     int kl;          // this lane's knot point inside the tile
+    long long tile;  // global tile index (split-role loop)
+    T aux[NA > 0 ? NA : 1];
     T x[NX], u[NU];
     T t, h;
     bool term;
@@ -477,6 +484,7 @@ template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
     // per batch: N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
+    constexpr int NA = AuxOf<Fn>::N;
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -530,6 +538,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
                 const int idx = threadIdx.x & (TILE - 1);
                 t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
             }
+            if constexpr (NA > 0) {                        // lane-private extra inputs of the first tile (requested behind the tile's own loads)
+                const T* __restrict__ A = fn.aux_ptr();
+                const long long ka = k0 + (lane < nk ? lane : nk - 1);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) fr.aux[i] = A[ka * NA + i];
+            }
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = z0[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
@@ -553,13 +567,25 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
                 const int idx = threadIdx.x & (TILE - 1);
                 tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
             }
+            T apre[NA > 0 ? NA : 1];
+            if constexpr (NA > 0) {
+                const T* __restrict__ A = fn.aux_ptr();
+                const long long ka = more ? k1 + (lane < nk1 ? lane : nk1 - 1) : 0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) apre[i] = A[ka * NA + i];
+            }
             __builtin_amdgcn_sched_barrier(0);
             const int kl = lane < nk ? lane : nk - 1;
             const double hd = ts[TILE + kl];
             fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
             read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
             fr.kl = kl;
+            fr.tile = tile;
             Body::template run<0>(fn, fr);
+            if constexpr (NA > 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) fr.aux[i] = apre[i];
+            }
             __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }

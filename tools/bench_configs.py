@@ -265,11 +265,9 @@ def main():
         call = bare([lambda: RD.evaluate_(dmi, Xi, Zi)])[0]        # bare C calls: the checked Python call costs more than the kernel
         us = timed(lambda i: call(), a.reps)
         emit("satellite ImplicitMidpoint discrete_dynamics (Newton)", 65536, "f64", us, 65536 * (19 * 8 + 16 + 13 * 8))
-        Ji = RD.alloc_jacobians(dmi, 65536, Zi.data)
         ift = RD.ImplicitFunctionTheorem(RD.ForwardAD())
-        call = bare([lambda: RD.jacobian_(RD.StaticReturn(), ift, dmi, Ji, Xi, Zi)])[0]
-        us = timed(lambda i: call(), a.reps)
-        emit("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", 65536, "f64", us, 65536 * 2248)
+        # outputs rotated like every other Jacobian case: with ONE 136 MB output the stores land in the Infinity Cache (tools/ift_probe.py)
+        jac_case("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", sat, Zs, RD.ImplicitMidpoint, ift, f64, a.reps)
         jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
         jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
         return
@@ -333,17 +331,9 @@ def main():
     call = bare([lambda: RD.evaluate_(dmi, Xi, Zi)])[0]            # bare C calls: the checked Python call costs more than the kernel
     us = timed(lambda i: call(), a.reps)
     emit("satellite ImplicitMidpoint discrete_dynamics (Newton)", 65536, "f64", us, 65536 * (19 * 8 + 16 + 13 * 8))
-    Ji = RD.alloc_jacobians(dmi, 65536, Zi.data)
     ift = RD.ImplicitFunctionTheorem(RD.ForwardAD())
-    call = bare([lambda: RD.jacobian_(RD.StaticReturn(), ift, dmi, Ji, Xi, Zi)])[0]
-    us = timed(lambda i: call(), a.reps)
-    emit("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", 65536, "f64", us, 65536 * 2248)
-    dci = RD.DiscretizedDynamics(cart, RD.ImplicitMidpoint)
-    Zc = RD.PackedTrajectory(4, 1, rng.random((1 << 20, 5)), np.zeros(1 << 20), np.full(1 << 20, 0.1)).to(DEV)
-    Jc = RD.alloc_jacobians(dci, 1 << 20, Zc.data); Xc = torch.empty((1 << 20, 4), dtype=torch.float64, device=DEV)
-    call = bare([lambda: RD.jacobian_(RD.StaticReturn(), ift, dci, Jc, Xc, Zc)])[0]
-    us = timed(lambda i: call(), 10, warm=2)
-    emit("cartpole ImplicitMidpoint jacobian (Newton + IFT), 1M knots", 1 << 20, "f64", us, (1 << 20) * 248)
+    jac_case("satellite ImplicitMidpoint jacobian (Newton + implicit function theorem)", sat, Zs, RD.ImplicitMidpoint, ift, f64, a.reps)
+    jac_case("cartpole ImplicitMidpoint jacobian (Newton + IFT), 1M knots", cart, rng.random((1 << 20, 5)), RD.ImplicitMidpoint, ift, f64, 10)
     Zb = rigid_inputs(1 << 20, 6, rng)
     eval_case("large-N satellite RK4 discrete_dynamics", sat, Zb, RD.RK4, f64, 20)
     eval_case("large-N satellite continuous dynamics", sat, Zb, None, f64, 20)
