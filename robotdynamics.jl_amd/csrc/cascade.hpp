@@ -390,6 +390,9 @@ template <class Fn, class T, class Plan, class Cas, int G, int C> struct FdCasca
     static constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NS = rule_stages<Fn::RULE_ID>();
     static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&f0)[NX], const T (&S)[NS][NX]) {
         if constexpr (C < NZ) {
+            if constexpr (FirstSplitOf<Plan>::N > 0 && C == FirstSplitOf<Plan>::N) {
+                if (fr.first) __syncthreads();              // barrier E of the split-role loop: the early part of the first tile is complete
+            }
             if constexpr (Plan::wave_of(C) == G) {
                 constexpr int B = C < NX ? Cas::block_of(C) : Cas::control_block(C - NX);
                 T x1[NX], u1[NU], y1[NX];
@@ -426,6 +429,7 @@ template <class Fn, class T, class Plan, class Cas, int G, int C> struct FdCasca
     }
 };
 template <class Fn, class T, class Plan, class Cas> struct FdCascadeBody {
+    static constexpr bool EARLY = true;
     static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
     template <int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&f0)[NX], const T (&S)[NS][NX]) {
         if constexpr (G < Plan::NG) {

@@ -5,25 +5,30 @@
 #include "dispatch.hpp"
 namespace rd {
 // Satellite columns: r 0-2, q 3-6, v 7-9, w 10-12, uF 13-15, tau 16-18.  Measured fp64 instruction counts per column of the RK4
-// tangent (diagonal J): r 0, v 2, q ~225, w ~343, uF ~57, tau ~257 (+ ~150-200 shared per wave) -> four waves of ~850-950
-// instead of 380/840/1260/1020 for contiguous ranges:  wave 0: r, q3-q5, v   wave 1: w10, w11   wave 2: q6, w12, uF (+ f(z))   wave 3: tau
-using SatPlan = TablePlan<19, 4, 2, /*r*/ 0, 0, 0, /*q*/ 0, 0, 0, 2, /*v*/ 0, 0, 0, /*w*/ 1, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
-// Quadrotor columns: r 0-2, q 3-6, v 7-9, w 10-12, u 13-16 (each rotor thrust feeds both F and tau)
-using QuadPlan = TablePlan<17, 4, 0, /*r*/ 0, 0, 0, /*q*/ 0, 0, 0, 1, /*v*/ 0, 0, 0, /*w*/ 1, 2, 2, /*u*/ 3, 3, 3, 1>;
+// tangent (diagonal J): r 0, v 2, q ~225, w ~343, uF ~57, tau ~257 (+ ~150-200 shared per wave).  Two constraints shape the table: the four
+// waves carry similar totals (~740-830), and every wave carries ONE quaternion column ahead of everything expensive, so that the leading ten
+// columns (r, q, v: 53 % of a row) of a workgroup's first tile are final after a quarter of the arithmetic and their whole 128-byte lines
+// leave while the rest is computed (TablePlanS, kernels.hpp; tuning harness, back-to-back launches at N = 65 536: 28.1 -> 26.4 us).
+//   wave 0: r, q3, w10, uF13   wave 1: q4, v, w11, uF14, uF15 (+ f(z))   wave 2: q5, w12, tau18   wave 3: q6, tau16, tau17
+using SatPlan = TablePlanS<19, 4, 1, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 1, /*tau*/ 3, 3, 2>;
+// Quadrotor columns: r 0-2, q 3-6, v 7-9, w 10-12, u 13-16 (each rotor thrust feeds both F and tau, ~310 per column)
+//   wave 0: q3, w10, u15   wave 1: q4, w11, u16   wave 2: r, q5, v, w12 (+ f(z))   wave 3: q6, u13, u14
+using QuadPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
 // every rule of the rigid bodies gets the compile-time-column (structural zeros folded) split-role kernel
 template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
 template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls
-using SatErrPlan = TablePlan<18, 4, 2, /*r*/ 0, 0, 0, /*phi*/ 0, 0, 0, /*v*/ 0, 0, 0, /*w*/ 1, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
-using QuadErrPlan = TablePlan<16, 4, 0, /*r*/ 0, 0, 0, /*phi*/ 0, 0, 1, /*v*/ 0, 0, 0, /*w*/ 1, 2, 2, /*u*/ 3, 3, 3, 1>;
+// (one attitude column per wave first: the leading nine columns r, phi, v are the early part of a first tile, like SatPlan's ten)
+using SatErrPlan = TablePlanS<18, 4, 0, 9, /*r*/ 3, 3, 3, /*phi*/ 0, 1, 2, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 2, /*tau*/ 3, 3, 3>;
+using QuadErrPlan = TablePlanS<16, 4, 2, 9, /*r*/ 3, 3, 3, /*phi*/ 0, 1, 2, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { using Plan = SatErrPlan; };
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { using Plan = QuadErrPlan; };
 
 // FiniteDifference along the cascade: a column costs the blocks it can change -- r, v, uF: the r,v block (~141 fp64 instructions of an RK4
-// step); q: q + r,v (~231); w, tau and the quadrotor's rotors: everything (~312).  Four waves of ~1030-1190 (compiled counts).
-using SatFdPlan = TablePlan<19, 4, 3, /*r*/ 3, 3, 0, /*q*/ 2, 2, 2, 2, /*v*/ 3, 3, 3, /*w*/ 0, 0, 0, /*uF*/ 3, 3, 3, /*tau*/ 1, 1, 1>;
-using QuadFdPlan = TablePlan<17, 4, 3, /*r*/ 3, 0, 0, /*q*/ 2, 2, 2, 2, /*v*/ 3, 3, 3, /*w*/ 0, 0, 0, /*u*/ 1, 1, 1, 3>;
+// step); q: q + r,v (~231); w, tau and the quadrotor's rotors: everything (~312).  Four waves of ~900-1090, the early part (r, q, v) spread evenly.
+using SatFdPlan = TablePlanS<19, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*uF*/ 2, 2, 3, /*tau*/ 0, 1, 3>;
+using QuadFdPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*u*/ 0, 1, 3, 3>;
 template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>> { static constexpr bool value = true; using Plan = SatFdPlan; };
 template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>> { static constexpr bool value = true; using Plan = QuadFdPlan; };
 

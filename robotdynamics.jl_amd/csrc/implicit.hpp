@@ -375,7 +375,10 @@ template <class Mdl, class T> struct ImplicitRegOps {
     // store instruction writes 16 B per lane over 2-3 such runs (with one column per sweep and 8 B per lane the kernel issued 304 store
     // instructions per tile over 104-B runs, half of its time; now 130).  Rows are only sizeof(T)-aligned: the 16-B stores may be misaligned
     // by 8 B, which gfx950 global memory accepts.  J0 = the wave's first Jacobian, nk = its number of valid knot points.
-    static constexpr int CG = 4;                                      // columns per LDS group
+    // columns per LDS group: 4 (a quarter of a CU's LDS for four waves of a 13-state model) -- or ALL of them when the whole n x (n+m) slab of
+    // 64 knot points is small (cartpole: 10 KB per wave): the wave's Jacobians are then one contiguous piece of memory written as whole lines
+    // (a 4-of-5-column group leaves every 160-byte slab of the cartpole with partially written 128-byte lines, see implicit_ift_split_kernel)
+    static constexpr int CG = (NX * (NX + NU) <= 96) ? (NX + NU) : 4;
     static constexpr int RS = (CG * NX) | 1;                          // lane stride of the group buffer (odd: conflict-free lane-strided writes)
     static constexpr size_t LDS_BYTES = (size_t)TILE * RS * sizeof(T);
     template <int C> static RD_DEV void ift_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, bool term, const T (&a)[NX][NX], const int (&piv)[NX],
@@ -499,6 +502,9 @@ template <class Fn, class T, class Plan, int G, int C> struct IftCols {
     static constexpr int NX = Fn::NX, NU = Fn::NU;
     static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr, const T (&xm)[NX], const T (&a)[NX][NX], const int (&piv)[NX]) {
         if constexpr (C < NX + NU) {
+            if constexpr (FirstSplitOf<Plan>::N > 0 && C == FirstSplitOf<Plan>::N) {
+                if (fr.first) __syncthreads();              // barrier E of the split-role loop: the early part of the first tile is complete
+            }
             if constexpr (Plan::wave_of(C) == G) {
                 T col[NX];
                 if constexpr (C < NX) {
@@ -524,6 +530,7 @@ template <class Fn, class T, class Plan, int G, int C> struct IftCols {
     }
 };
 template <class Fn, class T, class Plan> struct IftBody {
+    static constexpr bool EARLY = true;
     using Mdl = decltype(Fn::m);
     using R = ImplicitRegOps<Mdl, T>;
     static constexpr int NX = Fn::NX, NU = Fn::NU;

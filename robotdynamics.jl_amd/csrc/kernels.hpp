@@ -199,6 +199,19 @@ template <int NZ, int NG_, int VW, int... W> struct TablePlan {
     static constexpr int wave_of(int c) { constexpr int w[NZ] = {W...}; return w[c]; }
     static constexpr int value_chunk = 0, value_wave = VW;
 };
+// TablePlan whose first SPLIT columns form the EARLY PART of a workgroup's first tile (split-role loop, bodies that support it): every compute
+// wave handles its columns in ascending order, so once all waves are past column SPLIT the leading SPLIT*NY values of every row are final and
+// the copy waves start storing them while the remaining columns are still being computed -- the first tile of a launch is the only one whose
+// arithmetic has no store stream to hide under.  The table should give every wave a similar amount of work on either side of SPLIT.
+template <int NZ, int NG_, int VW, int SPLIT, int... W> struct TablePlanS : TablePlan<NZ, NG_, VW, W...> {
+    static_assert(SPLIT > 0 && SPLIT < NZ, "the early part is a proper prefix of the columns");
+    static constexpr int FIRST_SPLIT = SPLIT;
+};
+template <class Plan, class = void> struct FirstSplitOf { static constexpr int N = 0; };
+template <class Plan> struct FirstSplitOf<Plan, decltype((void)Plan::FIRST_SPLIT)> { static constexpr int N = Plan::FIRST_SPLIT; };
+template <class Body, class = void> struct EarlyOf { static constexpr bool value = false; };
+template <class Body> struct EarlyOf<Body, decltype((void)Body::EARLY)> { static constexpr bool value = Body::EARLY; };
+
 template <class Fn, class T, class Plan> struct JacLds {
     static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
     static constexpr int run(int ch) { return (Plan::chunk_end(ch) - Plan::chunk_begin(ch)) * NY + (ch == Plan::value_chunk ? NY : 0); }
@@ -218,6 +231,7 @@ template <class Fn, class T> struct JacFrame {
     const T* zs;     // the staged input tile (bodies with Fn::NEXT read the following knot point from it)
     int kl;          // this lane's knot point inside the tile
     long long tile;  // global tile index (split-role loop)
+    bool first;      // split-role loop: this is the workgroup's first tile (bodies with EARLY pass a workgroup barrier at column Plan::FIRST_SPLIT)
     T aux[NA > 0 ? NA : 1];
     T x[NX], u[NU];
     T t, h;
@@ -280,6 +294,7 @@ RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, co
     fr.row = out + lane * L::RS;
     fr.yrow = nullptr;
     fr.want_y = (Y != nullptr);
+    fr.first = false;                                // (no early part in this loop: every wave computes and copies)
 
     long long tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -356,6 +371,9 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
         constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY;
         constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
         if constexpr (C < C1) {
+            if constexpr (FirstSplitOf<Plan>::N > 0 && C == FirstSplitOf<Plan>::N) {
+                if (fr.first) __syncthreads();              // barrier E of the split-role loop: the early part of the first tile is complete
+            }
             if constexpr (Plan::wave_of(C) == G) {
                 using D = Dual<T, 1>;
                 D xd[NX], ud[NU], yd[NY];
@@ -393,6 +411,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
     }
 };
 template <class Fn, class T, class Plan> struct AdUnrolledBody {
+    static constexpr bool EARLY = true;                     // AdCols passes barrier E at column Plan::FIRST_SPLIT of a first tile
     template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr) {
         if constexpr (G < Plan::NG) {
             if (fr.g == G) AdCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr);
@@ -485,6 +504,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
     // per batch: N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
     constexpr int NA = AuxOf<Fn>::N;
+    // early part of a workgroup's first tile: the leading ES columns (ES * NY values of every row), see TablePlanS
+#if defined(RD_NO_EARLY)
+    constexpr int ES = 0;
+#else
+    constexpr int ES = EarlyOf<Body>::value ? FirstSplitOf<Plan>::N : 0;
+#endif
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -520,6 +545,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
         constexpr int ZPT = (TIN * NZ + NTC - 1) / NTC;
         JacFrame<Fn, T> fr;
         fr.g = wave;
+        fr.first = ES > 0;
         fr.row = jt + lane * OW;
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
@@ -582,6 +608,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
             fr.kl = kl;
             fr.tile = tile;
             Body::template run<0>(fn, fr);
+            fr.first = false;
             if constexpr (NA > 0) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) fr.aux[i] = apre[i];
@@ -600,12 +627,38 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
         __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
         __syncthreads();                                   // barrier 0
+        bool first = ES > 0;
+        // 16-byte unit u of the tile slab lies in a 128-byte line that is covered by the early columns [0, ES) of ONE row
+        auto early_line = [](int u) {
+            constexpr int RB = OW * (int)sizeof(T), EB = ES * Fn::NY * (int)sizeof(T);
+            const int l0 = (u >> 3) << 7, k = l0 / RB;
+            return l0 + 128 <= k * RB + EB;
+        };
         for (; tile < tend; tile += tstep) {
             const TileRef<T> cur = bt.at(tile);
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
             V4 jv[L::JPL], yv[L::YPL];
+            bool skip_early = false;
+            if constexpr (ES > 0) {
+                if (first) {
+                    // first tile: the compute waves pass barrier E at column ES; the 128-byte lines that lie entirely inside the early columns
+                    // of one row leave now, under the arithmetic of the remaining columns (whole lines only: partially written lines are
+                    // what made every chunked store pattern slow), and the sweep behind barrier B skips them
+                    __syncthreads();                       // barrier E
+                    if (nk == TILE) {
+                        V4* jd = reinterpret_cast<V4*>(cur.J + k0 * OW);
+#pragma unroll
+                        for (int r = 0; r < L::JPL; ++r) {
+                            const int u = r * (NC * TILE) + ct;
+                            if (u < L::JU && early_line(u)) RD_TILE_STORE(jd + u, jsrc[u]);
+                        }
+                        skip_early = true;
+                    }
+                    first = false;
+                }
+            }
             __syncthreads();                               // barrier A
 #pragma unroll
             for (int r = 0; r < L::JPL; ++r) { const int u = r * (NC * TILE) + ct; jv[r] = jsrc[u < L::JU ? u : 0]; }
@@ -619,6 +672,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
 #pragma unroll
             for (int r = 0; r < L::JPL; ++r) {
                 const int u = r * (NC * TILE) + ct;
+                if (ES > 0 && skip_early && early_line(u)) continue;
                 if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
                 else if (u * 16 < jbytes) {                // partial last unit of a ragged tile: element-wise
                     const T* pv = reinterpret_cast<const T*>(&jv[r]);
@@ -685,6 +739,9 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
         constexpr int NX = Fn::NX, NU = Fn::NU, NE = Fn::NE;
         constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
         if constexpr (C < C1) {
+            if constexpr (FirstSplitOf<Plan>::N > 0 && C == FirstSplitOf<Plan>::N) {
+                if (fr.first) __syncthreads();              // barrier E of the split-role loop: the early part of the first tile is complete
+            }
             if constexpr (Plan::wave_of(C) == G) {
                 using D = Dual<T, 1>;
                 D xd[NX], ud[NU], yd[NX];
@@ -722,6 +779,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
     }
 };
 template <class Fn, class T, class Plan> struct ErrUnrolledBody {
+    static constexpr bool EARLY = true;
     using Mdl = decltype(Fn::m);
     static constexpr int NR = Mdl::NROT > 0 ? Mdl::NROT : 1;
     template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&qc)[NR][4], const T (&qn)[NR][4]) {
@@ -971,6 +1029,9 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
         constexpr int C0 = Plan::chunk_begin(CH), C1 = Plan::chunk_end(CH);
         using CB = ChainBody<Fn, T, Plan>;
         if constexpr (C < C1) {
+            if constexpr (FirstSplitOf<Plan>::N > 0 && C == FirstSplitOf<Plan>::N) {
+                if (fr.first) __syncthreads();              // barrier E of the split-role loop: the early part of the first tile is complete
+            }
             if constexpr (Plan::wave_of(C) == G) {
                 if constexpr (VALUE_PENDING) {
                     if (fr.want_y) { T y[NY]; fn.eval(fr.x, fr.u, fr.t, fr.h, y); fr.put_value(C1 - C0, y); }
@@ -1021,6 +1082,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
     }
 };
 template <class Fn, class T, class Plan> struct ChainUnrolledBody {
+    static constexpr bool EARLY = true;
     template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&x2)[Fn::NX], const T (&x3)[Fn::NX], const T (&x4)[Fn::NX]) {
         if constexpr (G < Plan::NG) {
             if (fr.g == G) ChainCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr, x2, x3, x4);

@@ -72,6 +72,13 @@ template <class Plan, int SL, int OCC> void launch_wave(const Fn& fn, long long 
 using SatPlanA = TablePlan<19, 4, 2, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3>;
 using SatPlanB = TablePlan<19, 4, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 2>;   // q | w10,w11 | w12,uF,tau18 | tau16,tau17 (+y)
 using SatPlan5 = TablePlan<19, 5, 4, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 2, 2, 3, 4, 4, 4, 3, 4, 4>;   // 5 compute waves
+// first-tile early part (TablePlanS): SPLIT = 10 (r, q, v)
+using SatS0 = TablePlanS<19, 4, 2, 10, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3>;                 // the shipped table, early part = what waves 0 / 2 finish first
+using SatS1 = TablePlanS<19, 4, 0, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*uF*/ 1, 0, 1, /*tau*/ 3, 3, 2>;
+using SatP1 = TablePlan<19, 4, 0, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*uF*/ 1, 0, 1, /*tau*/ 3, 3, 2>;
+using SatS2 = TablePlanS<19, 4, 0, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
+using SatP2 = TablePlan<19, 4, 0, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 2, 2, 2, /*tau*/ 3, 3, 3>;
+using SatS3 = TablePlanS<19, 4, 1, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 1, /*tau*/ 3, 3, 2>;
 struct SatPlanBal8 {
     static constexpr int NGROUPS = 8, NRUNS = 2;
     static constexpr int B[8][2] = {{10, 0}, {11, 7}, {12, 0}, {14, 0}, {17, 0}, {18, 0}, {3, 0}, {5, 0}};
@@ -221,6 +228,18 @@ int main(int argc, char** argv) {
         double md = 0; for (size_t i = 0; i < out.size(); ++i) md = std::max(md, std::fabs(out[i] - ref[i]));
         printf("round %d  %-28s median %7.2f us  min %7.2f us   %6.0f GB/s (median)  frac %.3f   maxdiff_vs_v0 %.2e\n", round, vars[v].name, ms[REPS / 2] * 1e3, ms[0] * 1e3,
                bytes / (ms[REPS / 2] * 1e-3) / 1e9, bytes / (ms[REPS / 2] * 1e-3) / 8e12, md);
+    }
+    // back-to-back launches (what a sustained caller sees; the event-timed single launches above carry the launch latency)
+    for (int round = 0; round < 2; ++round)
+    for (size_t v = 0; v < vars.size(); ++v) {
+        const int B2B = 400;
+        for (int i = 0; i < 50; ++i) vars[v].launch(fn, N, dZ, dt_, ddt, dJ[i % NBUF], dY[i % NBUF], s);
+        CK(hipStreamSynchronize(s));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < B2B; ++i) vars[v].launch(fn, N, dZ, dt_, ddt, dJ[i % NBUF], dY[i % NBUF], s);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float msb; CK(hipEventElapsedTime(&msb, e0, e1));
+        printf("b2b   %d  %-28s %7.2f us per launch   frac %.3f\n", round, vars[v].name, msb * 1e3 / B2B, bytes / (msb * 1e-3 / B2B) / 8e12);
     }
 #ifdef RD_STAMP
     {   // phase time stamps of variant 0 (a split-role kernel with 8 waves: compute wave 0 and copy wave 4 are printed)

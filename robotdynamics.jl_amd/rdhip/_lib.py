@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "librdhip.so")
+LIB_PATH = os.environ.get("RDHIP_LIB") or os.path.join(_PKG, "lib", "librdhip.so")      # RDHIP_LIB: A/B builds of the library (tuning)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "rdhip.h")
 
 # rdhip_status

@@ -1138,6 +1138,31 @@ def test_implicit_midpoint_register_pass_falls_back_when_rows_must_be_exchanged(
     RD.setnewtoniters(dm, 10)
 
 
+def test_implicit_midpoint_jacobian_at_the_last_tested_iterate_when_the_iteration_limit_stops_the_solve():
+    """The reference takes the IFT Jacobian where its Newton loop last evaluated the residual (src/integration.jl:422-463, :517-538); when the
+    iteration limit ends the loop, x_next is one update past that point.  The tile kernel (implicit_ift_split_kernel) linearises about x_next,
+    so knots that stopped at the limit must be routed to the exact kernel: with 2 iterations and tol 1e-12 no ordinary knot converges, a
+    terminal knot (h = 0, residual 0 at the first test) does, and both kinds sit in the same tiles."""
+    rng = np.random.default_rng(52)
+    for model, om, mctl in ((RD.Satellite(2.0, np.diag([2.0, 3.0, 1.0])), O.body(), 6), (RD.Quadrotor(), O.quadrotor(), 4)):
+        dm = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+        N = 64 * 5 + 9
+        Zn = H.rand_rigid(rng, N, mctl, 0.6 if mctl == 4 else 0.0, 1.9 if mctl == 4 else 1.0)
+        t = np.arange(N) * 0.1; dt = np.full(N, 0.1); dt[::5] = 0.0
+        try:
+            for iters in (2, 10):
+                RD.setnewtoniters(dm, iters)
+                Xo, Jo, its = om.implicit_midpoint(Zn, t, dt, newton_iters=iters)
+                Z = traj(model, Zn, t, dt, "cuda")
+                J = RD.alloc_jacobians(dm, N, Z.data)
+                Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+                RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dm, J, Y, Z)
+                np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
+                np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+        finally:
+            RD.setnewtoniters(dm, 10)
+
+
 def test_rollout_matches_oracle_and_is_idempotent():
     rng = np.random.default_rng(9)
     M, K = 37, 21
