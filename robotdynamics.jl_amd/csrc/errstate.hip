@@ -8,6 +8,7 @@
 // store instruction writes 64 consecutive elements; the quaternion is re-read through L1/L2 (104 B per knot).
 #include "common.hpp"
 #include <cstdint>
+#include <cstdlib>
 
 namespace rd {
 
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) errstate_tile_kernel(LieDesc d, long long
     const int per = rows * d.e;
     const long long k0 = (long long)blockIdx.x * TK;
     const int nk = (int)((N - k0) < TK ? (N - k0) : TK);
-    const int total = nk * per;                              // elements of this tile (TK*per is a multiple of VN: TK = 64)
+    const int total = nk * per;                              // elements of this tile (TK*per is a multiple of VN: TK = 32 or 64)
     // the lane's quaternions (and nablaG's xbar parts) are requested first: their latency hides under the zero fill
     T qv[4][4], bv[4][4];
     const bool owner = threadIdx.x < nk;
@@ -280,7 +281,8 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
     if (d.nrot == 0) {   // EuclideanState: G = I (always cleared, src/statevectortype.jl:149-155)
         hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d.n, d.e, N, (T*)G, 1);
     } else if (clear) {
-        constexpr int TK = 64;
+        // 32 knot points per tile (40 KB for a rigid body: four workgroups per CU; 64-knot tiles, two per CU, ran 3 % slower; 16-knot tiles 1.5 %)
+        constexpr int TK = 32;
         const size_t lds = (size_t)TK * d.n * d.e * sizeof(T);
         if (lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
             auto kern = errstate_tile_kernel<T, 0, TK>;

@@ -42,12 +42,13 @@ struct JitModel {
     std::string err;
     std::vector<int> plan_wave;                           // column -> compute wave (after jit_balance); empty: contiguous ranges
     int plan_value_wave = 0;
+    int plan_split = 0;                                   // > 0: the leading plan_split columns are the early part of a first tile (TablePlanS)
     std::vector<int> rot_starts;                         // LieState{QuatRotation,P}: state index of every quaternion (empty: EuclideanState or MRP / RP)
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
        JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12,
-       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
 
 static std::string rot_start_expr(const JitModel& M) {
     std::ostringstream e;
@@ -69,6 +70,17 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const char* T = dtype == RDHIP_F64 ? "double" : "float";
     const int nz = M.n + M.m;
     std::ostringstream fn, s;
+    if (op == JOP_IMPLICIT_IFT) {            // IFT Jacobian through the split-role tile loop (implicit.hpp implicit_ift_split_kernel)
+        s << "rd::implicit_ift_split_kernel<rd::IftFun<rd::UserModel<" << T << "> >, " << T << ", ";
+        if (!M.plan_wave.empty()) {
+            if (M.plan_split > 0) s << "rd::TablePlanS<" << nz << ", 4, " << M.plan_value_wave << ", " << M.plan_split;
+            else s << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
+            for (int c = 0; c < nz; ++c) s << ", " << M.plan_wave[c];
+            s << ">";
+        } else s << "rd::ContiguousPlan<" << nz << ", 4>";
+        s << ", 4>";
+        return s.str();
+    }
     if (op >= JOP_IMPLICIT_X_REG) {          // Newton matrix in registers (implicit.hpp)
         s << "rd::" << (op == JOP_IMPLICIT_ROLLOUT_REG ? "implicit_rollout_reg_kernel" : "implicit_midpoint_reg_kernel") << "<rd::UserModel<" << T << ">, " << T;
         if (op == JOP_IMPLICIT_X_REG) s << ", false"; else if (op == JOP_IMPLICIT_J_REG) s << ", true";
@@ -102,7 +114,8 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const int ng = nz >= 4 ? 4 : nz;
     std::ostringstream plan;
     if (!M.plan_wave.empty() && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN) && nz > 10) {     // cost-balanced column -> wave table
-        plan << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
+        if (M.plan_split > 0) plan << "rd::TablePlanS<" << nz << ", 4, " << M.plan_value_wave << ", " << M.plan_split;
+        else plan << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
         for (int c = 0; c < nz; ++c) plan << ", " << M.plan_wave[c];
         plan << ">";
     } else plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
@@ -216,10 +229,10 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         if (hipModuleGetFunction(&jk.fn, jk.mod, M.lowered[key].c_str()) != hipSuccess) { M.err = "hipModuleGetFunction failed for " + M.lowered[key]; return RDHIP_ERR_HIP; }
         const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = M.n + M.m, ny = M.n;
         jk.small = (op == JOP_JAC_AD && nz <= 10);
-        const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD);
+        const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD || op == JOP_IMPLICIT_IFT);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || op >= JOP_IMPLICIT_X_REG) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op != JOP_IMPLICIT_IFT)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
@@ -270,9 +283,21 @@ int jit_balance(void* h) {
     size_t base = cost[0]; for (size_t v : cost) base = v < base ? v : base;        // fixed code-object overhead ~ the cheapest column
     std::vector<int> order(nz); for (int c = 0; c < nz; ++c) order[c] = c;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    // early part of a workgroup's first tile (TablePlanS, kernels.hpp): the prefix of columns that holds the most bytes for the least arithmetic
+    // -- at least a quarter of a row, and only if it is worth a barrier (a satellite: r, q, v = 53 % of the bytes for 32 % of the work)
+    size_t total = 0; for (int c = 0; c < nz; ++c) total += cost[c] - base + 64;
+    int split = 0; double best = 0.10;
+    { size_t acc = 0; for (int sp = 1; sp < nz; ++sp) { acc += cost[sp - 1] - base + 64; const double gain = (double)sp / nz - (double)acc / (double)total; if (4 * sp >= nz && gain > best) { best = gain; split = sp; } } }
+    M.plan_split = split;
     size_t load[4] = {0, 0, 0, 0};
     M.plan_wave.assign(nz, 0);
-    for (int c : order) { int w = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[w]) w = i; M.plan_wave[c] = w; load[w] += cost[c] - base + 64; }
+    // longest-processing-time-first, the early columns first (so that the four waves reach the split together), the others on top of those loads
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c : order) {
+            if ((c < split) != (pass == 0)) continue;
+            int w = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[w]) w = i;
+            M.plan_wave[c] = w; load[w] += cost[c] - base + 64;
+        }
     int vw = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[vw]) vw = i;
     M.plan_value_wave = vw;
     // kernels compiled with the old plan are stale
@@ -386,6 +411,33 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     const int* gate = nullptr;
     const unsigned gr = (unsigned)((N + 63) / 64);
     int tile_flags = (mode != 3 && (long long)gr <= IMPLICIT_FLAG_WORDS) ? 1 : 0;      // one word per 64-knot tile, written unconditionally
+    // mode 1, models whose Jacobian tile fits the split-role loop: Newton solve (register kernel) -> IFT Jacobian as whole-line tile stores ->
+    // the exact LDS kernel for flagged tiles (dispatch.hpp launch_implicit does the same for the compiled-in models)
+    {
+        const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = M.n + M.m;
+        auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
+        const size_t lds_ift = a16((size_t)64 * M.n * nz * ts) + a16((size_t)64 * M.n * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8;
+        if (mode == 1 && a.flag && M.n > 6 && M.n <= 14 && nz > 10 && lds_ift <= 160 * 1024 && (reinterpret_cast<uintptr_t>(a.J) & 15) == 0) {
+            JitKernel *kr, *ki;
+            rc = jit_get(M, JOP_IMPLICIT_X_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
+            rc = jit_get(M, JOP_IMPLICIT_IFT, RDHIP_IMPLICIT_MIDPOINT, dtype, &ki); if (rc) return rc;
+            int* flag = a.flag;
+            if (!tile_flags && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
+            int tf2 = tile_flags | 2;
+            { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&nul, &iters, &tol, &flag, &tf2}; rc = launch(M, kr, gr, a.stream, ar); if (rc) return rc; }
+            // IftFun<UserModel<T>> = { UserModel m; const T* xn; int* flag; int tile_flags; } with the natural alignment of its members
+            std::vector<unsigned char> ifn(fn);
+            ifn.resize((ifn.size() + 7) / 8 * 8);
+            const size_t off = ifn.size();
+            ifn.resize(off + 24, 0);
+            const void* xn = Y;
+            std::memcpy(ifn.data() + off, &xn, 8); std::memcpy(ifn.data() + off + 8, &flag, 8); std::memcpy(ifn.data() + off + 16, &tile_flags, 4);
+            { void* ar[] = {ifn.data(), &N, &Z, &t, &dt, &J}; rc = launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar); if (rc) return rc; }
+            const int* gate2 = flag;
+            void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&J, &iters, &tol, &gate2, &tile_flags};
+            return launch(M, k, tile_grid(k->lds, 64, nblk), a.stream, args);
+        }
+    }
     if (a.flag && M.n <= 14) {
         JitKernel* kr; rc = jit_get(M, mode == 0 ? JOP_IMPLICIT_X_REG : mode == 1 ? JOP_IMPLICIT_J_REG : JOP_IMPLICIT_ROLLOUT_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
         int* flag = a.flag;

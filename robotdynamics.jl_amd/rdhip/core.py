@@ -640,7 +640,8 @@ class CustomModel(ContinuousDynamics):
     of the compiled-in models works: dynamics, discrete_dynamics, jacobian! with ForwardAD / FiniteDifference / UserDefined,
     rollout!, dynamics_error, and -- with `liestate=(R, P)` as in LieState{R,P} -- the error-state operators."""
     _kind = L.MODEL_CUSTOM
-    _OPS = {"evaluate": 0, "rollout": 1, "ForwardAD": 2, "FiniteDifference": 3, "UserDefined": 4, "error_expansion": 12}
+    _OPS = {"evaluate": 0, "rollout": 1, "ForwardAD": 2, "FiniteDifference": 3, "UserDefined": 4, "error_expansion": 12,
+            "implicit_solve": 13, "implicit_jacobian": 16}
 
     def __init__(self, n, m, dynamics, params=(), preamble="", liestate=None):
         self.n, self.m = int(n), int(m)

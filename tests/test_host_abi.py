@@ -256,6 +256,7 @@ def test_custom_model_jit_compiles_without_a_gpu():
     tvs = RD.CustomModel(13, 6, H.TV_SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0, 0.7, 0.4, 2.5), liestate=(RD.QuatRotation, (3, 6)))
     tvs.precompile("ForwardAD", RD.RK4)
     tvs.precompile("error_expansion", RD.RK4)
+    tvs.precompile("implicit_jacobian", RD.ImplicitMidpoint)                     # the IFT Jacobian as a split-role tile kernel (n + m > 10)
     RD.CustomModel(2, 1, "const T t = p[0]; xdot[0] = x[1] * t; xdot[1] = u[0];", params=(2.0,)).precompile("evaluate", RD.RK4)
     with pytest.raises(NotImplementedError):                                      # LieDesc tables hold 4 rotations
         RD.dims(RD.CustomModel(16, 1, "xdot[0] = u[0];", liestate=(RD.MRP, (0, 0, 0, 0, 0, 1))))
