@@ -252,6 +252,52 @@ template <class S> static void dyn_rigidbody(const OModel& M, const S* x, const 
     for (int i = 0; i < 3; ++i) { xd[i] = rd[i]; xd[7 + i] = vd[i]; xd[10 + i] = wd[i]; }
     for (int i = 0; i < 4; ++i) xd[3 + i] = qd[i];
 }
+// RigidBody{MRP} / RigidBody{RodriguesParam}: the same Newton-Euler equations (src/rigidbody.jl:213-236) on x = [r(3) p(3) v(3) w(3)]
+// (gen_inds src/rigidbody.jl:80-94).  Rotations.jl [3P, SURVEY App. A]: a three-parameter rotation acts on a vector through its unit
+// quaternion -- MRP: q = [1 - p.p, 2p] / (1 + p.p); RodriguesParam: q = [1, g] / sqrt(1 + g.g) -- and its kinematics are
+// pdot = 1/4 A(p) w with A = (1 - p.p) I + 2 (skew(p) + p p'), gdot = 1/2 (I + skew(g) + g g') w; A and I + skew + gg' are also
+// grad-differential of the two types (oracle_errstate_jacobian).  Written with the explicit 3 x 3 matrices.
+template <class S> static void rot3_quat(int rot, const S p[3], S q[4]) {
+    S n = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    if (rot == ROT_MRP) { S d = 1.0 + n; q[0] = (1.0 - n) / d; for (int i = 0; i < 3; ++i) q[1 + i] = 2.0 * p[i] / d; }
+    else { S d = sqrt_(1.0 + n); q[0] = S(1.0) / d; for (int i = 0; i < 3; ++i) q[1 + i] = p[i] / d; }
+}
+template <class S> static void rot3_gradient(int rot, const S p[3], S A[3][3]) {    // grad-differential(p)
+    S n = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    S sk[3][3] = {{S(0.0), -p[2], p[1]}, {p[2], S(0.0), -p[0]}, {-p[1], p[0], S(0.0)}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        if (rot == ROT_MRP) A[i][j] = ((i == j) ? 1.0 - n : S(0.0)) + 2.0 * (sk[i][j] + p[i] * p[j]);
+        else A[i][j] = ((i == j) ? S(1.0) : S(0.0)) + sk[i][j] + p[i] * p[j];
+    }
+}
+template <class S> static void dyn_rigidbody3(const OModel& M, const S* x, const S* u, S* xd) {
+    double mass = M.p[0]; const double* J = M.p + 1; double Jinv[9]; inv3(J, Jinv);
+    const S* p = x + 3; const S* v = x + 6; const S* w = x + 9;
+    S q[4]; rot3_quat(M.rot, p, q);
+    S F[3], T[3];
+    if (M.kind == M_SATELLITE) { S f[3] = {u[0], u[1], u[2]}; qrot(q, f, F); T[0] = u[3]; T[1] = u[4]; T[2] = u[5]; }
+    else {
+        const double* g = M.p + 10; double L = M.p[13], kf = M.p[14], km = M.p[15];
+        S F1 = max0_(kf * u[0]), F2 = max0_(kf * u[1]), F3 = max0_(kf * u[2]), F4 = max0_(kf * u[3]);
+        S Fb[3] = {S(0.0), S(0.0), F1 + F2 + F3 + F4}; S qF[3]; qrot(q, Fb, qF);
+        for (int i = 0; i < 3; ++i) F[i] = mass * g[i] + qF[i];
+        T[0] = L * (F2 - F4); T[1] = L * (F3 - F1); T[2] = km * u[0] - km * u[1] + km * u[2] - km * u[3];
+    }
+    S A[3][3]; rot3_gradient(M.rot, p, A);
+    const double kfac = M.rot == ROT_MRP ? 0.25 : 0.5;
+    for (int i = 0; i < 3; ++i) xd[3 + i] = kfac * (A[i][0] * w[0] + A[i][1] * w[1] + A[i][2] * w[2]);
+    if (M.frame == FRAME_WORLD) {
+        for (int i = 0; i < 3; ++i) { xd[i] = v[i]; xd[6 + i] = F[i] / mass; }
+    } else {
+        S rd[3]; qrot(q, v, rd);
+        S Fm[3] = {F[0] / mass, F[1] / mass, F[2] / mass}; S a[3]; qrot_inv(q, Fm, a);
+        S c[3]; cross3(w, v, c);
+        for (int i = 0; i < 3; ++i) { xd[i] = rd[i]; xd[6 + i] = a[i] - c[i]; }
+    }
+    S Jw[3]; matvec3(J, w, Jw); S c[3]; cross3(w, Jw, c);
+    S tt[3] = {T[0] - c[0], T[1] - c[1], T[2] - c[2]}; S wd[3]; matvec3(Jinv, tt, wd);
+    for (int i = 0; i < 3; ++i) xd[9 + i] = wd[i];
+}
 // SatellitePair LieState(R,(0,3,3)): examples/satellite_pair.jl:14-38; params (J1[9], J2[9])
 template <class S> static void dyn_satpair(const OModel& M, const S* x, const S* u, S* xd) {
     for (int b = 0; b < 2; ++b) {
@@ -281,7 +327,9 @@ template <class S> static void dynamics(const OModel& M, const S* x, const S* u,
         case M_CARTPOLE: dyn_cartpole(M, x, u, xd); break;
         case M_DOUBLE_INTEGRATOR: dyn_di(M, x, u, xd); break;
         case M_LINEAR: dyn_linear(M, x, u, xd); break;
-        case M_SATELLITE: case M_QUADROTOR: case M_TV_SATELLITE: dyn_rigidbody(M, x, u, t, xd); break;
+        case M_SATELLITE: case M_QUADROTOR: case M_TV_SATELLITE:
+            if (M.rot != ROT_QUAT && M.kind != M_TV_SATELLITE) dyn_rigidbody3(M, x, u, xd); else dyn_rigidbody(M, x, u, t, xd);
+            break;
         case M_TV_PENDULUM: dyn_tv_pendulum(M, x, u, t, xd); break;
         case M_SATELLITE_PAIR: dyn_satpair(M, x, u, xd); break;
         case M_LIE_SATELLITE: dyn_liesat(M, x, u, xd); break;
@@ -390,6 +438,7 @@ static int user_jacobian(const OModel& M, const double* x, const double* u, doub
         const double* A = M.p + 2; const double* B = A + n * n;
         for (int i = 0; i < n * n; ++i) J[i] = A[i]; for (int i = 0; i < n * m; ++i) J[n * n + i] = B[i]; return 0;
     }
+    if ((M.kind == M_SATELLITE || M.kind == M_QUADROTOR) && M.rot != ROT_QUAT) return -1;   // jacobian!(::RigidBody{<:QuatRotation}, ...) only (src/rigidbody.jl:260)
     if (M.kind == M_SATELLITE || M.kind == M_QUADROTOR || M.kind == M_TV_SATELLITE) {      // (the test model's disturbance is additive: same Jacobian)
         // src/rigidbody.jl:260-313 (formulas; the reference method itself references an undefined `z`
         // at :278 and cannot run -- the formulas below are its intended content with the wrench
@@ -617,14 +666,14 @@ int oracle_gen_inds(const OModel* M, int* first, int* len) {
 
 // Z: (n+m) x N column-major; t, dt: N
 int oracle_dynamics(const OModel* M, int N, const double* Z, const double* t, const double* dt, double* Xdot) {
-    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE && M->kind != M_SATELLITE && M->kind != M_QUADROTOR) return -2;   // three-parameter attitudes: the RigidBody satellite / quadrotor only
     int nz = M->n + M->m;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < N; ++k) evaluate(*M, -1, 0, Z + (size_t)k * nz, t[k], dt[k], Xdot + (size_t)k * M->n);
     return 0;
 }
 int oracle_discrete_dynamics(const OModel* M, int rule, int sig, int N, const double* Z, const double* t, const double* dt, double* Xn) {
-    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE && M->kind != M_SATELLITE && M->kind != M_QUADROTOR) return -2;   // three-parameter attitudes: the RigidBody satellite / quadrotor only
     int nz = M->n + M->m;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < N; ++k) evaluate(*M, rule, sig, Z + (size_t)k * nz, t[k], dt[k], Xn + (size_t)k * M->n);
@@ -632,7 +681,7 @@ int oracle_discrete_dynamics(const OModel* M, int rule, int sig, int N, const do
 }
 // rule < 0: continuous jacobian!(sig,diff,model,J,y,z); else DiscretizedDynamics{rule}
 int oracle_jacobian(const OModel* M, int rule, int diff, int sig, int N, const double* Z, const double* t, const double* dt, double* J, double* Y) {
-    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE && M->kind != M_SATELLITE && M->kind != M_QUADROTOR) return -2;   // three-parameter attitudes: the RigidBody satellite / quadrotor only
     int n = M->n, nz = M->n + M->m; int rc_all = 0; jac_ad_fn* tab = jac_table();
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < N; ++k) {
@@ -649,7 +698,6 @@ int oracle_jacobian(const OModel* M, int rule, int diff, int sig, int N, const d
 // X: ldx x N (state in rows 0..n-1), G: n x e x N column-major
 int oracle_errstate_jacobian(const OModel* M, int N, const double* X, int ldx, int clear, double* G) {
     OLie s; int lie = model_lie(*M, &s); int n = M->n; int e = lie ? lie_errdim(s) : n;
-    if (lie && s.rot != ROT_QUAT) return -2;
     for (int k = 0; k < N; ++k) {
         const double* x = X + (size_t)k * ldx; double* Gk = G + (size_t)k * n * e;
         if (!lie) { for (int i = 0; i < n * e; ++i) Gk[i] = 0; for (int i = 0; i < n; ++i) Gk[i + i * n] = 1.0; continue; }
@@ -657,7 +705,11 @@ int oracle_errstate_jacobian(const OModel* M, int N, const double* X, int ldx, i
         int r = 0, c = 0;
         for (int v = 0; v < s.nP; ++v) {
             for (int j = 0; j < s.P[v]; ++j) { Gk[r + c * n] = 1.0; ++r; ++c; }
-            if (v < s.nP - 1) {
+            if (v < s.nP - 1 && s.rot != ROT_QUAT) {                              // grad-differential(p), 3 x 3
+                double A[3][3]; rot3_gradient(s.rot, x + r, A);
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Gk[(r + i) + (c + j) * n] = A[i][j];
+                r += 3; c += 3;
+            } else if (v < s.nP - 1) {
                 double q[4]; qnormalize(x + r, q); double L[4][4]; lmult(q, L);   // grad-differential(q) = L(q) H
                 for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) Gk[(r + i) + (c + j) * n] = L[i][j + 1];
                 r += 4; c += 3;
@@ -669,7 +721,6 @@ int oracle_errstate_jacobian(const OModel* M, int N, const double* X, int ldx, i
 // state_diff(model, x, x0): Euclidean x - x0; rotations: rotation_error(q, q0, CayleyMap) = vec(q0^-1 q)/scalar
 int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const double* X0, int ldx0, double* dX) {
     OLie s; int lie = model_lie(*M, &s); int n = M->n; int e = lie ? lie_errdim(s) : n;
-    if (lie && s.rot != ROT_QUAT) return -2;
     for (int k = 0; k < N; ++k) {
         const double* x = X + (size_t)k * ldx; const double* x0 = X0 + (size_t)k * ldx0; double* d = dX + (size_t)k * e;
         if (!lie) { for (int i = 0; i < n; ++i) d[i] = x[i] - x0[i]; continue; }
@@ -677,10 +728,12 @@ int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const do
         for (int v = 0; v < s.nP; ++v) {
             for (int j = 0; j < s.P[v]; ++j) { d[c] = x[r] - x0[r]; ++r; ++c; }
             if (v < s.nP - 1) {
-                double q[4], q0[4]; qnormalize(x + r, q); qnormalize(x0 + r, q0);
+                double q[4], q0[4];
+                if (s.rot == ROT_QUAT) { qnormalize(x + r, q); qnormalize(x0 + r, q0); }
+                else { rot3_quat(s.rot, x + r, q); rot3_quat(s.rot, x0 + r, q0); }      // inv(CayleyMap)(R0 \ R) goes through the quaternion of R0 \ R
                 double q0c[4] = {q0[0], -q0[1], -q0[2], -q0[3]}; double dq[4]; qmul(q0c, q, dq);
                 for (int j = 0; j < 3; ++j) d[c + j] = dq[1 + j] / dq[0];
-                r += 4; c += 3;
+                r += rot_params(s.rot); c += 3;
             }
         }
     }
@@ -762,7 +815,7 @@ static void implicit_midpoint_parts(const OModel& M, const double* x1, const dou
 // Xn: n x N ; J: n x nz x N or NULL ; iters_used: N or NULL
 int oracle_implicit_midpoint(const OModel* M, int N, const double* Z, const double* t, const double* dt, int newton_iters, double tol,
                              double* Xn, double* J, int* iters_used) {
-    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE && M->kind != M_SATELLITE && M->kind != M_QUADROTOR) return -2;   // three-parameter attitudes: the RigidBody satellite / quadrotor only
     const int n = M->n, nz = M->n + M->m;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < N; ++k) {
@@ -796,7 +849,7 @@ int oracle_implicit_midpoint(const OModel* M, int N, const double* Z, const doub
 }
 // dynamics_error / dynamics_error_jacobian! of ImplicitMidpoint for the N-1 consecutive pairs: E n x (N-1), J2, J1: n x nz x (N-1) (any may be NULL)
 int oracle_implicit_midpoint_error(const OModel* M, int N, const double* Z, const double* t, const double* dt, double* E, double* J2, double* J1) {
-    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE) return -2;
+    if (M->rot != ROT_QUAT && M->kind >= M_SATELLITE && M->kind != M_SATELLITE && M->kind != M_QUADROTOR) return -2;   // three-parameter attitudes: the RigidBody satellite / quadrotor only
     const int n = M->n, nz = M->n + M->m;
     for (int k = 0; k + 1 < N; ++k) {
         const double* z1 = Z + (size_t)k * nz; const double* z2 = Z + (size_t)(k + 1) * nz;

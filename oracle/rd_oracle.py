@@ -289,17 +289,17 @@ def linear(A, B):
     return Model(LINEAR, np.concatenate([[n, m], A.flatten(order="F"), B.flatten(order="F")]))
 
 
-def satellite(mass=1.0, J=np.eye(3), frame=FRAME_WORLD):   # examples/single_satellite.jl:33-35
-    return Model(SATELLITE, np.concatenate([[mass], np.asarray(J, float).flatten(order="F")]), frame=frame)
+def satellite(mass=1.0, J=np.eye(3), frame=FRAME_WORLD, rot=ROT_QUAT):   # examples/single_satellite.jl:33-35 ; rot: RigidBody{R}, test/rigidbody_test.jl:79-98
+    return Model(SATELLITE, np.concatenate([[mass], np.asarray(J, float).flatten(order="F")]), frame=frame, rot=rot)
 
 
 def body(frame=FRAME_WORLD):   # test/rigidbody_test.jl:53-54  (mass 2, J = diag(2,3,1))
     return satellite(2.0, np.diag([2.0, 3.0, 1.0]), frame)
 
 
-def quadrotor(frame=FRAME_WORLD):   # test/quadrotor.jl:36-46
+def quadrotor(frame=FRAME_WORLD, rot=ROT_QUAT):   # test/quadrotor.jl:36-46
     J = np.diag([0.0023, 0.0023, 0.004])
-    return Model(QUADROTOR, np.concatenate([[0.5], J.flatten(order="F"), [0, 0, -9.81], [0.1750, 1.0, 0.0245]]), frame=frame)
+    return Model(QUADROTOR, np.concatenate([[0.5], J.flatten(order="F"), [0, 0, -9.81], [0.1750, 1.0, 0.0245]]), frame=frame, rot=rot)
 
 
 def satellite_pair(J1=np.eye(3), J2=2 * np.eye(3)):   # examples/satellite_pair.jl:42-44

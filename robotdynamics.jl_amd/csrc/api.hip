@@ -64,8 +64,9 @@ static void build_lie(rdhip_model* M) {
         for (int j = 0; j < d.lie_P[v]; ++j) { L.row_kind[r] = 0; L.row_col[r] = (signed char)c; L.err_src[c] = (signed char)r; ++r; ++c; }
         if (v < d.lie_nP - 1) {
             L.rot_row0[v] = (signed char)r; L.rot_col0[v] = (signed char)c;
-            // G tables (errstate_jacobian!, nabla): quaternion blocks only; MRP / RodriguesParam models are served by state_diff alone
-            if (rp == 4) for (int i = 0; i < 4; ++i) { L.row_kind[r + i] = 1; L.row_col[r + i] = (signed char)c; L.row_sub[r + i] = (signed char)i; L.row_q0[r + i] = (signed char)r; }
+            // G tables (errstate_jacobian!, nabla)
+            // (MRP / RodriguesParam rows -- kind 2 -- are read by errstate3_kernel only)
+            for (int i = 0; i < rp; ++i) { L.row_kind[r + i] = rp == 4 ? 1 : 2; L.row_col[r + i] = (signed char)c; L.row_sub[r + i] = (signed char)i; L.row_q0[r + i] = (signed char)r; }
             for (int j = 0; j < 3; ++j) L.err_src[c + j] = (signed char)(-1 - v);
             r += rp; c += 3;
         }
@@ -352,10 +353,15 @@ static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long
     if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
     return RDHIP_OK;
 }
-static int check_rotation(rdhip_ctx* c, const rdhip_model* M) {
-    if (M->d.lie_nP > 0 && M->d.rot != RDHIP_ROT_QUAT)
-        return fail(c, RDHIP_ERR_UNSUPPORTED, "only QuatRotation models have kernels (MRP / RodriguesParam: index queries only)");
-    return RDHIP_OK;
+// what a MRP / RodriguesParam model can do: op 0 = dynamics-type calls (the RigidBody{MRP|RodriguesParam} satellites and quadrotors, models.hpp
+// RigidBody3), op 1 = errstate_jacobian! (any LieState{MRP|RodriguesParam,P}: the 3 x 3 blocks of errstate.hip), op 2 = everything whose
+// Rotations.jl formula could not be pinned (nabla-errstate_jacobian!, the fused error-state expansion)
+static int check_rotation(rdhip_ctx* c, const rdhip_model* M, int op = 2) {
+    if (M->d.lie_nP == 0 || M->d.rot == RDHIP_ROT_QUAT) return RDHIP_OK;
+    if (op == 1) return RDHIP_OK;
+    if (op == 0 && (M->d.kind == RDHIP_MODEL_SATELLITE || M->d.kind == RDHIP_MODEL_QUADROTOR || M->d.kind == RDHIP_MODEL_CUSTOM)) return RDHIP_OK;   // (a custom model's dynamics are the user's source)
+    return fail(c, RDHIP_ERR_UNSUPPORTED, op == 0 ? "MRP / RodriguesParam dynamics exist for the RigidBody satellite and quadrotor only"
+                                                   : "QuatRotation models only (the MRP / RodriguesParam form of this operator is not pinned by the reference's tests)");
 }
 static thread_local const ModelDesc* g_jit_model = nullptr;     // set by family_* for custom models so that kernel_status can report the JIT error
 static int kernel_status(rdhip_ctx* c, int rc, const char* what) {
@@ -373,8 +379,8 @@ static int family_eval(const ModelDesc& d, int rule, int dtype, const LaunchArgs
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_eval(d, rule, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_eval(d, rule, dtype, a);
-        case RDHIP_MODEL_SATELLITE: return fam_satellite_eval(d, rule, dtype, a);
-        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_eval(d, rule, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_eval(d, rule, dtype, a) : fam_satellite_eval(d, rule, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_eval(d, rule, dtype, a) : fam_quadrotor_eval(d, rule, dtype, a);
         default: return fam_lie_eval(d, rule, dtype, a);
     }
 }
@@ -384,8 +390,8 @@ static int family_jacobian(const ModelDesc& d, int rule, int diff, int dtype, co
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_jacobian(d, rule, diff, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_jacobian(d, rule, diff, dtype, a);
-        case RDHIP_MODEL_SATELLITE: return fam_satellite_jacobian(d, rule, diff, dtype, a);
-        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_jacobian(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_jacobian(d, rule, diff, dtype, a) : fam_satellite_jacobian(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_jacobian(d, rule, diff, dtype, a) : fam_quadrotor_jacobian(d, rule, diff, dtype, a);
         default: return fam_lie_jacobian(d, rule, diff, dtype, a);
     }
 }
@@ -395,8 +401,8 @@ static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchA
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_rollout(d, rule, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_rollout(d, rule, dtype, a);
-        case RDHIP_MODEL_SATELLITE: return fam_satellite_rollout(d, rule, dtype, a);
-        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_rollout(d, rule, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_rollout(d, rule, dtype, a) : fam_satellite_rollout(d, rule, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_rollout(d, rule, dtype, a) : fam_quadrotor_rollout(d, rule, dtype, a);
         default: return fam_lie_rollout(d, rule, dtype, a);
     }
 }
@@ -410,8 +416,8 @@ static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_implicit(d, mode, dtype, a);
         case RDHIP_MODEL_DOUBLE_INTEGRATOR: case RDHIP_MODEL_LINEAR: return fam_simple_implicit(d, mode, dtype, a);
-        case RDHIP_MODEL_SATELLITE: return fam_satellite_implicit(d, mode, dtype, a);
-        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_SATELLITE: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_implicit(d, mode, dtype, a) : fam_satellite_implicit(d, mode, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_implicit(d, mode, dtype, a) : fam_quadrotor_implicit(d, mode, dtype, a);
         case RDHIP_MODEL_CUSTOM: { const int rc = jit_implicit(d.jit, mode, dtype, a); if (rc) g_jit_model = &d; return rc; }
         default: return fam_lie_implicit(d, mode, dtype, a);
     }
@@ -422,7 +428,7 @@ static int eval_common(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, 
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (N > 0 && (!Z || !t || !dt || !Y)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
     LaunchArgs a{}; a.stream = c->stream; a.N = N;
@@ -449,7 +455,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
     if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     if (N > 0 && (!Z || !t || !dt || !J)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
     if (implicit && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take ImplicitFunctionTheorem(ForwardAD()) only", what);
@@ -482,7 +488,7 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
         if (N[b] < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has negative N", what, b);
         if (N[b] > 0 && (!Z[b] || !t[b] || !dt[b] || !J[b])) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has a NULL data pointer", what, b);
     }
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const ModelDesc& d = M->d;
     bool fused = memspace == RDHIP_DEVICE && rule != RDHIP_IMPLICIT_MIDPOINT && d.kind != RDHIP_MODEL_CUSTOM;
     for (int b0 = 0; fused && b0 < nbatch; b0 += 32) {          // the kernel-argument table holds 32 batches: more go out in groups
@@ -515,7 +521,7 @@ static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
     if (!Z || !t || !dt || (!want_jac && !E)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d; const int nz = d.n + d.m;
     Stage s(c);
     const void* dZ = Z; const double* dtm = t; const double* ddt = dt; void* dJ2 = J2; void* dJ1 = J1; void* dE = E;
@@ -555,7 +561,7 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
     if (!Z || !t || !dt || !Ebar) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 2); if (rc) return rc;
     const ModelDesc& d = M->d;
     const bool rigid = d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR;
     const bool lie_fused = d.kind == RDHIP_MODEL_SATELLITE_PAIR || d.kind == RDHIP_MODEL_LIE_SATELLITE;   // compiled-in LieGroupModels: fused kernel too
@@ -595,7 +601,7 @@ int rdhip_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long 
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (N > 0 && (!X || !G)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     if (ldx < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: ldx=%d < state_dim=%d", what, ldx, M->d.n);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 1); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_errstate_jacobian(M->lie, dtype, c->stream, N, X, ldx, clear, G), what);
     Stage s(c);
@@ -625,7 +631,7 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype,
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (N > 0 && (!X || !Xb || !H)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     if (ldx < M->d.n || ldxb < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 2); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_nabla_errstate(M->lie, dtype, c->stream, N, X, ldx, Xb, ldxb, clear, H), what);
     Stage s(c);
@@ -642,7 +648,7 @@ int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long 
     if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
     if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (K * Mt > 0 && (!Z || !t || !dt)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
@@ -670,7 +676,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     const long long N = K * Mt;
     if (N == 0) return RDHIP_OK;
     if (!Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
     if (implicit && diff != RDHIP_FORWARD_AD) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take ImplicitFunctionTheorem(ForwardAD()) only", what);
     if (implicit && layout == RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take trajectory-major data only", what);

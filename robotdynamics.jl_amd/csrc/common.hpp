@@ -113,6 +113,7 @@ RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)
 RD_DECLARE_FAMILY(fam_quadrotor)
 RD_DECLARE_FAMILY(fam_lie)
+RD_DECLARE_FAMILY(fam_rigid3)   // RigidBody{MRP}, RigidBody{RodriguesParam}
 int fam_satellite_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
 int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
 int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);               // satellite pair, lie satellite
@@ -132,8 +133,8 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a);
 // error-state kernels (errstate.hip)
 struct LieDesc {
     int n, e, nrot;
-    int rot;                    // rdhip_rotation of the rotation blocks (QUAT: 4 parameters, MRP / RP: 3); only state_diff serves MRP / RP
-    signed char row_kind[16];   // 0: vector row, 1: quaternion row
+    int rot;                    // rdhip_rotation of the rotation blocks (QUAT: 4 parameters, MRP / RP: 3)
+    signed char row_kind[16];   // 0: vector row, 1: quaternion row, 2: MRP / RodriguesParam row
     signed char row_col[16];    // vector row: its column in G ; quaternion row: first column of the 3-wide block
     signed char row_sub[16];    // quaternion row: component index 0..3
     signed char row_q0[16];     // quaternion row: state index of the quaternion's scalar part

@@ -143,6 +143,34 @@ __global__ void __launch_bounds__(256) errstate_pattern_kernel(LieDesc d, long l
     }
 }
 
+// LieState{MRP,P} / LieState{RodriguesParam,P}: the 3 x 3 rotation blocks grad-differential(p) of Rotations.jl (the Jacobian of params(p * R(delta)) at
+// delta = 0, delta in the rotation's own parameters):   MRP  (1 - p.p) I + 2 (skew(p) + p p')      RodriguesParam  I + skew(g) + g g'
+// One thread per element of the n x e slab; clear = 0 writes only the pattern (vector-part ones and the blocks), like the reference.
+template <class T> __device__ __forceinline__ T rot3_block(int rot, const T* p, int i, int j) {
+    const T p0 = p[0], p1 = p[1], p2 = p[2];
+    const T pi = i == 0 ? p0 : i == 1 ? p1 : p2, pj = j == 0 ? p0 : j == 1 ? p1 : p2;
+    T sk = T(0);
+    if (i != j) { const int k = 3 - i - j; const T pk = k == 0 ? p0 : k == 1 ? p1 : p2; sk = ((j - i + 3) % 3 == 2) ? pk : -pk; }
+    if (rot == RDHIP_ROT_MRP) return ((i == j) ? T(1) - (p0 * p0 + p1 * p1 + p2 * p2) : T(0)) + T(2) * (sk + pi * pj);
+    return ((i == j) ? T(1) : T(0)) + sk + pi * pj;
+}
+template <class T>
+__global__ void __launch_bounds__(256) errstate3_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, int clear, T* __restrict__ G) {
+    const long long per = (long long)d.n * d.e;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * per) return;
+    const long long k = idx / per;
+    const int r_c = (int)(idx - k * per);
+    const int c = r_c / d.n, r = r_c - c * d.n;
+    if (d.row_kind[r] == 0) {
+        if (c == d.row_col[r]) G[idx] = T(1); else if (clear) G[idx] = T(0);
+    } else {
+        const int j = c - d.row_col[r];
+        if (j >= 0 && j < 3) G[idx] = rot3_block<T>(d.rot, X + k * ldx + d.row_q0[r], d.row_sub[r], j);
+        else if (clear) G[idx] = T(0);
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) state_diff_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, T* __restrict__ dX) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,6 +308,8 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
     if (N == 0) return RDHIP_OK;
     if (d.nrot == 0) {   // EuclideanState: G = I (always cleared, src/statevectortype.jl:149-155)
         hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d.n, d.e, N, (T*)G, 1);
+    } else if (d.rot != RDHIP_ROT_QUAT) {
+        hipLaunchKernelGGL((errstate3_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, clear, (T*)G);
     } else if (clear) {
         // 32 knot points per tile (40 KB for a rigid body: four workgroups per CU; 64-knot tiles, two per CU, ran 3 % slower; 16-knot tiles 1.5 %)
         constexpr int TK = 32;

@@ -203,6 +203,91 @@ template <class T, int WRENCH, bool BODY, bool DIAGJ> struct Cascade<RigidBody<T
     static constexpr int control_block(int j) { return (WRENCH == WRENCH_SATELLITE && j < 3) ? 2 : 0; }
 };
 
+// RigidBody{MRP} / RigidBody{RodriguesParam}: x = [r(3) p(3) v(3) w(3)] (gen_inds, src/rigidbody.jl:80-94: q = 4:6, v = 7:9, w = 10:12), n = 12.
+// src/rigidbody.jl:213-236 with the three-parameter attitude p:
+//   rotation of a vector: Rotations.jl multiplies through the unit quaternion of p (MRP: q = [(1 - p.p), 2p] / (1 + p.p);
+//                         RodriguesParam: q = [1, g] / sqrt(1 + g.g)), built WITHOUT renormalisation
+//   kinematics:           MRP  pdot = 1/4 ((1 - p.p) w + 2 p x w + 2 p (p.w))      RodriguesParam  gdot = 1/2 (w + g x w + g (g.w))
+// (the same matrices are the error-state blocks of errstate.hip).  The rotation kind and the velocity frame are run-time
+// members -- uniform branches; these models are not on a BASELINE configuration and get the compact run-time-column kernels.
+template <class T_, int WRENCH> struct RigidBody3 {
+    using T = T_;
+    static constexpr int NX = 12, NU = (WRENCH == WRENCH_SATELLITE) ? 6 : 4;
+    static constexpr int NROT = 0;                       // (no quaternion in the state: the fused error-state expansion is not offered)
+    static constexpr int rot_start(int) { return 3; }
+    static constexpr bool HAS_USER_JACOBIAN = false;    // the reference's analytic Jacobian is for RigidBody{<:QuatRotation} only (src/rigidbody.jl:260)
+    int rot;            // 1 = MRP, 2 = RodriguesParam (rdhip_rotation)
+    int body;           // velocity frame (src/rigidbody.jl:258)
+    T mass, inv_mass;
+    T J[9], Jinv[9];
+    T grav[3], L, kf, km;
+    static RigidBody3 make(const double* p, int rot_, int body_) {
+        RigidBody3 M; M.rot = rot_; M.body = body_; M.mass = T(p[0]); M.inv_mass = T(1.0 / p[0]);
+        double Ji[9]; host_inv3(p + 1, Ji);
+        for (int i = 0; i < 9; ++i) { M.J[i] = T(p[1 + i]); M.Jinv[i] = T(Ji[i]); }
+        if (WRENCH == WRENCH_QUADROTOR) {
+            for (int i = 0; i < 3; ++i) M.grav[i] = T(p[0] * p[10 + i]);
+            M.L = T(p[13]); M.kf = T(p[14]); M.km = T(p[15]);
+        } else { M.grav[0] = M.grav[1] = M.grav[2] = T(0); M.L = M.kf = M.km = T(0); }
+        return M;
+    }
+    template <class S> RD_DEV void to_quat(const S* p, S* q) const {
+        const S n = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        if (rot == 1) {
+            const S d = recip_(n + T(1)), M = d * T(2);
+            q[0] = (T(1) - n) * d; q[1] = p[0] * M; q[2] = p[1] * M; q[3] = p[2] * M;
+        } else {
+            const S M = recip_(sqrt_(n + T(1)));
+            q[0] = M; q[1] = p[0] * M; q[2] = p[1] * M; q[3] = p[2] * M;
+        }
+    }
+    template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
+        const S* p = x + 3; const S* v = x + 6; const S* w = x + 9;
+        S q[4]; to_quat(p, q);
+        S F[3], tau[3];
+        if constexpr (WRENCH == WRENCH_SATELLITE) {
+            quat_rotate(q, u, F);
+            tau[0] = u[3]; tau[1] = u[4]; tau[2] = u[5];
+        } else {
+            const S F1 = max0_(u[0] * kf), F2 = max0_(u[1] * kf), F3 = max0_(u[2] * kf), F4 = max0_(u[3] * kf);
+            const S fb[3] = {S(T(0)), S(T(0)), F1 + F2 + F3 + F4};
+            S qF[3]; quat_rotate(q, fb, qF);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) F[i] = qF[i] + grav[i];
+            tau[0] = (F2 - F4) * L; tau[1] = (F3 - F1) * L;
+            tau[2] = (u[0] - u[1] + u[2] - u[3]) * km;
+        }
+        // kinematics
+        {
+            const S pp = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], pw = p[0] * w[0] + p[1] * w[1] + p[2] * w[2];
+            S c[3]; cross3(p, w, c);
+            if (rot == 1) {
+                const S a = T(1) - pp;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xd[3 + i] = (a * w[i] + (c[i] + p[i] * pw) * T(2)) * T(0.25);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xd[3 + i] = (w[i] + c[i] + p[i] * pw) * T(0.5);
+            }
+        }
+        if (!body) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xd[i] = v[i]; xd[6 + i] = F[i] * inv_mass; }
+        } else {
+            quat_rotate(q, v, xd);
+            S Fm[3] = {F[0] * inv_mass, F[1] * inv_mass, F[2] * inv_mass};
+            S a[3]; quat_rotate_inv(q, Fm, a);
+            S c[3]; cross3(w, v, c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xd[6 + i] = a[i] - c[i];
+        }
+        S Jw[3]; mat3vec(J, w, Jw);
+        S c[3]; cross3(w, Jw, c);
+        S tt[3] = {tau[0] - c[0], tau[1] - c[1], tau[2] - c[2]};
+        mat3vec(Jinv, tt, xd + 9);
+    }
+};
+
 // SatellitePair: x = [q1(4) w1(3) q2(4) w2(3)], u = [u1(3) u2(3)]
 template <class T_> struct SatellitePair {
     using T = T_;

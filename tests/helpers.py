@@ -56,7 +56,12 @@ def model_spec(name, d):
 
 def oracle_model(name, d):
     kind, params, frame = model_spec(name, d)
-    return O.Model(kind, params, frame=frame)
+    return O.Model(kind, params, frame=frame, rot=int(d["rot"]) if "rot" in d else O.ROT_QUAT)      # rot: RigidBody{MRP|RodriguesParam} fixtures (make_golden_rot3.py)
+
+
+def three_parameter(name):
+    """dyn_* fixtures of RigidBody{MRP} / RigidBody{RodriguesParam} (no user-defined Jacobian in the reference: src/rigidbody.jl:260)"""
+    return "_mrp_" in name or "_rp_" in name
 
 
 def rand_rigid(rng, N, m, ulo=0.0, uhi=1.0):

@@ -25,10 +25,11 @@ def rd_model(name, d):
         return RD.DoubleIntegrator(int(d["params"][0]))
     if name.startswith("linear"):
         return RD.LinearModel(d["A"], d["B"])
+    R = {0: RD.QuatRotation, 1: RD.MRP, 2: RD.RodriguesParam}[int(d["rot"]) if "rot" in d else 0]
     if name.startswith(("satellite_", "body_", "satfull_")):
-        return RD.Satellite(float(d["mass"]), d["J"], bodyframe=bool(d["frame"]))
+        return RD.Satellite(float(d["mass"]), d["J"], R, bodyframe=bool(d["frame"]))
     if name.startswith("quadrotor"):
-        return RD.Quadrotor(mass=float(d["mass"]), J=d["J"], gravity=d["gravity"], motor_dist=float(d["L"]), kf=float(d["kf"]), km=float(d["km"]),
+        return RD.Quadrotor(R, mass=float(d["mass"]), J=d["J"], gravity=d["gravity"], motor_dist=float(d["L"]), kf=float(d["kf"]), km=float(d["km"]),
                             bodyframe=bool(d["frame"]))
     if name.startswith("satpair"):
         return RD.SatellitePair(d["J1"], d["J2"])
@@ -73,7 +74,7 @@ def test_golden_dynamics_and_jacobians(name, where):
         np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=1e-6 * scale)
         # UserDefined: the integrator's chain rule over continuous stage Jacobians == AD through the step to 1e-10
         # (test/integration_tests.jl:7-18); models without a user Jacobian raise NotImplementedError (src/functionbase.jl:257)
-        if name.startswith(("satpair", "liesat")):
+        if name.startswith(("satpair", "liesat")) or H.three_parameter(name):
             with pytest.raises(NotImplementedError):
                 RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), dm, J, Y, Z)
         else:
@@ -81,7 +82,7 @@ def test_golden_dynamics_and_jacobians(name, where):
             RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), dm, J, Y, Z)
             np.testing.assert_allclose(host(J), d["Jd_" + rn], rtol=0, atol=TOL * scale)
             np.testing.assert_allclose(host(Y), d["xn_" + rn], rtol=0, atol=TOL)
-    if not name.startswith(("satpair", "liesat")):
+    if not name.startswith(("satpair", "liesat")) and not H.three_parameter(name):
         RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), model, J, Y, Z)
         np.testing.assert_allclose(host(J), d["Jc"], rtol=0, atol=TOL * max(1.0, np.abs(d["Jc"]).max()))
 
@@ -108,6 +109,42 @@ def test_golden_errstate(tag, mk, where):
     dG = base.transpose(1, 2) if where == "cuda" else base.transpose(0, 2, 1)
     RD.nabla_errstate_jacobian_(model, dG, X, Xb)
     np.testing.assert_allclose(host(dG), d["dG"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("rtag", ["mrp", "rp"])
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_golden_errstate_three_parameter_rotations(rtag, where):
+    """errstate_jacobian! / state_diff of LieState{MRP,P} and LieState{RodriguesParam,P} (src/liestate.jl:262-298, :210-260): the rigid body's (3, 6)
+    and test/liestate.jl:56-68's (3, 2, 3), against blocks differentiated from the composition map params(R * R(delta)) (make_golden_rot3.py) and
+    against the oracle's closed forms; G is not cleared unless asked; the second-order map is not offered for these rotations."""
+    R = RD.MRP if rtag == "mrp" else RD.RodriguesParam
+    for tag, what, om in (("rigid", RD.Body(R), O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), rot=O.ROT_MRP if rtag == "mrp" else O.ROT_RP)), ("p323", RD.LieState(R, (3, 2, 3)), None)):
+        d = H.load(f"err_{tag}_{rtag}")
+        X, X0 = d["X"], d["X0"]
+        if where == "cuda":
+            X, X0 = torch.as_tensor(X).cuda(), torch.as_tensor(X0).cuda()
+        N, n = X.shape
+        e = RD.errstate_dim(what)
+        assert e == n and d["G"].shape == (N, n, e)
+        mk = lambda fill: ((torch.full((N, e, n), fill, dtype=torch.float64, device="cuda") if where == "cuda" else np.full((N, e, n), fill)).transpose(1, 2) if where == "cuda"
+                           else np.full((N, e, n), fill).transpose(0, 2, 1))
+        G = mk(0.0)
+        RD.errstate_jacobian_(what, G, X)
+        np.testing.assert_allclose(host(G), d["G"], rtol=0, atol=TOL)
+        G2 = mk(7.0)
+        RD.errstate_jacobian_(what, G2, X, clear=True)
+        np.testing.assert_allclose(host(G2), d["G"], rtol=0, atol=TOL)
+        G3 = mk(7.0)
+        RD.errstate_jacobian_(what, G3, X)                     # pattern only: everything outside the ones and the 3 x 3 blocks keeps its 7
+        g3 = host(G3)
+        pattern = d["G"] != 0
+        np.testing.assert_allclose(g3[pattern], d["G"][pattern], rtol=0, atol=TOL)
+        assert np.all(g3[~pattern & (np.abs(d["G"]) == 0)][:5] == 7.0)
+        np.testing.assert_allclose(host(RD.state_diff(what, X, X0)), d["dX"], rtol=0, atol=1e-9)
+        if om is not None:
+            np.testing.assert_allclose(host(G), om.errstate_jacobian(d["X"]), rtol=0, atol=TOL)
+        with pytest.raises(NotImplementedError):
+            RD.nabla_errstate_jacobian_(what, torch.zeros((N, e, e), dtype=torch.float64, device="cuda").transpose(1, 2) if where == "cuda" else np.zeros((N, e, e)).transpose(0, 2, 1), X, X0)
 
 
 def test_errstate_does_not_clear_by_default():
@@ -471,9 +508,9 @@ def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
                 r += rp; c += 3
         a, b = (torch.as_tensor(X).cuda(), torch.as_tensor(X0).cuda()) if where == "cuda" else (X, X0)
         np.testing.assert_allclose(host(RD.state_diff(s, a, b)), exp, rtol=0, atol=1e-12)
-        if kind != "quat":      # the error-state Jacobians of MRP / RodriguesParam states are not built (formulas unpinned)
+        if kind != "quat":      # the second-order map of MRP / RodriguesParam states is not built (formula unpinned)
             with pytest.raises(NotImplementedError):
-                RD.errstate_jacobian_(s, np.zeros((N, 14, n)).transpose(0, 2, 1), X, clear=True)
+                RD.nabla_errstate_jacobian_(s, np.zeros((N, 14, 14)).transpose(0, 2, 1), X, X0)
 
 
 def test_empty_batch_is_a_noop():
@@ -1315,6 +1352,51 @@ def test_rollout_then_jacobians_in_one_call(case):
     np.testing.assert_allclose(Jg.reshape(Jref.shape), Jref, rtol=0, atol=1e-8 if implicit else TOL)
     if after is not None:
         assert abs(float(after) - float(Jref.sum())) <= 1e-6 * max(1.0, abs(float(Jref.sum())))
+
+
+@pytest.mark.parametrize("rtag", ["mrp", "rp"])
+def test_three_parameter_rigid_bodies_rollout_implicit_midpoint_and_finite_difference(rtag):
+    """RigidBody{MRP} / RigidBody{RodriguesParam} (src/rigidbody.jl:80-107, :213-236; test/rigidbody_test.jl:79-98) beyond the golden fixtures: both
+    velocity frames and wrenches through rollout!, ImplicitMidpoint (Newton solve + implicit-function-theorem Jacobian), FiniteDifference and a
+    terminal knot point, against the oracle; dimension queries bit-exact; fp32 against the fp64 oracle."""
+    R, rot = (RD.MRP, O.ROT_MRP) if rtag == "mrp" else (RD.RodriguesParam, O.ROT_RP)
+    rng = np.random.default_rng(61)
+    for body in (False, True):
+        frame = O.FRAME_BODY if body else O.FRAME_WORLD
+        for model, om, mctl, ulo, uhi in ((RD.Body(R, body), O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), frame, rot), 6, 0.0, 1.0),
+                                          (RD.Quadrotor(R, bodyframe=body), O.quadrotor(frame, rot), 4, 0.6, 1.9)):
+            assert RD.dims(model)[:2] == (12, mctl) and RD.errstate_dim(model) == 12
+            N = 64 * 2 + 11
+            Zn = np.concatenate([rng.random((N, 3)), 0.6 * rng.random((N, 3)) - 0.3, rng.random((N, 6)), ulo + (uhi - ulo) * rng.random((N, mctl))], axis=1)
+            t, dt = np.arange(N) * 0.1, np.full(N, 0.1); dt[-1] = 0.0
+            Z = traj(model, Zn, t, dt, "cuda")
+            dm = RD.DiscretizedDynamics(model, RD.RK4)
+            J = RD.alloc_jacobians(dm, N, Z.data)
+            Y = torch.empty((N, 12), dtype=torch.float64, device="cuda")
+            RD.jacobian_(RD.StaticReturn(), RD.FiniteDifference(), dm, J, Y, Z)
+            Jex, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+            np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+            np.testing.assert_allclose(host(J), Jex, rtol=0, atol=1e-6 * max(1.0, np.abs(Jex).max()))
+            assert np.all(host(J)[-1][:, 12:] == 0.0)                          # terminal knot point: zero control columns
+            dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+            RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, J, Y, Z)
+            Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
+            np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
+            np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL * max(1.0, np.abs(Jo).max()))
+            # rollout!
+            M, K = 70, 9
+            data = np.stack([np.roll(Zn[:M], k, axis=0) for k in range(K)], axis=1)
+            tt = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy(); dd = np.full((M, K), 0.05)
+            ref = om.rollout(O.RK4, data, tt, dd)
+            stack = {"data": torch.as_tensor(np.ascontiguousarray(data)).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+            RD.rollout_(RD.StaticReturn(), dm, stack)
+            np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
+            # fp32 against the fp64 oracle
+            Z32 = traj(model, Zn, t, dt, "cuda", dtype=np.float32)
+            J32 = RD.alloc_jacobians(dm, N, Z32.data)
+            RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J32, None, Z32)
+            Jo32, _ = om.jacobian(O.RK4, O.FORWARD_AD, Zn.astype(np.float32).astype(np.float64), t, dt)
+            np.testing.assert_allclose(host(J32), Jo32, rtol=1e-4, atol=1e-4)
 
 
 def test_single_knot_point_api_reads_like_the_reference():

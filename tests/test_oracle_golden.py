@@ -46,7 +46,7 @@ def test_finite_difference_within_1e6(name):
     np.testing.assert_allclose(J, d["Jd_rk4"], rtol=0, atol=1e-6 * scale)
 
 
-@pytest.mark.parametrize("name", [n for n in H.dyn_cases() if not n.startswith(("satpair", "liesat"))])
+@pytest.mark.parametrize("name", [n for n in H.dyn_cases() if not n.startswith(("satpair", "liesat")) and not H.three_parameter(n)])
 def test_user_defined_chain_rule(name):
     # chain rule == AD through the step to 1e-10 (test/integration_tests.jl:7-18,64-71,102-109)
     d = H.load("dyn_" + name)
@@ -64,6 +64,19 @@ def test_user_defined_missing_raises():
     M = O.satellite_pair()
     with pytest.raises(NotImplementedError):
         M.jacobian(O.CONTINUOUS, O.USER, np.ones((1, 20)), 0.0, 0.1)
+    with pytest.raises(NotImplementedError):                                      # the analytic rigid-body Jacobian is for QuatRotation only (src/rigidbody.jl:260)
+        O.satellite(rot=O.ROT_MRP).jacobian(O.RK4, O.USER, np.ones((1, 18)), 0.0, 0.1)
+
+
+@pytest.mark.parametrize("rtag,rot", [("mrp", O.ROT_MRP), ("rp", O.ROT_RP)])
+def test_errstate_three_parameter_rotations(rtag, rot):
+    """grad-differential of MRP / RodriguesParam (oracle closed forms) against the blocks differentiated from the composition map
+    params(R * R(delta)) in tests/golden/make_golden_rot3.py; Cayley state difference through scipy."""
+    d = H.load(f"err_rigid_{rtag}")
+    M = O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), rot=rot)
+    assert (M.n, M.e) == (12, 12)                                                  # test/rigidbody_test.jl:94-98
+    np.testing.assert_allclose(M.errstate_jacobian(d["X"]), d["G"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(M.state_diff(d["X"], d["X0"]), d["dX"], rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("tag,mk", [("rigid", O.satellite), ("satpair", O.satellite_pair), ("liesat", O.lie_satellite)])
