@@ -376,7 +376,7 @@ def main():
                        "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
                        "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlan<19,4,...>,4>",
+                         "traffic": traffic, "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
         }
         if gather:

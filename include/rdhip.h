@@ -106,7 +106,11 @@ int rdhip_memcpy_h2d(rdhip_ctx* ctx, void* dst, const void* src, unsigned long l
 int rdhip_memcpy_d2h(rdhip_ctx* ctx, void* dst, const void* src, unsigned long long bytes); /* synchronous */
 
 /* ---------------------------------------------------------------- models and integer queries --------- */
-/* host-only object (no GPU needed) */
+/* host-only object (no GPU needed).  rotation: the R of RigidBody{R} / LieState{R,P} (src/rigidbody.jl:46, src/liestate.jl:75-83).  RDHIP_ROT_QUAT serves
+ * every operator.  RDHIP_ROT_MRP / RDHIP_ROT_RP (n = 12 rigid bodies, src/rigidbody.jl:80-94, test/rigidbody_test.jl:79-98): dynamics, the explicit rules
+ * and ImplicitMidpoint, ForwardAD / FiniteDifference Jacobians, rollout, errstate_jacobian!, state_diff for the SATELLITE and QUADROTOR kinds;
+ * errstate_jacobian! and state_diff for every LieState; RDHIP_USER_DEFINED -> RDHIP_ERR_NOT_IMPLEMENTED (the reference's analytic Jacobian is
+ * QuatRotation-only, src/rigidbody.jl:260); nabla-errstate_jacobian! and rdhip_error_expansion -> RDHIP_ERR_UNSUPPORTED (not pinned by any test). */
 int rdhip_model_create(int kind, int rotation, int velocity_frame, const double* params, int nparams, rdhip_model** out);
 int rdhip_model_destroy(rdhip_model* model);
 /* A user-defined ContinuousDynamics model (the reference's `dynamics(model, x, u)` method, src/dynamics.jl:23-45), given as HIP source:
@@ -214,7 +218,8 @@ int rdhip_error_expansion(rdhip_ctx* ctx, const rdhip_model* model, int rule, in
  * a packed trajectory).  G: n x e x N column-major.  clear != 0: G is fully overwritten (zeros elsewhere);
  * clear == 0 reproduces the reference exactly for RotationState models: only the identity diagonals and the
  * rotation blocks are written, every other entry of G is left untouched (src/liestate.jl:293-297).
- * EuclideanState models always write G = I (the reference clears in that branch). */
+ * EuclideanState models always write G = I (the reference clears in that branch).  Rotation blocks: QuatRotation 4 x 3 L(q)H (q normalised);
+ * MRP 3 x 3 (1 - p.p) I + 2 (skew(p) + p p'); RodriguesParam 3 x 3 I + skew(g) + g g' (Rotations.jl grad-differential). */
 int rdhip_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
                             const void* X, int ldx, int clear, void* G, int memspace);
 
@@ -225,7 +230,7 @@ int rdhip_state_diff(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long l
                      const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace);
 
 /* nabla-errstate_jacobian!(model, nablaG, x, xbar) (v0.3: nabla^2 differential!): src/statevectortype.jl:137-147,
- * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian. */
+ * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian.  QuatRotation states only (RDHIP_ERR_UNSUPPORTED otherwise). */
 int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
                                   const void* X, int ldx, const void* Xbar, int ldxbar, int clear, void* nablaG, int memspace);
 
