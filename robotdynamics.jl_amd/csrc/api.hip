@@ -21,6 +21,7 @@ struct rdhip_ctx {
     bool own_stream;
     hipEvent_t ev0, ev1;
     bool capturing = false;               // between rdhip_graph_begin_capture and rdhip_graph_end_capture
+    int epoch = 0;                        // implicit calls on this context so far (mod 2^23, never 0): LaunchArgs::epoch
     int* d_flag = nullptr;                // device words "a row exchange was needed" of the implicit kernels (allocated with the context: never inside a capture)
     std::string err;
     // grow-only device workspace slots for RDHIP_HOST staging
@@ -100,6 +101,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, (size_t)(1 + IMPLICIT_FLAG_WORDS) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));          // word 0 = epoch of the last call that raised a tile word (0: none yet)
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
@@ -412,6 +414,8 @@ static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype
     a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
     if (mode != 2) {     // Newton kernels: register pass + gated LDS pass communicate through a device word
         a.flag = c->d_flag;
+        c->epoch = c->epoch >= (1 << 23) ? 1 : c->epoch + 1;
+        a.epoch = c->epoch;
     }
     switch (d.kind) {
         case RDHIP_MODEL_CARTPOLE: return fam_cartpole_implicit(d, mode, dtype, a);

@@ -98,6 +98,7 @@ struct LaunchArgs {
     double newton_tol;
     int time_major;     // rollout: knot k of trajectory j at k*M + j instead of j*K + k
     int* flag;          // implicit rules: device word of the context ("a row exchange was needed"); NULL = LDS kernels only
+    int epoch;          // implicit rules: 1 .. 2^23, different for consecutive calls on a context (0: none); see implicit_midpoint_kernel
     const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
                               // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED and the caller loops over the batches
 };

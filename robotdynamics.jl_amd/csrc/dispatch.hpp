@@ -270,7 +270,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     const unsigned gridr = (unsigned)((a.N + TILE - 1) / TILE);
     constexpr bool reg_is_exact = ImplicitRegOps<Mdl, T>::PIVOT;     // small models pivot in registers: no second pass
     // one flag word per 64-knot tile when the context has enough of them (written unconditionally by the register kernel: no memset)
-    const int tile_flags = (mode != 3 && (long long)gridr <= IMPLICIT_FLAG_WORDS) ? 1 : 0;
+    const int tile_flags = (mode != 3 && (long long)gridr <= IMPLICIT_FLAG_WORDS) ? (1 | (a.epoch << 8)) : 0;
     constexpr size_t lds_reg = ImplicitRegOps<Mdl, T>::LDS_BYTES;
     if (a.flag && !reg_is_exact) {
         if (!tile_flags && hipMemsetAsync(a.flag, 0, sizeof(int), a.stream) != hipSuccess) return RDHIP_ERR_HIP;

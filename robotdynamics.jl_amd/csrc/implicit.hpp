@@ -187,7 +187,13 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // tile_flags: bit 0 = one flag word per 64-knot tile (gate[1 + tile]) instead of the single word gate[0]; bits 8.. = the call's epoch (0: none):
+    // with tile words, gate[0] holds the epoch of the last call in which ANY tile was raised, so a pass with nothing to do ends after one load
+    // instead of scanning its tile words (the register kernels store the epoch next to the tile word they raise; no clearing, no memset)
+    const int epoch = tile_flags >> 8;
+    tile_flags &= 1;
     if (gate && !tile_flags && *gate == 0) return;                       // second pass behind the register kernel: only if a row exchange was needed
+    if (gate && tile_flags && epoch && *gate != epoch) return;
     const int lane = threadIdx.x;
     T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
     int* piv = reinterpret_cast<int*>(smem + (size_t)L::KP * L::RSA * sizeof(T)) + lane * 16;
@@ -265,6 +271,113 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
 // faster than the LDS version above.  For n > 6 partial pivoting is reproduced exactly as long as it would not have exchanged rows (|pivot| >=
 // every entry below it, the usual case for I - (h/2) A); every lane checks that, and if any lane of the launch fails the check a flag
 // is raised and the LDS kernels above (launched behind this one, gated on the flag) recompute the whole batch with real row exchanges.
+// ---- Newton's method along the cascade ---------------------------------------------------------------------------------------------------
+// For a model with a block structure (Cascade<>: block b's derivative reads blocks 0..b only) the Newton matrix (h/2) A - I is block lower
+// triangular, and so is the implicit equation itself: block 0 of x_next solves its own small system, block 1 follows from it, and so on.  The
+// full Newton iteration of the reference (src/integration.jl:422-463) converges to the same root -- its block-0 iterates ARE the iterates of
+// block 0 alone, the later blocks trail by the linearisation error of the earlier ones -- but solving block by block costs a 3 x 3 iteration for
+// a rigid body's angular velocity, ONE 4 x 4 solve for its attitude (the kinematics are linear in q) and one 6 x 6 solve for r, v instead of
+// 3-4 factorisations of a 13 x 13 matrix.  What has to stay exact is the reference's behaviour when its loop ends at the iteration limit: it then returns an
+// iterate that is NOT the root (and takes the Jacobian one update earlier), so a lane is handed to the exact kernel (`hand_over`) whenever the
+// reference's full iteration could have run into the limit: its convergence test passes at the test at which block 0 passes or up to NB - 1
+// tests later, and block 0's own test count is known here.
+template <class Cas, int NX> struct BlockIndex {
+    static constexpr int count(int b) { int c = 0; for (int i = 0; i < NX; ++i) c += Cas::block_of(i) == b ? 1 : 0; return c; }
+    static constexpr int nth(int b, int j) { int c = 0; for (int i = 0; i < NX; ++i) if (Cas::block_of(i) == b) { if (c == j) return i; ++c; } return 0; }
+};
+// LU of a block WITHOUT row exchanges (the compile-time sparsity of the block survives: a world-frame r, v block is [[-I, (h/2) I], [0, -I]] and costs
+// nothing), pivots stored as reciprocals; returns true if partial pivoting would have exchanged rows somewhere (the lane then goes to the exact kernel,
+// like the lanes of the 13 x 13 factorisation below)
+template <class T, int N> RD_DEV bool lu_small(T (&a)[N][N]) {
+    bool need = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const T pk = a[k][k] < T(0) ? -a[k][k] : a[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) { const T v = a[i][k] < T(0) ? -a[i][k] : a[i][k]; need = need || (v > pk); }
+        const T inv = T(1) / a[k][k];
+        a[k][k] = inv;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const T l = a[i][k] * inv; a[i][k] = l;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) a[i][j] -= l * a[k][j];
+        }
+    }
+    return need;
+}
+template <class T, int N> RD_DEV void solve_small(const T (&a)[N][N], T (&b)[N]) {
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) b[i] -= a[i][j] * b[j];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) b[i] -= a[i][j] * b[j];
+        b[i] = b[i] * a[i][i];
+    }
+}
+template <class Mdl, class T, class Cas> struct CascadeNewton {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NB = Cas::NB;
+    using BI = BlockIndex<Cas, NX>;
+    using Ops = ImplicitOps<Mdl, T>;
+    // column J of block B of (h/2) A - I, rows of block B only (compile-time recursion over J; the other rows of the tangent fold away)
+    template <int B, int J, int NBK> static RD_DEV void block_cols(const Mdl& m, const T (&xm)[NX], const T (&u)[NU], T tj, T h, T (&a)[NBK][NBK]) {
+        if constexpr (J < NBK) {
+            constexpr int C = BI::nth(B, J);
+            T col[NX];
+            Ops::template jcol<C>(m, xm, u, tj, col);
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) a[i][J] = col[BI::nth(B, i)] * (h * T(0.5)) - ((i == J) ? T(1) : T(0));
+            block_cols<B, J + 1, NBK>(m, xm, u, tj, h, a);
+        }
+    }
+    // block B of x_next (upstream blocks of xn final, this and the downstream ones still x1); tests = residual evaluations until ||r_B|| < tol
+    template <int B> static RD_DEV void solve_from(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], int& tests0, bool& open) {
+        if constexpr (B < NB) {
+            constexpr int NBK = BI::count(B);
+            const T tm = tj + h * T(0.5);
+            bool done = false;
+            int tests = 0;
+            for (int it = 0; it < iters; ++it) {
+                T xm[NX], f[NX], r[NBK];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xm[i] = (x1[i] + xn[i]) * T(0.5);
+                model_f(m, xm, u, tm, f);
+                T nr = T(0);
+#pragma unroll
+                for (int i = 0; i < NBK; ++i) { const int gi = BI::nth(B, i); r[i] = x1[gi] + h * f[gi] - xn[gi]; nr += r[i] * r[i]; }
+                if (!done) ++tests;
+                if ((double)sqrt_(nr) < tol) done = true;
+                if (__all(done)) break;
+                T a[NBK][NBK];
+                block_cols<B, 0, NBK>(m, xm, u, tj, h, a);
+                const bool need = lu_small<T, NBK>(a);
+                if (!done) open = open || need;
+                solve_small<T, NBK>(a, r);
+                if (!done) {
+#pragma unroll
+                    for (int i = 0; i < NBK; ++i) xn[BI::nth(B, i)] -= r[i];
+                }
+            }
+            if (B == 0) tests0 = tests;
+            open = open || !done;
+            solve_from<B + 1>(m, x1, u, tj, h, iters, tol, xn, tests0, open);
+        }
+    }
+    // returns true if the lane has to be redone by the exact kernel (see above)
+    static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = x1[i];
+        int tests0 = 0; bool open = false;
+        // every block meets the same norm as the reference's full residual would: ||r||^2 = sum of the blocks' < NB (tol / sqrt(NB))^2
+        solve_from<0>(m, x1, u, tj, h, iters, tol * 0.5773502691896258, xn, tests0, open);
+        return open || (tests0 + NB - 1 > iters);
+    }
+};
+
 template <class Mdl, class T> struct ImplicitRegOps {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU;
     using Ops = ImplicitOps<Mdl, T>;
@@ -338,6 +451,15 @@ template <class Mdl, class T> struct ImplicitRegOps {
     // one Newton solve from x1 (src/integration.jl:422-463): xn = solution, xl = last tested iterate; true if a row exchange was needed
     // (*unconv = the lane left the loop at the iteration limit, i.e. xn is one update past the last tested iterate xl)
     static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX], bool* unconv = nullptr) {
+#if !defined(RD_NO_CASCADE_NEWTON)
+        if constexpr (Cascade<Mdl>::NB > 1) {          // block by block (CascadeNewton above); a lane it cannot vouch for goes to the exact kernel
+            const bool hand_over = CascadeNewton<Mdl, T, Cascade<Mdl>>::newton(m, x1, u, tj, h, iters, tol, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xl[i] = xn[i];
+            if (unconv) *unconv = false;
+            return hand_over;
+        }
+#endif
         const T tm = tj + h * T(0.5);
         T xm[NX], f[NX], r[NX];
 #pragma unroll
@@ -470,7 +592,10 @@ __global__ void __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(2))) 
     // "partial pivoting would have exchanged rows": per 64-knot tile (word 1 + tile, written unconditionally: no memset in front of the
     // launch) or, for batches with more tiles than the context holds words for, the single word 0 (cleared by the host)
     if (flag) {
-        if (tile_flags & 1) { const bool any = __any(need); if (threadIdx.x == 0) flag[1 + blockIdx.x] = any ? 1 : 0; }
+        if (tile_flags & 1) {
+            const bool any = __any(need);
+            if (threadIdx.x == 0) { flag[1 + blockIdx.x] = any ? 1 : 0; if (any && (tile_flags >> 8)) flag[0] = tile_flags >> 8; }      // (+ the call's epoch, see implicit_midpoint_kernel)
+        }
         else if (need) *flag = 1;
     }
 }
@@ -493,7 +618,7 @@ template <class Mdl> struct IftFun {
     Mdl m;
     const T* xn;         // the Newton solutions (n x N)
     int* flag;           // word 0, or word 1 + tile with tile_flags
-    int tile_flags;
+    int tile_flags;      // bit 0: tile words; bits 8..: the call's epoch (implicit_midpoint_kernel)
     RD_DEV const T* aux_ptr() const { return xn; }
 };
 template <class Fn, class T, class Plan, int G, int C> struct IftCols {
@@ -548,7 +673,10 @@ template <class Fn, class T, class Plan> struct IftBody {
         R::template fill<0>(fn.m, xm, fr.u, fr.t, fr.t + fr.h * T(0.5), fr.h, a, f);
         const bool need = R::lu(a, piv);
         if (fr.g == 0 && fn.flag) {                                  // every compute wave factorises the same matrices: one of them reports
-            if (__any(need) && (threadIdx.x & 63) == 0) fn.flag[fn.tile_flags ? 1 + fr.tile : 0] = 1;
+            if (__any(need) && (threadIdx.x & 63) == 0) {
+                fn.flag[(fn.tile_flags & 1) ? 1 + fr.tile : 0] = 1;
+                if ((fn.tile_flags & 1) && (fn.tile_flags >> 8)) fn.flag[0] = fn.tile_flags >> 8;
+            }
         }
         waves<0>(fn, fr, xm, a, piv);
     }
