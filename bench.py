@@ -93,10 +93,17 @@ def cpu_baseline(Zn, t, dt):
             "single_thread_value": v_one, "thread_scan": scan, "host_cpus": os.cpu_count(), "usable_cores": cores}
 
 
-def _timed_us(fn, reps, warm=20):
+def _timed_us(fn, reps, warm=20, load_s=0.1):
+    """HIP-event time per call of `reps` back-to-back calls, after `load_s` seconds of the same calls (allocating and uploading a case's inputs
+    leaves the GPU idle long enough for its clocks to drop: without the load the first ~100 ms of launches run 3-7 % slower)."""
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
+    t_end, i = _time.perf_counter() + load_s, 0
+    while _time.perf_counter() < t_end:
+        for _ in range(20):
+            fn(i); i += 1
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(reps):
