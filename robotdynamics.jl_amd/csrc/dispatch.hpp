@@ -160,6 +160,18 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
             constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+            if constexpr (Plan::NG == 4) {
+                // small batches (at most one tile per four CUs: up to 4 096 knot points on a whole MI355X): the columns of a tile over four workgroups
+                static const char* small_mode = getenv("RDHIP_SMALL");     // tuning switch: "tile" keeps the tile loop for every size
+                const long long ntiles = (a.N + TILE - 1) / TILE;
+                if (4 * ntiles <= (long long)dev_info().cus && !(small_mode && small_mode[0] == 't')) {
+                    constexpr size_t lds = ColSplitLds<Fn, T>::BYTES;
+                    auto kern = jac_ad_colsplit_kernel<Fn, T, Plan>;
+                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                    hipLaunchKernelGGL(kern, dim3((unsigned)(32 * ((ntiles + 7) / 8))), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+                    return hip_status(hipGetLastError());
+                }
+            }
             if constexpr (NC > 0) {
                 // compute/copy split-role kernel: needs 16-byte aligned output slabs (a tile is copied as 16-byte units)
                 if (aligned16(a.J) && aligned16(a.Y))

@@ -707,6 +707,101 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, mb);
 }
 
+// ---- small batches: one tile's columns over FOUR workgroups -----------------------------------------------------------------------------
+// A batch of a few thousand knot points (the reference's unit: ONE trajectory of 101 - 4 096 knot points) occupies at most 64 of the 256 CUs with
+// the tile loop above, and what it costs is a latency: launch, input round trip, then ~900 dependent fp64 instructions per compute wave (3.5 us),
+// then the stores.  Here workgroup (tile, g) computes only the columns the plan gives to compute wave g, spread over its own four waves (a wave
+// holds one or two columns: ~350 instead of ~900 instructions behind the inputs), so a 4 096-knot batch runs on all 256 CUs.  Every wave moves
+// its finished columns through a wave-private LDS buffer and stores them as 104-byte runs (8 B per lane, consecutive lanes consecutive
+// addresses); the partially written lines this leaves are harmless at these sizes -- the whole output is a few MB and stays in the caches until
+// it is complete (at 65 536 knot points the same pattern would cost what it cost the first ImplicitMidpoint kernel, implicit.hpp).
+// Same arithmetic per column as AdCols (same seeds, same fn.eval): results are bit-identical to the tile loop's.
+template <class Plan, int G, int C> struct GroupIndex {          // position of column C among the columns of plan wave G (compile time)
+    static constexpr int value() { int k = 0; for (int c = 0; c < C; ++c) k += Plan::wave_of(c) == G ? 1 : 0; return k; }
+};
+template <class Fn, class T, class Plan, int G, int W, int C> struct ColSplitCols {
+    static RD_DEV void run(const Fn& fn, const T (&x)[Fn::NX], const T (&u)[Fn::NU], T t, T h, bool term, T* buf, T* __restrict__ Jt, int nk, int lane) {
+        constexpr int NX = Fn::NX, NU = Fn::NU, NY = Fn::NY, NZ = NX + NU;
+        if constexpr (C < NZ) {
+            if constexpr (Plan::wave_of(C) == G && (GroupIndex<Plan, G, C>::value() & 3) == W) {
+                using D = Dual<T, 1>;
+                D xd[NX], ud[NU], yd[NY];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xd[i].v = x[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { ud[i].v = u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
+                fn.eval(xd, ud, t, h, yd);
+                const T sc = (C >= NX && term) ? T(0) : T(1);      // control columns of a terminal knot point are zero
+#pragma unroll
+                for (int i = 0; i < NY; ++i) buf[lane * NY + i] = yd[i].d[0] * sc;
+                wave_sync();
+                // 64 rows x NY values: element e = row * NY + i of the buffer goes to row's slab at column C
+#pragma unroll
+                for (int it = 0; it < NY; ++it) {
+                    const int e = it * TILE + lane, row = e / NY, i = e - row * NY;
+                    if (row < nk) Jt[(size_t)row * NY * NZ + C * NY + i] = buf[e];
+                }
+                wave_sync();
+            }
+            ColSplitCols<Fn, T, Plan, G, W, C + 1>::run(fn, x, u, t, h, term, buf, Jt, nk, lane);
+        }
+    }
+};
+template <class Fn, class T, class Plan>
+__global__ void __launch_bounds__(4 * TILE) jac_ad_colsplit_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+                                                                  const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
+    constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY;
+    static_assert(Plan::NG == 4 && Fn::NEXT == 0, "four column groups; bodies that read the next knot point use the tile loop");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* zs = reinterpret_cast<T*>(smem);                                                    // 64 x NZ inputs
+    double* ts = reinterpret_cast<double*>(smem + ((size_t)TILE * NZ * sizeof(T) + 15) / 16 * 16);        // t[64], dt[64]
+    T* bufs = reinterpret_cast<T*>(smem + ((size_t)TILE * NZ * sizeof(T) + 15) / 16 * 16 + 2 * TILE * sizeof(double));   // 4 x (64 x NY)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the four workgroups of a tile write into the same 128-byte lines: keep them on ONE XCD (workgroups are dealt to the 8 XCDs round-robin), so
+    // that their pieces of a line meet in one L2 instead of leaving four XCDs as partial lines.  Grid = 32 x ceil(ntiles / 8).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long tile = (long long)(slot >> 2) * 8 + xcd;
+    const int grp = slot & 3;
+    if (tile * TILE >= N) return;
+    const long long k0 = tile * TILE;
+    const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+    {
+        const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+        const int idx = threadIdx.x & (TILE - 1);
+        const double t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
+        stage_in<T, TILE * NZ, 4 * TILE>(Z + k0 * NZ, zs, nk * NZ, threadIdx.x);
+        if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
+    }
+    __syncthreads();
+    const int kl = lane < nk ? lane : nk - 1;
+    const double hd = ts[TILE + kl];
+    const T t = (T)ts[kl], h = (T)hd;
+    const bool term = is_terminal_dt(hd);
+    T x[NX], u[NU];
+    read_knot<Fn, T>(zs, kl, term, x, u);
+    T* buf = bufs + (size_t)wave * TILE * NY;
+    T* __restrict__ Jt = J + k0 * NY * NZ;
+    if (Y && grp == Plan::value_wave && wave == 3) {              // f(z): the last wave of the value group (it carries the fewest columns)
+        T y[NY];
+        fn.eval(x, u, t, h, y);
+#pragma unroll
+        for (int i = 0; i < NY; ++i) buf[lane * NY + i] = y[i];
+        wave_sync();
+#pragma unroll
+        for (int it = 0; it < NY; ++it) { const int e = it * TILE + lane; if (e < nk * NY) Y[k0 * NY + e] = buf[e]; }
+        wave_sync();
+    }
+#define RD_COLSPLIT_CASE(G_, W_) if (grp == G_ && wave == W_) ColSplitCols<Fn, T, Plan, G_, W_, 0>::run(fn, x, u, t, h, term, buf, Jt, nk, lane)
+    RD_COLSPLIT_CASE(0, 0); else RD_COLSPLIT_CASE(0, 1); else RD_COLSPLIT_CASE(0, 2); else RD_COLSPLIT_CASE(0, 3);
+    else RD_COLSPLIT_CASE(1, 0); else RD_COLSPLIT_CASE(1, 1); else RD_COLSPLIT_CASE(1, 2); else RD_COLSPLIT_CASE(1, 3);
+    else RD_COLSPLIT_CASE(2, 0); else RD_COLSPLIT_CASE(2, 1); else RD_COLSPLIT_CASE(2, 2); else RD_COLSPLIT_CASE(2, 3);
+    else RD_COLSPLIT_CASE(3, 0); else RD_COLSPLIT_CASE(3, 1); else RD_COLSPLIT_CASE(3, 2); else RD_COLSPLIT_CASE(3, 3);
+#undef RD_COLSPLIT_CASE
+}
+template <class Fn, class T> struct ColSplitLds {
+    static constexpr size_t BYTES = ((size_t)TILE * (Fn::NX + Fn::NU) * sizeof(T) + 15) / 16 * 16 + 2 * TILE * sizeof(double) + (size_t)4 * TILE * Fn::NY * sizeof(T);
+};
+
 // ---- error-state expansion: [G(x_{k+1})' A_k G(x_k) | G(x_{k+1})' B_k] fused into the Jacobian kernel ----------------------
 // (error_expansion! of TrajectoryOptimization.jl; G = errstate_jacobian!, src/liestate.jl:262-298).  G is block diagonal with
 // identities except for the 4x3 blocks L(q)H of the normalised quaternions, so the projection costs no extra pass:
