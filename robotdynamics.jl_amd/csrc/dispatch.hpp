@@ -161,10 +161,14 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
             constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
             if constexpr (Plan::NG == 4) {
-                // small batches (at most one tile per four CUs: up to 4 096 knot points on a whole MI355X): the columns of a tile over four workgroups
+                // small batches (at most two of these workgroups per CU: up to 8 192 knot points on a whole MI355X): the columns of a tile over four
+                // workgroups.  rocprofv3 medians against the tile loop: 4.8 vs 7.5 us up to 512 knot points, 5.7 vs 8.7 at 4 096, 8.0 vs 8.7 at 8 192;
+                // with four per CU 10.8 vs 8.6 at 12 288 and 12.8 vs 9.3 at 16 384 (tools/small_trace.sh)
                 static const char* small_mode = getenv("RDHIP_SMALL");     // tuning switch: "tile" keeps the tile loop for every size
                 const long long ntiles = (a.N + TILE - 1) / TILE;
-                if (4 * ntiles <= (long long)dev_info().cus && !(small_mode && small_mode[0] == 't')) {
+                static const char* small_max = getenv("RDHIP_SMALL_MAX");  // tuning: workgroups per CU up to which the column-split kernel is used
+                const long long per_cu = small_max ? atoll(small_max) : 2;
+                if (4 * ntiles <= per_cu * (long long)dev_info().cus && !(small_mode && small_mode[0] == 't')) {
                     constexpr size_t lds = ColSplitLds<Fn, T>::BYTES;
                     auto kern = jac_ad_colsplit_kernel<Fn, T, Plan>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;

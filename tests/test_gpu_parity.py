@@ -929,10 +929,10 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
                     np.testing.assert_allclose(host(Ys[b]), Yo, rtol=0, atol=TOL)
                 J1 = RD.alloc_jacobians(dm, N, Zs[b].data)
                 RD.jacobian_(sig, AD, dm, J1, None, Zs[b])
-                # the same arithmetic per column as the single-batch launch; batches of <= 4 096 knot points take the column-split kernel there
+                # the same arithmetic per column as the single-batch launch; batches of <= 8 192 knot points take the column-split kernel there
                 # (a separately compiled instantiation of the same column code: FMA contraction may differ in the last bit), larger ones the
                 # very same tile loop
-                if N > 4096 or RD.state_dim(model) + RD.control_dim(model) <= 10:
+                if N > 8192 or RD.state_dim(model) + RD.control_dim(model) <= 10:
                     assert torch.equal(J1, Js[b])
                 else:
                     np.testing.assert_allclose(host(J1), host(Js[b]), rtol=0, atol=1e-13)

@@ -7,11 +7,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "robotdynamics.jl_amd"), os.path.join(R
 import rdhip as RD
 import bench_configs as BC
 rng = np.random.default_rng(2)
-tag = os.environ.get("RDHIP_SMALL", "colsplit")
+tag = os.environ.get("RDHIP_SMALL", "colsplit") + os.environ.get("RDHIP_SMALL_MAX", "")
 def emit(name, N, dt, us, alg, extra=None): print(json.dumps({"mode": tag, "name": name, "N": N, "us": round(us, 2), "frac": round(alg / us / 1e6 / 8, 3)}), flush=True)
 BC.emit = emit
 sat, quad = RD.Satellite(), RD.Quadrotor()
-for N in (101, 512, 1024, 2048, 4096, 8192):
+for N in (101, 512, 1024, 2048, 4096, 8192, 12288, 16384, 32768):
     BC.jac_case("satellite RK4 AD", sat, BC.rigid_inputs(N, 6, rng), RD.RK4, RD.ForwardAD(), np.float64, 300)
 BC.jac_case("quadrotor RK4 AD", quad, BC.rigid_inputs(4096, 4, rng, 0.6, 1.9), RD.RK4, RD.ForwardAD(), np.float64, 300)
 BC.jac_case("satellite RK4 AD fp32", sat, BC.rigid_inputs(4096, 6, rng), RD.RK4, RD.ForwardAD(), np.float32, 300)

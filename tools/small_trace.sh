@@ -1,17 +1,17 @@
+# rocprofv3 kernel durations of single small batches: column-split kernel (RDHIP_SMALL_MAX = workgroups per CU up to which it is used) vs tile loop
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k test_jacobian_multi_fuses 2>&1 | grep -v amdgpu | tail -25
-for m in colsplit tile; do
-out=$R/gpurun_out/small_$m; mkdir -p $out
-(cd /tmp && RDHIP_SMALL=$m rocprofv3 --kernel-trace --stats --output-format csv -d $out -o x -- python $R/tools/small_probe.py > /dev/null 2>&1)
-python - $out/x_kernel_trace.csv $m <<'PY'
+for m in "colsplit 1" "colsplit 2" "colsplit 4" "tile 1"; do
+set -- $m
+out=/tmp/small_$1_$2; mkdir -p $out
+(cd /tmp && RDHIP_SMALL=$1 RDHIP_SMALL_MAX=$2 rocprofv3 --kernel-trace --output-format csv -d $out -o x -- python $R/tools/small_probe.py > /dev/null 2>&1)
+python - $out/x_kernel_trace.csv "$1$2" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "jac_ad" in r["Kernel_Name"]:
-        agg[(r["Kernel_Name"][9:60], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if "jac_ad" in r["Kernel_Name"] and "double, 0" in r["Kernel_Name"] and ">, 3>" in r["Kernel_Name"][:120]:
+        agg[(r["Kernel_Name"][9:31], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, v in sorted(agg.items(), key=lambda kv: kv[0][1]):
     v.sort(); print(sys.argv[2], k, len(v), "median", v[len(v)//2], "min", v[0])
 PY
-find $out -name "*.db" -delete
 done
