@@ -136,6 +136,14 @@ int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_t
  * and assign the columns to the compute waves of the Jacobian kernel by cost instead of in contiguous ranges.  Optional; call it before
  * the first Jacobian (kernels compiled earlier are discarded). */
 int rdhip_model_balance_columns(rdhip_model* model);
+/* Declare the block structure of a custom model's dynamics -- what `Cascade<>` states for the compiled-in rigid bodies (angular velocity | attitude |
+ * position, velocity: src/rigidbody.jl:213-236): state_block[i] in 0 .. nblocks-1 is the block of state component i, and the time derivative of a
+ * block may read blocks 0 .. b only; control_block[j] is the first block whose derivative reads control j.  With a declaration the model gets the
+ * kernels that exploit it: FiniteDifference that re-integrates only what a column can change, rollout! with one wavefront per block, Newton's method
+ * block by block for ImplicitMidpoint.  The declaration is verified on first use on a GPU (the continuous ForwardAD Jacobian at 32 points must have exact
+ * zeros wherever it promises them; RDHIP_ERR_INVALID_ARG with the offending entry otherwise).  2 <= nblocks <= 6, at most 8 state components per block;
+ * nblocks <= 1 removes the declaration.  Kernels compiled before the call are recompiled on next use. */
+int rdhip_model_set_cascade(rdhip_model* model, int nblocks, const int* state_block, const int* control_block);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
  * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT), 12 = fused error-state expansion (LieState models), 13 / 14 / 15 = the register-matrix

@@ -258,6 +258,11 @@ int rdhip_model_balance_columns(rdhip_model* M) {
     const int rc = jit_balance(M->d.jit);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
+int rdhip_model_set_cascade(rdhip_model* M, int nblocks, const int* state_block, const int* control_block) {
+    if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_set_cascade: not a custom model");
+    const int rc = jit_set_cascade(M->d.jit, nblocks, state_block, control_block);
+    return rc ? fail(nullptr, rc, "rdhip_model_set_cascade: %s", jit_last_error(M->d.jit)) : RDHIP_OK;
+}
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
     if (op < 0 || op > 16 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");

@@ -125,6 +125,7 @@ void jit_model_destroy(void* h);
 const char* jit_last_error(void* h);
 int jit_precompile(void* h, int op, int rule, int dtype);
 int jit_balance(void* h);
+int jit_set_cascade(void* h, int nb, const int* state_block, const int* control_block);
 int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a);
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a);
 int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a);

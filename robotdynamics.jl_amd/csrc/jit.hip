@@ -19,6 +19,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -44,6 +45,10 @@ struct JitModel {
     int plan_value_wave = 0;
     int plan_split = 0;                                   // > 0: the leading plan_split columns are the early part of a first tile (TablePlanS)
     std::vector<int> rot_starts;                         // LieState{QuatRotation,P}: state index of every quaternion (empty: EuclideanState or MRP / RP)
+    // declared block structure (jit_set_cascade; models.hpp Cascade<>): state component -> block, control -> first block that reads it
+    int cas_nb = 0;
+    std::vector<int> cas_state, cas_control;
+    bool cas_checked = false;                             // the declaration has been verified against the model's Jacobian pattern (first GPU use)
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
@@ -58,12 +63,21 @@ static std::string rot_start_expr(const JitModel& M) {
 }
 static std::string program_source(const JitModel& M) {
     std::ostringstream s;
-    s << "#include \"implicit.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
+    s << "#include \"implicit.hpp\"\n#include \"cascade.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
       << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
       << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    static constexpr int NROT = " << M.rot_starts.size() << ";\n"
       << "    static constexpr int rot_start(int r) { " << rot_start_expr(M) << " }\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
       // the body sits in an inner block: a body written for the time-invariant signature may declare its own `t`
-      << "    template <class S> RD_DEV void f(const S* x, const S* u, T t, S* xdot) const {\n        (void)t;\n        {\n" << M.body << "\n        }\n    }\n};\n}\n";
+      << "    template <class S> RD_DEV void f(const S* x, const S* u, T t, S* xdot) const {\n        (void)t;\n        {\n" << M.body << "\n        }\n    }\n};\n";
+    if (M.cas_nb > 1) {            // the declared block structure: the cascade kernels (FiniteDifference, rollout, Newton) pick it up like a compiled-in model's
+        s << "template <class T_> struct Cascade<UserModel<T_> > {\n    static constexpr int NB = " << M.cas_nb << ";\n"
+          << "    static constexpr int block_of(int i) { constexpr int b[" << M.n << "] = {";
+        for (int i = 0; i < M.n; ++i) s << (i ? ", " : "") << M.cas_state[i];
+        s << "}; return b[i]; }\n    static constexpr int control_block(int j) { constexpr int b[" << M.m << "] = {";
+        for (int j = 0; j < M.m; ++j) s << (j ? ", " : "") << M.cas_control[j];
+        s << "}; return b[j]; }\n};\n";
+    }
+    s << "}\n";
     return s.str();
 }
 static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
@@ -113,7 +127,7 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
     const int ng = nz >= 4 ? 4 : nz;
     std::ostringstream plan;
-    if (!M.plan_wave.empty() && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN) && nz > 10) {     // cost-balanced column -> wave table
+    if (!M.plan_wave.empty() && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || (op == JOP_JAC_FD && M.cas_nb > 1 && rule != RDHIP_CONTINUOUS)) && nz > 10) {     // cost-balanced column -> wave table
         if (M.plan_split > 0) plan << "rd::TablePlanS<" << nz << ", 4, " << M.plan_value_wave << ", " << M.plan_split;
         else plan << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
         for (int c = 0; c < nz; ++c) plan << ", " << M.plan_wave[c];
@@ -121,7 +135,10 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     } else plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
     switch (op) {
         case JOP_EVAL: s << "rd::eval_kernel<" << fn.str() << ", " << T << ">"; break;
-        case JOP_ROLLOUT: s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">"; break;
+        case JOP_ROLLOUT:
+            if (M.cas_nb > 1) s << "rd::rollout_cascade_kernel<" << fn.str() << ", " << T << ", rd::Cascade<rd::UserModel<" << T << "> >, 4>";
+            else s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">";
+            break;
         case JOP_JAC_AD:       // small models: all columns per lane; larger ones: the split-role kernel with compile-time columns
             if (nz <= 10) s << "rd::jac_ad_small_kernel<" << fn.str() << ", " << T << ">";
             else s << "rd::jac_ad_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
@@ -129,6 +146,7 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
         case JOP_JAC_AD_LOOP: s << "rd::jac_ad_loop_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
         case JOP_JAC_FD:
             if (nz <= 10) s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">";
+            else if (M.cas_nb > 1 && rule != RDHIP_CONTINUOUS) s << "rd::jac_fd_cascade_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", rd::Cascade<rd::UserModel<" << T << "> >, 4>";
             else s << "rd::jac_fd_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
             break;
         case JOP_JAC_FD_LOOP: s << "rd::jac_fd_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
@@ -232,6 +250,13 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD || op == JOP_IMPLICIT_IFT);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
+        else if (op == JOP_ROLLOUT && M.cas_nb > 1) {          // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp), one wavefront per block + the IO wavefront
+            const int ns = rule == RDHIP_EULER ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4, R = 4, S = 4;
+            int npub = 0; for (int i = 0; i < M.n; ++i) npub += M.cas_state[i] < M.cas_nb - 1 ? 1 : 0;
+            const size_t ring_slot = (size_t)ns * npub * 64, in_elems = (size_t)S * 64 * (M.m | 1), out_elems = (size_t)S * 64 * (M.n | 1), ts_elems = (size_t)2 * S * 64;
+            const size_t in_off = a16(R * ring_slot * ts), ts_off = in_off + a16(2 * in_elems * ts), out_off = ts_off + 2 * ts_elems * 8, flag_off = out_off + a16(2 * out_elems * ts);
+            jk.block = (M.cas_nb + 1) * 64; jk.lds = flag_off + 64;
+        }
         else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op != JOP_IMPLICIT_IFT)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
@@ -255,6 +280,37 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         it = M.loaded.emplace(kd.str(), jk).first;
     }
     *out = &it->second;
+    return RDHIP_OK;
+}
+
+// kernels compiled for an earlier plan / block structure are stale.  They are not unloaded: jit_get hands out JitKernel pointers that are launched
+// after the model lock is released (e.g. by the host threads of rdhip_jacobian_sharded); the entries move to a retired key and their modules are
+// unloaded with the model.  Caller holds M.mu.
+static void retire_compiled(JitModel& M) {
+    ++M.generation;
+    std::vector<std::string> keys;
+    for (auto& kv : M.loaded) if (kv.first.compare(0, 7, "retired") != 0) keys.push_back(kv.first);
+    for (const std::string& k : keys) {          // re-key the map NODE (extract / insert keeps the JitKernel at its address)
+        auto nh = M.loaded.extract(k);
+        nh.key() = "retired" + std::to_string(M.generation) + ":" + k;
+        M.loaded.insert(std::move(nh));
+    }
+    M.code.clear(); M.lowered.clear();
+}
+
+// Declare the block structure of a custom model (models.hpp Cascade<>): block b's derivative reads blocks 0..b and the controls whose
+// control_block is <= b.  nb <= 1 removes the declaration.  The declaration is VERIFIED against the model on first GPU use (jit_verify_cascade).
+int jit_set_cascade(void* h, int nb, const int* state_block, const int* control_block) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    std::lock_guard<std::mutex> g(M.mu);
+    if (nb <= 1) { M.cas_nb = 0; M.cas_state.clear(); M.cas_control.clear(); M.cas_checked = false; retire_compiled(M); return RDHIP_OK; }
+    if (nb > 6 || !state_block || !control_block) { M.err = "cascade: 2..6 blocks, non-NULL tables"; return RDHIP_ERR_INVALID_ARG; }
+    std::vector<int> cnt(nb, 0);
+    for (int i = 0; i < M.n; ++i) { if (state_block[i] < 0 || state_block[i] >= nb) { M.err = "cascade: state block index out of range"; return RDHIP_ERR_INVALID_ARG; } ++cnt[state_block[i]]; }
+    for (int j = 0; j < M.m; ++j) if (control_block[j] < 0 || control_block[j] >= nb) { M.err = "cascade: control block index out of range"; return RDHIP_ERR_INVALID_ARG; }
+    for (int b = 0; b < nb; ++b) if (cnt[b] == 0 || cnt[b] > 8) { M.err = "cascade: every block needs 1..8 state components"; return RDHIP_ERR_INVALID_ARG; }
+    M.cas_nb = nb; M.cas_state.assign(state_block, state_block + M.n); M.cas_control.assign(control_block, control_block + M.m); M.cas_checked = false;
+    retire_compiled(M);
     return RDHIP_OK;
 }
 
@@ -300,18 +356,7 @@ int jit_balance(void* h) {
         }
     int vw = 0; for (int i = 1; i < 4; ++i) if (load[i] < load[vw]) vw = i;
     M.plan_value_wave = vw;
-    // kernels compiled with the old plan are stale
-    // (not unloaded here: jit_get hands out JitKernel pointers that are launched after the model lock is released, e.g. by the host threads
-    // of rdhip_jacobian_sharded; the stale entries are kept under a retired key and their modules are unloaded with the model)
-    ++M.generation;
-    std::vector<std::string> keys;
-    for (auto& kv : M.loaded) if (kv.first.compare(0, 7, "retired") != 0) keys.push_back(kv.first);
-    for (const std::string& k : keys) {          // re-key the map NODE (extract / insert keeps the JitKernel at its address)
-        auto nh = M.loaded.extract(k);
-        nh.key() = "retired" + std::to_string(M.generation) + ":" + k;
-        M.loaded.insert(std::move(nh));
-    }
-    M.code.clear(); M.lowered.clear();
+    retire_compiled(M);
     return RDHIP_OK;
 }
 
@@ -355,9 +400,49 @@ int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a) {
     void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y};
     return launch(M, k, (unsigned)((N + 255) / 256), a.stream, args);
 }
+// A declared block structure is only a promise; the cascade kernels produce wrong numbers if it is false.  Before its first use on a GPU the
+// continuous ForwardAD Jacobian is evaluated at 32 points and every entry that the declaration says is structurally zero -- a row of block a
+// against a state column of a block > a, or against a control whose control_block is > a -- must be exactly zero (tangents propagate exact
+// zeros; non-finite entries are skipped).
+static int jit_verify_cascade(JitModel& M, hipStream_t stream) {
+    if (M.cas_nb <= 1 || M.cas_checked) return RDHIP_OK;
+    M.cas_checked = true;                                  // (the check itself goes through jit_jacobian)
+    const int n = M.n, m = M.m, nz = n + m, NP = 32;
+    std::vector<double> Z((size_t)NP * nz), t(NP, 0.3), dt(NP, 0.1), J((size_t)NP * n * nz);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (double& v : Z) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = 0.1 + 0.8 * (double)(st >> 11) / 9007199254740992.0; }
+    void *dZ = nullptr, *dT = nullptr, *dD = nullptr, *dJ = nullptr;
+    int rc = RDHIP_ERR_HIP;
+    if (hipMalloc(&dZ, Z.size() * 8) == hipSuccess && hipMalloc(&dT, NP * 8) == hipSuccess && hipMalloc(&dD, NP * 8) == hipSuccess && hipMalloc(&dJ, J.size() * 8) == hipSuccess &&
+        hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dT, t.data(), NP * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dD, dt.data(), NP * 8, hipMemcpyHostToDevice) == hipSuccess) {
+        LaunchArgs a{}; a.stream = stream; a.N = NP; a.Z = dZ; a.t = (const double*)dT; a.dt = (const double*)dD; a.J = dJ;
+        rc = jit_jacobian(&M, RDHIP_CONTINUOUS, RDHIP_FORWARD_AD, RDHIP_F64, a);
+        if (rc == RDHIP_OK && (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(J.data(), dJ, J.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = RDHIP_ERR_HIP;
+    } else M.err = "cascade check: device allocation failed";
+    (void)hipFree(dZ); (void)hipFree(dT); (void)hipFree(dD); (void)hipFree(dJ);
+    if (rc) { M.cas_checked = false; return rc; }
+    for (int k = 0; k < NP; ++k)
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < nz; ++c) {
+                const int col_block = c < n ? M.cas_state[c] : M.cas_control[c - n];
+                const double v = J[((size_t)k * nz + c) * n + i];
+                unsigned long long bits; std::memcpy(&bits, &v, 8);
+                const bool finite = ((bits >> 52) & 0x7ff) != 0x7ff;          // (tested on the bit pattern: the build uses -ffinite-math-only)
+                if (M.cas_state[i] < col_block && finite && (bits << 1) != 0) {
+                    char msg[256];
+                    snprintf(msg, sizeof msg, "the declared cascade is not one: d xdot[%d] / d %s[%d] = %g, but xdot[%d] is in block %d and that %s in block %d",
+                             i, c < n ? "x" : "u", c < n ? c : c - n, v, i, M.cas_state[i], c < n ? "state" : "control enters", col_block);
+                    M.err = msg; M.cas_checked = false;
+                    return RDHIP_ERR_INVALID_ARG;
+                }
+            }
+    return RDHIP_OK;
+}
 int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
+    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
     JitKernel* k; int rc = jit_get(M, JOP_ROLLOUT, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long K = a.K, Mt = a.N, sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
@@ -368,6 +453,7 @@ int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
     if (a.N == 0) return RDHIP_OK;
+    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
     int op = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.J) | reinterpret_cast<uintptr_t>(a.Y)) & 15) == 0;
     if (M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);   // the split-role kernels copy 16-B units
@@ -399,6 +485,7 @@ int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a) {
 int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
     if (a.N == 0) return RDHIP_OK;
+    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
     const int op = mode == 0 ? JOP_IMPLICIT_X : mode == 1 ? JOP_IMPLICIT_J : mode == 2 ? JOP_IMPLICIT_ERR : JOP_IMPLICIT_ROLLOUT;
     JitKernel* k; int rc = jit_get(M, op, RDHIP_IMPLICIT_MIDPOINT, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);

@@ -453,6 +453,20 @@ RobotDynamics.dynamics(model::AnyCustom, x, u, t) = model.f(x, u, t)
 RobotDynamics.dynamics(model::AnyCustom, x, u) = model.f(x, u, 0.0)
 "Cost-balance the Jacobian columns of a custom model with n+m > 10 over the compute waves (rdhip_model_balance_columns); call before the first Jacobian."
 balance_columns!(model::AnyCustom) = (check(nothing, ccall((:rdhip_model_balance_columns, librdhip), Cint, (Ptr{Cvoid},), handle(model))); model)
+"""
+    set_cascade!(model, state_block, control_block)
+
+Declare the block structure of a custom model's dynamics (0-based block numbers; what the compiled-in rigid bodies state as ω | q | r, v,
+`src/rigidbody.jl:213-236`): the time derivative of block `b` reads blocks `0:b` only, `control_block[j]` is the first block whose derivative reads
+control `j`.  The model then gets the kernels that exploit it (FiniteDifference along the cascade, `rollout!` with one wavefront per block,
+block-by-block Newton for `ImplicitMidpoint`); the declaration is verified against the Jacobian pattern on first GPU use.
+"""
+function set_cascade!(model::AnyCustom, state_block::AbstractVector{<:Integer}, control_block::AbstractVector{<:Integer})
+    sb = Vector{Cint}(state_block); cb = Vector{Cint}(control_block)
+    nb = Cint(max(maximum(sb; init=0), maximum(cb; init=0)) + 1)
+    check(nothing, ccall((:rdhip_model_set_cascade, librdhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Cint}), handle(model), nb, sb, cb))
+    return model
+end
 "JIT-compile one kernel of a custom model now (works without a GPU): `op` as in rdhip_model_precompile."
 precompile_kernel(model::AnyCustom, op::Integer, rule::Integer, ::Type{T}=Float64) where {T} =
     check(nothing, ccall((:rdhip_model_precompile, librdhip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), handle(model), op, rule, dtypecode(T)))

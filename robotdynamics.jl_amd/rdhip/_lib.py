@@ -64,6 +64,7 @@ _SIGS = {
     "rdhip_model_precompile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "rdhip_model_set_newton": (C.c_int, [_P, C.c_int, C.c_double]),
     "rdhip_model_balance_columns": (C.c_int, [_P]),
+    "rdhip_model_set_cascade": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rdhip_model_dims": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
     "rdhip_model_statevectortype": (C.c_int, [_P, _IP]),
     "rdhip_model_liestate": (C.c_int, [_P, _IP, _IP, _IP]),

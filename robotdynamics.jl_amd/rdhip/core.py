@@ -674,6 +674,20 @@ class CustomModel(ContinuousDynamics):
         L.check(L.lib().rdhip_model_balance_columns(self._handle))
         return self
 
+    def set_cascade(self, state_block, control_block):
+        """Declare the block structure of the dynamics (what the compiled-in rigid bodies state as w | q | r, v, src/rigidbody.jl:213-236): the time
+        derivative of block b reads blocks 0..b only; control_block[j] = the first block whose derivative reads control j.  The model then gets
+        the kernels that exploit it (FiniteDifference along the cascade, rollout_ with one wavefront per block, block-by-block Newton for
+        ImplicitMidpoint); the declaration is verified against the Jacobian pattern on first GPU use (ValueError names the offending entry)."""
+        sb = np.ascontiguousarray(np.asarray(state_block, dtype=np.int32).ravel())
+        cb = np.ascontiguousarray(np.asarray(control_block, dtype=np.int32).ravel())
+        if sb.size != self.n or cb.size != self.m:
+            raise ValueError(f"set_cascade: need {self.n} state blocks and {self.m} control blocks")
+        nb = int(max(sb.max(initial=0), cb.max(initial=0))) + 1
+        L.check(L.lib().rdhip_model_set_cascade(self._handle, nb, sb.ctypes.data_as(C.POINTER(C.c_int)), cb.ctypes.data_as(C.POINTER(C.c_int))))
+        self.cascade = (tuple(int(v) for v in sb), tuple(int(v) for v in cb))
+        return self
+
     def precompile(self, what="ForwardAD", rule=RK4, dtype=np.float64):
         """JIT-compile one kernel now (works without a GPU); raises ValueError with the compiler log if the source does not compile."""
         code = L.CONTINUOUS if rule is None else _rule_code(rule() if isinstance(rule, type) else rule)

@@ -1405,6 +1405,57 @@ def test_three_parameter_rigid_bodies_rollout_implicit_midpoint_and_finite_diffe
             np.testing.assert_allclose(host(J32), Jo32, rtol=1e-4, atol=1e-4)
 
 
+def test_custom_model_with_a_declared_cascade_gets_the_cascade_kernels():
+    """rdhip_model_set_cascade: a custom rigid body (the satellite as a source string) that declares w | q | r, v runs FiniteDifference along the
+    cascade, rollout! with one wavefront per block and the block-by-block Newton solve -- same answers as the oracle and as the undeclared model;
+    upstream blocks of the FiniteDifference columns are exact zeros; a false declaration is refused with the offending entry named."""
+    rng = np.random.default_rng(71)
+    mk = lambda: RD.CustomModel(13, 6, H.SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
+    plain, model = mk(), mk()
+    model.set_cascade([2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [2, 2, 2, 0, 0, 0])
+    om = O.body()
+    N = 64 * 3 + 17
+    Zn = H.rand_rigid(rng, N, 6)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1); dt[-1] = 0.0; dt[70] = 0.0
+    Z = traj(model, Zn, t, dt, "cuda")
+    for Q, rule in ((RD.RK4, O.RK4), (RD.RK2, O.RK2)):
+        dm, dp = RD.DiscretizedDynamics(model, Q), RD.DiscretizedDynamics(plain, Q)
+        J = RD.alloc_jacobians(dm, N, Z.data); Jp = RD.alloc_jacobians(dp, N, Z.data)
+        Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+        RD.jacobian_(RD.StaticReturn(), RD.FiniteDifference(), dm, J, Y, Z)
+        RD.jacobian_(RD.StaticReturn(), RD.FiniteDifference(), dp, Jp, None, Z)
+        Jex, Yo = om.jacobian(rule, O.FORWARD_AD, Zn, t, dt)
+        np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(J), Jex, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(J), host(Jp), rtol=0, atol=4e-7)          # two evaluation orders of the same differences, divided by eps
+        Jg = host(J)
+        assert np.all(Jg[:, 3:7, 0:3] == 0.0) and np.all(Jg[:, 10:13, 0:3] == 0.0) and np.all(Jg[:, 10:13, 3:7] == 0.0) and np.all(Jg[-1][:, 13:] == 0.0)
+    # rollout!: the cascade kernel (64 x K chunks through the IO wavefront, a ragged group, a short trajectory)
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    for M, K in ((130, 9), (64, 26), (5, 3)):
+        data = H.rand_rigid(rng, M * K, 6).reshape(M, K, 19)
+        tt = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy(); dd = np.full((M, K), 0.05)
+        ref = om.rollout(O.RK4, data, tt, dd)
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+        RD.rollout_(RD.StaticReturn(), dm, stack)
+        np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
+    # ImplicitMidpoint: block-by-block Newton + the IFT tile kernel
+    dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+    J = RD.alloc_jacobians(dmi, N, Z.data)
+    Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, J, Y, Z)
+    Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
+    np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+    # a false promise: the attitude placed UPSTREAM of the angular velocity it depends on
+    liar = mk()
+    liar.set_cascade([2, 2, 2, 0, 0, 0, 0, 2, 2, 2, 1, 1, 1], [2, 2, 2, 1, 1, 1])
+    with pytest.raises(ValueError, match="declared cascade is not one"):
+        RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(liar, RD.RK4), {"data": torch.as_tensor(H.rand_rigid(rng, 64 * 5, 6).reshape(64, 5, 19)).cuda(),
+                                                                                 "t": torch.zeros((64, 5), dtype=torch.float64, device="cuda"),
+                                                                                 "dt": torch.full((64, 5), 0.1, dtype=torch.float64, device="cuda")})
+
+
 def test_single_knot_point_api_reads_like_the_reference():
     # examples/cartpole.jl:41-57 restated with v0.4 calls (SURVEY App. B)
     model = RD.Cartpole()

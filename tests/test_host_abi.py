@@ -257,6 +257,14 @@ def test_custom_model_jit_compiles_without_a_gpu():
     tvs.precompile("ForwardAD", RD.RK4)
     tvs.precompile("error_expansion", RD.RK4)
     tvs.precompile("implicit_jacobian", RD.ImplicitMidpoint)                     # the IFT Jacobian as a split-role tile kernel (n + m > 10)
+    # a declared block structure (rdhip_model_set_cascade): the cascade forms of FiniteDifference, rollout and the Newton solve compile without a GPU
+    tvs.set_cascade([2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [2, 2, 2, 0, 0, 0])      # w | q | r, v ; thrust enters r, v ; torque enters w
+    tvs.precompile("FiniteDifference", RD.RK4)
+    tvs.precompile("rollout", RD.RK3, np.float32)
+    tvs.precompile("implicit_solve", RD.ImplicitMidpoint)
+    for bad in (([0] * 12, [0] * 6), ([0] * 13, [7] * 6), ([0, 0, 0, 2, 2, 2, 2, 0, 0, 0, 0, 0, 0], [0] * 6)):     # wrong length / block out of range / empty block 1
+        with pytest.raises(ValueError):
+            tvs.set_cascade(*bad)
     RD.CustomModel(2, 1, "const T t = p[0]; xdot[0] = x[1] * t; xdot[1] = u[0];", params=(2.0,)).precompile("evaluate", RD.RK4)
     with pytest.raises(NotImplementedError):                                      # LieDesc tables hold 4 rotations
         RD.dims(RD.CustomModel(16, 1, "xdot[0] = u[0];", liestate=(RD.MRP, (0, 0, 0, 0, 0, 1))))
