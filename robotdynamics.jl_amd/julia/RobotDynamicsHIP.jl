@@ -467,6 +467,47 @@ function set_cascade!(model::AnyCustom, state_block::AbstractVector{<:Integer}, 
     check(nothing, ccall((:rdhip_model_set_cascade, librdhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Cint}), handle(model), nb, sb, cb))
     return model
 end
+"""
+    rigid_body_source(forces_src, moments_src; bodyframe=false)
+
+HIP body of `dynamics(model::RigidBody{QuatRotation}, x, u, t)` (`src/rigidbody.jl:213-236`) around user wrenches: `forces_src` fills `F[0..2]` (world
+frame), `moments_src` fills `tau[0..2]` (body frame) -- the reference's `forces` / `moments` methods (`src/rigidbody.jl:244-258`) as HIP source; both may
+read `q`, `r`, `v`, `w`, `x`, `u`, `t` and the user parameters `P[i]`.  Parameters of the generated model: mass, inertia (9), its inverse (9), then `P`.
+"""
+function rigid_body_source(forces_src::AbstractString, moments_src::AbstractString; bodyframe::Bool=false)
+    lin = bodyframe ?
+        "quat_rotate(q, v, xdot);\n    { S Fm[3] = {F[0] * im, F[1] * im, F[2] * im}; S a[3]; quat_rotate_inv(q, Fm, a); S cv[3]; cross3(w, v, cv);\n      for (int i = 0; i < 3; ++i) xdot[7 + i] = a[i] - cv[i]; }" :
+        "for (int i = 0; i < 3; ++i) { xdot[i] = v[i]; xdot[7 + i] = F[i] * im; }"
+    return """
+    const S* r = x; const S* q = x + 3; const S* v = x + 7; const S* w = x + 10; const T* P = p + 19;
+    (void)r; (void)P;
+    S F[3], tau[3];
+    { $forces_src }
+    { $moments_src }
+    quat_kinematics(q, w, xdot + 3);
+    const T im = T(1) / p[0];
+    $lin
+    S Jw[3]; mat3vec(p + 1, w, Jw);
+    S c[3]; cross3(w, Jw, c);
+    const S tt[3] = {tau[0] - c[0], tau[1] - c[1], tau[2] - c[2]};
+    mat3vec(p + 10, tt, xdot + 10);
+"""
+end
+"""
+    CustomRigidBody(m, f, forces_src, moments_src; mass=1.0, J=I, params=Float64[], bodyframe=false, cascade=true, force_only_controls=Int[])
+
+A user-defined `RigidBody{QuatRotation}` for the GPU -- what `struct MyBody <: RigidBody{R}` with `forces` / `moments` methods is in the reference -- as a
+`CustomLieModel` with `LieState{QuatRotation,(3,6)}`; `f(x, u, t)` is the Julia `dynamics` for per-knot CPU calls.  `cascade=true` declares the block
+structure ω | q | r, v (`set_cascade!`; valid when the moments read neither q nor r, v and the forces neither r nor v; verified on first GPU use).
+"""
+function CustomRigidBody(m::Integer, f, forces_src::AbstractString, moments_src::AbstractString; mass=1.0, J=SMatrix{3,3,Float64}(I), params=Float64[],
+                         bodyframe::Bool=false, preamble::AbstractString="", cascade::Bool=true, force_only_controls=Int[])
+    Js = SMatrix{3,3,Float64,9}(J)
+    p = Float64[mass; _inertia9(Js); _inertia9(inv(Js)); collect(Float64, params)]
+    model = CustomLieModel(QuatRotation{Float64}, (3, 6), m, f, rigid_body_source(forces_src, moments_src; bodyframe=bodyframe); params=p, preamble=preamble)
+    cascade && set_cascade!(model, [2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [(j in force_only_controls) ? 2 : 0 for j in 0:m-1])
+    return model
+end
 "JIT-compile one kernel of a custom model now (works without a GPU): `op` as in rdhip_model_precompile."
 precompile_kernel(model::AnyCustom, op::Integer, rule::Integer, ::Type{T}=Float64) where {T} =
     check(nothing, ccall((:rdhip_model_precompile, librdhip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), handle(model), op, rule, dtypecode(T)))

@@ -698,6 +698,46 @@ class LieGroupModel(ContinuousDynamics):
     pass
 
 
+def rigid_body_source(forces, moments, bodyframe=False):
+    """The HIP body of `dynamics(model::RigidBody{QuatRotation}, x, u, t)` (src/rigidbody.jl:213-236) around user wrenches -- the reference's
+    extension points `forces(model, x, u)` (world frame) and `moments(model, x, u)` (body frame), src/rigidbody.jl:244-258, given as code that fills
+    `F[0..2]` / `tau[0..2]` and may read `q` (the attitude quaternion, 4 values), `r`, `v`, `w`, `x`, `u`, `t` and the user parameters `P[i]`
+    (= p[19 + i]).  Parameter layout of the generated model: p[0] = mass, p[1..9] = inertia (column-major), p[10..18] = its inverse."""
+    lin = ("for (int i = 0; i < 3; ++i) { xdot[i] = v[i]; xdot[7 + i] = F[i] * im; }" if not bodyframe else
+           "quat_rotate(q, v, xdot);\n    { S Fm[3] = {F[0] * im, F[1] * im, F[2] * im}; S a[3]; quat_rotate_inv(q, Fm, a); S cv[3]; cross3(w, v, cv);\n"
+           "      for (int i = 0; i < 3; ++i) xdot[7 + i] = a[i] - cv[i]; }")
+    return f"""
+    const S* r = x; const S* q = x + 3; const S* v = x + 7; const S* w = x + 10; const T* P = p + 19;
+    (void)r; (void)P;
+    S F[3], tau[3];
+    {{ {forces} }}
+    {{ {moments} }}
+    quat_kinematics(q, w, xdot + 3);
+    const T im = T(1) / p[0];
+    {lin}
+    S Jw[3]; mat3vec(p + 1, w, Jw);
+    S c[3]; cross3(w, Jw, c);
+    const S tt[3] = {{tau[0] - c[0], tau[1] - c[1], tau[2] - c[2]}};
+    mat3vec(p + 10, tt, xdot + 10);
+"""
+
+
+def CustomRigidBody(m, forces, moments, mass=1.0, J=None, params=(), bodyframe=False, preamble="", cascade=True, force_only_controls=()):
+    """A user-defined RigidBody{QuatRotation} for the GPU: what `struct MyBody <: RigidBody{R}` + `forces` / `moments` methods are in the reference
+    (src/rigidbody.jl:244-258; examples/single_satellite.jl:18-27), with the wrenches given as HIP source (see rigid_body_source).  `m` controls,
+    LieState{QuatRotation,(3,6)}.  cascade=True declares the block structure w | q | r, v (valid when the moments read neither q nor r, v and the
+    forces read neither r nor v, as for the reference's satellite and quadrotor; verified on first GPU use -- pass cascade=False otherwise);
+    `force_only_controls`: controls that enter the forces only (they then belong to the r, v block)."""
+    Jm = np.eye(3) if J is None else np.asarray(J, dtype=np.float64)
+    p = np.concatenate([[float(mass)], Jm.flatten(order="F"), np.linalg.inv(Jm).flatten(order="F"), np.asarray(params, dtype=np.float64).ravel()])
+    model = CustomModel(13, int(m), rigid_body_source(forces, moments, bodyframe), params=p, preamble=preamble, liestate=(QuatRotation, (3, 6)))
+    model.velocity_frame = "body" if bodyframe else "world"
+    if cascade:
+        fo = {int(j) for j in force_only_controls}
+        model.set_cascade([2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [2 if j in fo else 0 for j in range(int(m))])
+    return model
+
+
 class Cartpole(ContinuousDynamics):          # examples/cartpole.jl:5-12 ; test/cartpole_model.jl:2-9
     _kind = L.MODEL_CARTPOLE
 

@@ -1456,6 +1456,49 @@ def test_custom_model_with_a_declared_cascade_gets_the_cascade_kernels():
                                                                                  "dt": torch.full((64, 5), 0.1, dtype=torch.float64, device="cuda")})
 
 
+def test_custom_rigid_body_from_forces_and_moments_source():
+    """RD.CustomRigidBody: the reference's way of defining a rigid body -- `forces` and `moments` methods on a RigidBody subtype (src/rigidbody.jl:244-258;
+    test/quadrotor.jl:56-96) -- with the two wrench functions given as HIP source.  The quadrotor written that way must reproduce the compiled-in
+    quadrotor's oracle in both velocity frames for dynamics, every diff method, rollout!, ImplicitMidpoint and the error-state operators."""
+    rng = np.random.default_rng(73)
+    forces = """const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
+                const S fb[3] = {S(T(0)), S(T(0)), F1 + F2 + F3 + F4}; S qF[3]; quat_rotate(q, fb, qF);
+                for (int i = 0; i < 3; ++i) F[i] = qF[i] + p[0] * P[i];"""
+    moments = """const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
+                 tau[0] = (F2 - F4) * P[3]; tau[1] = (F3 - F1) * P[3]; tau[2] = (u[0] - u[1] + u[2] - u[3]) * P[5];"""
+    for body in (False, True):
+        model = RD.CustomRigidBody(4, forces, moments, mass=0.5, J=np.diag([0.0023, 0.0023, 0.004]), params=(0.0, 0.0, -9.81, 0.1750, 1.0, 0.0245), bodyframe=body)
+        om = O.quadrotor(O.FRAME_BODY if body else O.FRAME_WORLD)
+        assert RD.dims(model)[:2] == (13, 4) and RD.errstate_dim(model) == 12
+        N = 64 * 2 + 9
+        Zn = H.rand_rigid(rng, N, 4, 0.6, 1.9); Zn[3, 13] = -0.2                      # one negative rotor command: max(0, kf u)
+        t, dt = np.arange(N) * 0.1, np.full(N, 0.1); dt[-1] = 0.0
+        Z = traj(model, Zn, t, dt, "cuda")
+        np.testing.assert_allclose(host(RD.dynamics(model, Z)), om.dynamics(Zn, t, dt), rtol=0, atol=TOL)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        J = RD.alloc_jacobians(dm, N, Z.data)
+        Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+        Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+        for diff, tol in ((RD.ForwardAD(), TOL), (RD.UserDefined(), TOL), (RD.FiniteDifference(), 1e-6)):
+            RD.jacobian_(RD.StaticReturn(), diff, dm, J, Y, Z)
+            np.testing.assert_allclose(host(J), Jo, rtol=0, atol=tol * max(1.0, np.abs(Jo).max()))
+            np.testing.assert_allclose(host(Y), Yo, rtol=0, atol=TOL)
+        M, K = 70, 11
+        data = H.rand_rigid(rng, M * K, 4, 0.6, 1.9).reshape(M, K, 17)
+        tt = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy(); dd = np.full((M, K), 0.05)
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+        RD.rollout_(RD.StaticReturn(), dm, stack)
+        np.testing.assert_allclose(host(stack["data"]), om.rollout(O.RK4, data, tt, dd), rtol=0, atol=TOL)
+        dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+        RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, J, Y, Z)
+        Xo, Jio, _ = om.implicit_midpoint(Zn, t, dt)
+        np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(J), Jio, rtol=0, atol=TOL * max(1.0, np.abs(Jio).max()))
+        G = RD.alloc_errstate_jacobians(model, N, Z.data)
+        RD.errstate_jacobian_(model, G, Z, clear=True)
+        np.testing.assert_allclose(host(G), om.errstate_jacobian(Zn[:, :13]), rtol=0, atol=TOL)
+
+
 def test_single_knot_point_api_reads_like_the_reference():
     # examples/cartpole.jl:41-57 restated with v0.4 calls (SURVEY App. B)
     model = RD.Cartpole()

@@ -262,6 +262,12 @@ def test_custom_model_jit_compiles_without_a_gpu():
     tvs.precompile("FiniteDifference", RD.RK4)
     tvs.precompile("rollout", RD.RK3, np.float32)
     tvs.precompile("implicit_solve", RD.ImplicitMidpoint)
+    # a rigid body defined the reference's way -- `forces` and `moments` (src/rigidbody.jl:244-258) -- as two snippets of HIP source
+    crb = RD.CustomRigidBody(6, "quat_rotate(q, u, F);", "tau[0] = u[3]; tau[1] = u[4]; tau[2] = u[5] * P[0];", mass=2.0, J=np.diag([2.0, 3.0, 1.0]), params=(1.0,),
+                             bodyframe=True, force_only_controls=(0, 1, 2))
+    assert RD.dims(crb)[:2] == (13, 6) and RD.errstate_dim(crb) == 12 and crb.cascade[1] == (2, 2, 2, 0, 0, 0)
+    crb.precompile("ForwardAD", RD.RK4)
+    crb.precompile("rollout", RD.RK4)
     for bad in (([0] * 12, [0] * 6), ([0] * 13, [7] * 6), ([0, 0, 0, 2, 2, 2, 2, 0, 0, 0, 0, 0, 0], [0] * 6)):     # wrong length / block out of range / empty block 1
         with pytest.raises(ValueError):
             tvs.set_cascade(*bad)
