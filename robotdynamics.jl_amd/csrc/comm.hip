@@ -90,6 +90,10 @@ struct rdhip_comm {
     std::vector<ncclComm_t> nccl;       // its RCCL communicator; empty when nranks == 1 (nothing to talk to: librccl is not even loaded)
 };
 
+// RDHIP_COMM_FORCE_RCCL=1: a 1-rank communicator goes through librccl as well (ncclCommInit*, a 1-rank ncclAllGather, a grouped ncclSend / ncclRecv to
+// itself) instead of degenerating to a local copy: the only way to execute the RCCL calls of this file on a 1-GPU test box
+static bool force_rccl() { const char* e = getenv("RDHIP_COMM_FORCE_RCCL"); return e && e[0] == '1'; }
+
 extern "C" {
 
 int rdhip_comm_unique_id(char id[RDHIP_COMM_ID_BYTES]) {
@@ -119,7 +123,7 @@ int rdhip_comm_create(rdhip_ctx* const* ctxs, int n, rdhip_comm** out) {
     C->nranks = C->nlocal = n;
     C->rank.resize(n); C->ctx.assign(ctxs, ctxs + n);
     for (int i = 0; i < n; ++i) C->rank[i] = i;
-    if (n > 1) {
+    if (n > 1 || force_rccl()) {
         Rccl* R = rccl();
         if (!R->so) { delete C; return cfail(ctxs[0], RDHIP_ERR_UNSUPPORTED, "rdhip_comm_create: %s", R->err.c_str()); }
         C->nccl.resize(n);
@@ -134,11 +138,12 @@ int rdhip_comm_create_rank(rdhip_ctx* ctx, int nranks, int rank, const char id[R
     if (!out) return cfail(ctx, RDHIP_ERR_INVALID_ARG, "rdhip_comm_create_rank: out is NULL");
     *out = nullptr;
     if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return cfail(ctx, RDHIP_ERR_INVALID_ARG, "rdhip_comm_create_rank: bad arguments (nranks %d, rank %d)", nranks, rank);
+    const bool with_rccl = nranks > 1 || (force_rccl() && id);
     if (nranks > 1 && !id) return cfail(ctx, RDHIP_ERR_INVALID_ARG, "rdhip_comm_create_rank: id is NULL");
     rdhip_comm* C = new (std::nothrow) rdhip_comm();
     if (!C) return cfail(ctx, RDHIP_ERR_HIP, "out of host memory");
     C->nranks = nranks; C->nlocal = 1; C->rank.assign(1, rank); C->ctx.assign(1, ctx);
-    if (nranks > 1) {
+    if (with_rccl) {
         Rccl* R = rccl();
         if (!R->so) { delete C; return cfail(ctx, RDHIP_ERR_UNSUPPORTED, "rdhip_comm_create_rank: %s", R->err.c_str()); }
         if (hipSetDevice(rdhip_ctx_device_(ctx)) != hipSuccess) { delete C; return cfail(ctx, RDHIP_ERR_HIP, "hipSetDevice failed"); }
@@ -180,6 +185,7 @@ int rdhip_gather(rdhip_comm* C, int mode, int root, const void* const* shard, co
     if (mode == RDHIP_GATHER_ROOT && (root < 0 || root >= C->nranks)) return cfail(c0, RDHIP_ERR_INVALID_ARG, "rdhip_gather: root %d out of range [0,%d)", root, C->nranks);
     if (!shard || !bytes || !out) return cfail(c0, RDHIP_ERR_INVALID_ARG, "rdhip_gather: NULL table");
     const int P = C->nranks;
+    const bool use_rccl = !C->nccl.empty();
     std::vector<unsigned long long> off(P + 1, 0);
     for (int r = 0; r < P; ++r) off[r + 1] = off[r] + bytes[r];
     bool equal = true;
@@ -195,14 +201,15 @@ int rdhip_gather(rdhip_comm* C, int mode, int root, const void* const* shard, co
         const int r = C->rank[l];
         const bool receives = mode == RDHIP_GATHER_ALL || r == root;
         if (!receives || bytes[r] == 0) continue;
-        if (P > 1 && mode == RDHIP_GATHER_ALL && equal) continue;                       // ncclAllGather places it
+        if (use_rccl && mode == RDHIP_GATHER_ALL && equal) continue;                    // ncclAllGather places it
+        if (use_rccl && P == 1) continue;                                               // (forced 1-rank RCCL: sent to itself below)
         char* dst = static_cast<char*>(out[l]) + off[r];
         if (dst == shard[l]) continue;                                                  // computed in place inside the stack
         if (hipSetDevice(rdhip_ctx_device_(C->ctx[l])) != hipSuccess ||
             hipMemcpyAsync(dst, shard[l], bytes[r], hipMemcpyDeviceToDevice, (hipStream_t)rdhip_ctx_stream(C->ctx[l])) != hipSuccess)
             return cfail(C->ctx[l], RDHIP_ERR_HIP, "rdhip_gather: local copy failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    if (P == 1) return RDHIP_OK;
+    if (!use_rccl) return RDHIP_OK;
     Rccl* R = rccl();
     ncclResult_t rc = R->GroupStart();
     if (rc != ncclSuccess) return cfail(c0, RDHIP_ERR_HIP, "ncclGroupStart: %s", R->GetErrorString(rc));
@@ -212,6 +219,10 @@ int rdhip_gather(rdhip_comm* C, int mode, int root, const void* const* shard, co
         ncclComm_t comm = C->nccl[l];
         if (mode == RDHIP_GATHER_ALL && equal) {
             if (bytes[0] > 0) rc = R->AllGather(shard[l], out[l], (size_t)bytes[0], ncclChar, comm, s);
+            continue;
+        }
+        if (P == 1) {                                                                   // forced 1-rank RCCL: the shard travels rank 0 -> rank 0
+            if (bytes[0] > 0) { rc = R->Send(shard[l], (size_t)bytes[0], ncclChar, 0, comm, s); if (rc == ncclSuccess) rc = R->Recv(out[l], (size_t)bytes[0], ncclChar, 0, comm, s); }
             continue;
         }
         for (int p = 0; p < P && rc == ncclSuccess; ++p) {

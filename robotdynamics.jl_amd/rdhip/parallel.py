@@ -108,6 +108,8 @@ class Comm:
                 box[0] = ident.raw
             dist.broadcast_object_list(box, src=0, group=group)
             ident = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
+        elif os.environ.get("RDHIP_COMM_FORCE_RCCL") == "1":       # test switch: a 1-rank communicator that really goes through librccl
+            L.check(L.lib().rdhip_comm_unique_id(ident))
         ctx = L.Context(int(device), stream)
         h = C.c_void_p()
         L.check(L.lib().rdhip_comm_create_rank(ctx.handle, world, rank, ident, C.byref(h)), ctx.handle)

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI, via the rdhip host mirror) against the CPU oracle and the
 committed golden vectors.  Tolerances: fp64 max |GPU - oracle| < 1e-10 (BASELINE.json north_star); fp32 is compared
 with the fp64 oracle at rel 1e-4; integer queries are bit-exact (tests/test_host_abi.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
 torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RULES = {"euler": RD.Euler, "rk2": RD.RK2, "rk3": RD.RK3, "rk4": RD.RK4}
 ORULE = {"euler": O.EULER, "rk2": O.RK2, "rk3": O.RK3, "rk4": O.RK4}
@@ -1497,6 +1500,34 @@ def test_custom_rigid_body_from_forces_and_moments_source():
         G = RD.alloc_errstate_jacobians(model, N, Z.data)
         RD.errstate_jacobian_(model, G, Z, clear=True)
         np.testing.assert_allclose(host(G), om.errstate_jacobian(Zn[:, :13]), rtol=0, atol=TOL)
+
+
+def test_native_gather_really_calls_rccl_on_one_gpu():
+    """The RCCL calls of csrc/comm.hip (dlopen of librccl, ncclGetUniqueId, ncclCommInitAll / ncclCommInitRank, ncclAllGather, grouped ncclSend /
+    ncclRecv, ncclCommDestroy) cannot meet a second GPU on the test box; RDHIP_COMM_FORCE_RCCL=1 sends a 1-rank communicator through them anyway
+    (the shard travels rank 0 -> rank 0).  Both ways of building the communicator -- one process driving the devices (a Julia / C host) and one
+    process per GPU with an id (what bench.py --gpus N does) -- in a child process with a time limit: a broken RCCL binding must fail, not hang."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        os.environ["RDHIP_COMM_FORCE_RCCL"] = "1"
+        sys.path[:0] = [%r, %r]
+        import numpy as np, torch
+        import rdhip as RD
+        from rdhip import parallel as P
+        x = torch.arange(1 << 17, dtype=torch.float64, device="cuda:0") * 0.5 + 3.0
+        for make in (lambda: P.Comm.local([0]), lambda: P.Comm.from_torch_distributed(0)):
+            comm = make()
+            for mode in ("all", "root"):
+                out = torch.full_like(x, -1.0)
+                comm.gather(mode, [x], [x.numel() * 8], [out], root=0)
+                comm.synchronize(); torch.cuda.synchronize()
+                assert torch.equal(out, x), mode
+            comm.close()
+        print("RCCL_OK")
+    """) % (ROOT, os.path.join(ROOT, "robotdynamics.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_single_knot_point_api_reads_like_the_reference():
