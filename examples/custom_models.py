@@ -50,3 +50,20 @@ TV_SATELLITE_SRC = """
     S c[3]; cross3(w, Jw, c);
     xdot[10] = (u[3] + p[5] * sin_(wt) - c[0]) / p[1]; xdot[11] = (u[4] + p[5] * cos_(wt) - c[1]) / p[2]; xdot[12] = (u[5] + p[5] * sin_(T(2) * wt) - c[2]) / p[3];
 """
+
+# The reference's way of defining a rigid body: subtype RigidBody{R} and write `forces` (world frame) and `moments` (body frame),
+# src/rigidbody.jl:244-258 -- here the quadrotor of test/quadrotor.jl:56-96.  rdhip.CustomRigidBody(4, QUADROTOR_FORCES_SRC, QUADROTOR_MOMENTS_SRC,
+# mass=0.5, J=diag(.0023, .0023, .004), params=(0, 0, -9.81, 0.175, 1.0, 0.0245)) generates the Newton-Euler dynamics around the two snippets,
+# attaches LieState{QuatRotation,(3,6)} and declares the block structure w | q | r, v (verified on first GPU use).  In a snippet: q (attitude,
+# 4 values), r, v, w, x, u, t; user parameters P[i] (here gravity 0-2, motor distance 3, kf 4, km 5); the mass is p[0].
+QUADROTOR_FORCES_SRC = """
+    const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
+    const S fb[3] = {S(T(0)), S(T(0)), F1 + F2 + F3 + F4};
+    S qF[3]; quat_rotate(q, fb, qF);
+    for (int i = 0; i < 3; ++i) F[i] = qF[i] + p[0] * P[i];
+"""
+QUADROTOR_MOMENTS_SRC = """
+    const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
+    tau[0] = (F2 - F4) * P[3]; tau[1] = (F3 - F1) * P[3];
+    tau[2] = (u[0] - u[1] + u[2] - u[3]) * P[5];
+"""

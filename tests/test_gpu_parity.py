@@ -1464,11 +1464,7 @@ def test_custom_rigid_body_from_forces_and_moments_source():
     test/quadrotor.jl:56-96) -- with the two wrench functions given as HIP source.  The quadrotor written that way must reproduce the compiled-in
     quadrotor's oracle in both velocity frames for dynamics, every diff method, rollout!, ImplicitMidpoint and the error-state operators."""
     rng = np.random.default_rng(73)
-    forces = """const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
-                const S fb[3] = {S(T(0)), S(T(0)), F1 + F2 + F3 + F4}; S qF[3]; quat_rotate(q, fb, qF);
-                for (int i = 0; i < 3; ++i) F[i] = qF[i] + p[0] * P[i];"""
-    moments = """const S F1 = max0_(u[0] * P[4]), F2 = max0_(u[1] * P[4]), F3 = max0_(u[2] * P[4]), F4 = max0_(u[3] * P[4]);
-                 tau[0] = (F2 - F4) * P[3]; tau[1] = (F3 - F1) * P[3]; tau[2] = (u[0] - u[1] + u[2] - u[3]) * P[5];"""
+    from examples.custom_models import QUADROTOR_FORCES_SRC as forces, QUADROTOR_MOMENTS_SRC as moments
     for body in (False, True):
         model = RD.CustomRigidBody(4, forces, moments, mass=0.5, J=np.diag([0.0023, 0.0023, 0.004]), params=(0.0, 0.0, -9.81, 0.1750, 1.0, 0.0245), bodyframe=body)
         om = O.quadrotor(O.FRAME_BODY if body else O.FRAME_WORLD)
