@@ -146,7 +146,8 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         if constexpr (B < NB - 1) cfc = *cons;
         __builtin_amdgcn_sched_barrier(0);                    // keep the requests above the arithmetic
         CascadeHook<Fn, Cas, B> hk{Uc, ring + (size_t)(k & (R - 1)) * L::RING_SLOT + lane};
-        rk_hooked<Fn::RULE_ID>(fn.m, x, u, tk, (T)h, y, hk);
+        if constexpr (Fn::RULE_ID == RULE_IMPLICIT_MIDPOINT) fn.template block_step<Cas, B>(x, u, tk, (T)h, y, hk);      // implicit.hpp ImplicitRollFun
+        else rk_hooked<Fn::RULE_ID>(fn.m, x, u, tk, (T)h, y, hk);
         // next step's upstream flag is LOOKED AT here, before the last writes -- lgkmcnt is a 4-bit counter: behind ~20 LDS instructions the
         // wait for an old read degenerates into waiting for the writes to drain -- but a wave that has to wait for its upstream publishes
         // its own step first: the spin loop sits behind the writes

@@ -294,6 +294,23 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     }
     if (mode == 3) {          // rollout: a.N trajectories of a.K knot points
         if (a.K == 0) return RDHIP_OK;
+        if constexpr (Cascade<Mdl>::NB > 1) {
+            // one wavefront per cascade block + the IO wavefront, every wave solving its block of the implicit equation per step (ImplicitRollFun)
+            static const char* roll_mode = getenv("RDHIP_ROLLOUT");         // tuning switch: "plain" keeps one lane per trajectory
+            if (a.flag && !(roll_mode && roll_mode[0] == 'p') && a.K < (1LL << 26) && a.N < (1LL << 26)) {
+                using RFn = ImplicitRollFun<Mdl>;
+                using Cas = Cascade<Mdl>;
+                constexpr size_t ldsr = CascadeLds<RFn, Cas, 4>::BYTES;
+                auto kr = rollout_cascade_kernel<RFn, T, Cas, 4>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kr), ldsr) != hipSuccess) return RDHIP_ERR_HIP;
+                const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
+                hipLaunchKernelGGL(kr, dim3(gridr), dim3((Cas::NB + 1) * TILE), ldsr, a.stream, RFn{m, a.newton_iters, a.newton_tol, a.flag}, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                auto kern = implicit_rollout_kernel<Mdl, T>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
+                return hip_status(hipGetLastError());
+            }
+        }
         if (a.flag) hipLaunchKernelGGL((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_rollout_kernel<Mdl, T>;

@@ -319,6 +319,13 @@ template <class T, int N> RD_DEV void solve_small(const T (&a)[N][N], T (&b)[N])
         b[i] = b[i] * a[i][i];
     }
 }
+// The reference's tolerance (1e-12 by default) is below what fp32 can resolve: its loop then simply runs to the iteration limit and returns the
+// root to rounding.  The block iterations test against max(tol, 32 eps_T max(1, |x|)) instead -- unchanged in fp64 (7e-15 |x|), a rounding-level
+// floor in fp32 -- so that an fp32 batch converges in 2-3 iterations and is not handed to the exact kernel for a tolerance nobody can meet.
+template <class T> RD_DEV double block_tolerance(double tol, T xmax) {
+    const double floor_ = (sizeof(T) == 4 ? 32.0 * 1.1920928955078125e-07 : 32.0 * 2.220446049250313e-16) * (double)(xmax > T(1) ? xmax : T(1));
+    return tol > floor_ ? tol : floor_;
+}
 template <class Mdl, class T, class Cas> struct CascadeNewton {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NB = Cas::NB;
     using BI = BlockIndex<Cas, NX>;
@@ -341,6 +348,10 @@ template <class Mdl, class T, class Cas> struct CascadeNewton {
             const T tm = tj + h * T(0.5);
             bool done = false;
             int tests = 0;
+            T xmax = T(0);
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) { const T v = x1[BI::nth(B, i)]; const T av = v < T(0) ? -v : v; xmax = av > xmax ? av : xmax; }
+            const double tolb = block_tolerance<T>(tol, xmax);
             for (int it = 0; it < iters; ++it) {
                 T xm[NX], f[NX], r[NBK];
 #pragma unroll
@@ -350,7 +361,7 @@ template <class Mdl, class T, class Cas> struct CascadeNewton {
 #pragma unroll
                 for (int i = 0; i < NBK; ++i) { const int gi = BI::nth(B, i); r[i] = x1[gi] + h * f[gi] - xn[gi]; nr += r[i] * r[i]; }
                 if (!done) ++tests;
-                if ((double)sqrt_(nr) < tol) done = true;
+                if ((double)sqrt_(nr) < tolb) done = true;
                 if (__all(done)) break;
                 T a[NBK][NBK];
                 block_cols<B, 0, NBK>(m, xm, u, tj, h, a);
@@ -375,6 +386,67 @@ template <class Mdl, class T, class Cas> struct CascadeNewton {
         // every block meets the same norm as the reference's full residual would: ||r||^2 = sum of the blocks' < NB (tol / sqrt(NB))^2
         solve_from<0>(m, x1, u, tj, h, iters, tol * 0.5773502691896258, xn, tests0, open);
         return open || (tests0 + NB - 1 > iters);
+    }
+};
+
+// rollout!(DiscretizedDynamics{ImplicitMidpoint}) along the cascade: the function object rollout_cascade_kernel (cascade.hpp) steps with.  The
+// wavefront of block B solves ITS block of the implicit equation per step -- CascadeNewton's block iteration with the upstream blocks' midpoints
+// spliced in by the hook and its own midpoint published for the blocks downstream (the midpoint is the scheme's one "stage point") -- so the
+// three blocks of a rigid body run as a pipeline skewed by one step, exactly like the explicit rules: the chain per step is the longest block's
+// solve, not the sum.  A lane the block iteration cannot vouch for (CascadeNewton) raises the context's flag word and the exact kernel redoes
+// the batch behind this one.
+template <class Mdl> struct ImplicitRollFun {
+    using T = typename Mdl::T;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, RULE_ID = RULE_IMPLICIT_MIDPOINT;
+    Mdl m;
+    int iters; double tol;
+    int* flag;
+    template <class Cas, int B, class Hook> RD_DEV void block_step(const T (&x)[NX], const T* uu, T t, T h, T (&y)[NX], Hook& hk) const {
+        using BI = BlockIndex<Cas, NX>;
+        using CN = CascadeNewton<Mdl, T, Cas>;
+        constexpr int NBK = BI::count(B), NB = Cas::NB;
+        T xmax = T(0);
+#pragma unroll
+        for (int i = 0; i < NBK; ++i) { const T v = x[BI::nth(B, i)]; const T av = v < T(0) ? -v : v; xmax = av > xmax ? av : xmax; }
+        const double tolb = block_tolerance<T>(tol * (NB == 2 ? 0.7071067811865476 : NB == 3 ? 0.5773502691896258 : NB == 4 ? 0.5 : 0.4082482904638631), xmax);   // tol / sqrt(NB), NB <= 6
+        const T tm = t + h * T(0.5);
+        T u[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = uu[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x[i];
+        bool done = false, open = false;
+        int tests = 0;
+        T xs[NX];
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = (x[i] + y[i]) * T(0.5);
+            hk.template at<0>(xs);                        // upstream midpoints in, this block's midpoint out
+            T f[NX], r[NBK];
+            model_f(m, xs, u, tm, f);
+            T nr = T(0);
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) { const int gi = BI::nth(B, i); r[i] = x[gi] + h * f[gi] - y[gi]; nr += r[i] * r[i]; }
+            if (!done) ++tests;
+            if ((double)sqrt_(nr) < tolb) done = true;
+            if (__all(done)) break;
+            T a[NBK][NBK];
+            CN::template block_cols<B, 0, NBK>(m, xs, u, t, h, a);
+            const bool need = lu_small<T, NBK>(a);
+            if (!done) open = open || need;
+            solve_small<T, NBK>(a, r);
+            if (!done) {
+#pragma unroll
+                for (int i = 0; i < NBK; ++i) y[BI::nth(B, i)] -= r[i];
+            }
+        }
+        if (!__all(done)) {                               // the limit ended the loop behind an update: the published midpoint is one update old
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = (x[i] + y[i]) * T(0.5);
+            hk.template at<0>(xs);
+        }
+        open = open || !done || (B == 0 && tests + NB - 1 > iters);
+        if (open && flag) *flag = 1;
     }
 };
 

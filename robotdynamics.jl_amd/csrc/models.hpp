@@ -16,7 +16,7 @@
 
 namespace rd {
 
-enum { RULE_CONTINUOUS = -1, RULE_EULER = 0, RULE_RK2 = 1, RULE_RK3 = 2, RULE_RK4 = 3 };
+enum { RULE_CONTINUOUS = -1, RULE_EULER = 0, RULE_RK2 = 1, RULE_RK3 = 2, RULE_RK4 = 3, RULE_IMPLICIT_MIDPOINT = 4 };    // (4: the cascade rollout's implicit step, implicit.hpp)
 
 // ---- small vector helpers -------------------------------------------------------------------------------
 template <class S> RD_DEV void cross3(const S* a, const S* b, S* c) {
@@ -412,7 +412,7 @@ template <class Mdl, int RULE> struct Fun {
 // The same explicit rules with a hook on every stage point: `hk.template at<S>(xs)` sees (and may overwrite) the point at which stage S
 // evaluates the model.  rollout_cascade_kernel uses it to splice in the components other wavefronts own; the formulas are those of
 // Fun::eval above, operation for operation.
-template <int RULE> constexpr int rule_stages() { return RULE == RULE_EULER ? 1 : RULE == RULE_RK2 ? 2 : RULE == RULE_RK3 ? 3 : 4; }
+template <int RULE> constexpr int rule_stages() { return (RULE == RULE_EULER || RULE == RULE_IMPLICIT_MIDPOINT) ? 1 : RULE == RULE_RK2 ? 2 : RULE == RULE_RK3 ? 3 : 4; }   // (implicit midpoint: the midpoint is its one stage point)
 template <int RULE, class Mdl, class T, class Hook>
 RD_DEV void rk_hooked(const Mdl& m, const T (&x)[Mdl::NX], const T* u, T t, T h, T (&y)[Mdl::NX], Hook& hk) {
     constexpr int NX = Mdl::NX;

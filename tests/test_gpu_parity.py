@@ -1498,6 +1498,35 @@ def test_custom_rigid_body_from_forces_and_moments_source():
         np.testing.assert_allclose(host(G), om.errstate_jacobian(Zn[:, :13]), rtol=0, atol=TOL)
 
 
+def test_implicit_midpoint_fp32_against_the_fp64_oracle():
+    """ImplicitMidpoint in fp32: the reference's default tolerance (1e-12) is below fp32 resolution -- its loop runs to the iteration limit and returns the
+    root to rounding; the block iterations stop at a rounding-level floor instead (implicit.hpp block_tolerance) and must not fall back to the exact
+    kernel for it.  Solve, IFT Jacobian and rollout against the fp64 oracle at rel 1e-4 (the fp32 bar of this suite)."""
+    rng = np.random.default_rng(81)
+    for model, om, mctl, ulo, uhi in ((RD.Satellite(2.0, np.diag([2.0, 3.0, 1.0])), O.body(), 6, 0.0, 1.0), (RD.Quadrotor(), O.quadrotor(), 4, 0.6, 1.9)):
+        N = 64 * 2 + 5
+        Zn = H.rand_rigid(rng, N, mctl, ulo, uhi).astype(np.float32).astype(np.float64)
+        t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+        dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
+        Z = traj(model, Zn, t, dt, "cuda", dtype=np.float32)
+        J = RD.alloc_jacobians(dmi, N, Z.data)
+        Y = torch.empty((N, 13), dtype=torch.float32, device="cuda")
+        RD.jacobian_(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, J, Y, Z)
+        Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
+        np.testing.assert_allclose(host(Y), Xo, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(host(J), Jo, rtol=1e-4, atol=1e-4)
+        M, K = 70, 12
+        data = H.rand_rigid(rng, M * K, mctl, ulo, uhi).astype(np.float32).reshape(M, K, 13 + mctl)
+        tt = np.broadcast_to(np.arange(K) * 0.05, (M, K)).copy(); dd = np.full((M, K), 0.05)
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+        RD.rollout_(RD.StaticReturn(), dmi, stack)
+        got = host(stack["data"]).astype(np.float64)
+        # every simulated knot satisfies the implicit equation of its predecessor to fp32 accuracy (checked with the fp64 oracle's solve of each step)
+        for k in range(K - 1):
+            Xk, _, _ = om.implicit_midpoint(got[:, k, :], tt[:, k], dd[:, k], want_jacobian=False)
+            np.testing.assert_allclose(got[:, k + 1, :13], Xk, rtol=2e-4, atol=2e-4)
+
+
 def test_native_gather_really_calls_rccl_on_one_gpu():
     """The RCCL calls of csrc/comm.hip (dlopen of librccl, ncclGetUniqueId, ncclCommInitAll / ncclCommInitRank, ncclAllGather, grouped ncclSend /
     ncclRecv, ncclCommDestroy) cannot meet a second GPU on the test box; RDHIP_COMM_FORCE_RCCL=1 sends a 1-rank communicator through them anyway
