@@ -148,7 +148,7 @@ int rdhip_model_set_cascade(rdhip_model* model, int nblocks, const int* state_bl
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
  * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT), 12 = fused error-state expansion (LieState models), 13 / 14 / 15 = the register-matrix
  * forms of 7 / 8 / 10 (n <= 14; run first, 7 / 8 / 10 only when a row exchange is needed), 16 = the implicit-function-theorem Jacobian as a tile
- * kernel (n + m > 10: runs between 13 and 8); custom models only */
+ * kernel (n + m > 10: runs between 13 and 8), 17 = the implicit rollout along a declared cascade (rdhip_model_set_cascade); custom models only */
 int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
 /* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
 int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);

@@ -265,7 +265,7 @@ int rdhip_model_set_cascade(rdhip_model* M, int nblocks, const int* state_block,
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 16 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || op > 17 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }

@@ -53,7 +53,7 @@ struct JitModel {
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
        JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12,
-       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16, JOP_IMPLICIT_ROLLOUT_CAS = 17 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
 
 static std::string rot_start_expr(const JitModel& M) {
     std::ostringstream e;
@@ -84,6 +84,10 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     const char* T = dtype == RDHIP_F64 ? "double" : "float";
     const int nz = M.n + M.m;
     std::ostringstream fn, s;
+    if (op == JOP_IMPLICIT_ROLLOUT_CAS) {    // implicit rollout along the declared cascade (implicit.hpp ImplicitRollFun on cascade.hpp rollout_cascade_kernel)
+        s << "rd::rollout_cascade_kernel<rd::ImplicitRollFun<rd::UserModel<" << T << "> >, " << T << ", rd::Cascade<rd::UserModel<" << T << "> >, 4>";
+        return s.str();
+    }
     if (op == JOP_IMPLICIT_IFT) {            // IFT Jacobian through the split-role tile loop (implicit.hpp implicit_ift_split_kernel)
         s << "rd::implicit_ift_split_kernel<rd::IftFun<rd::UserModel<" << T << "> >, " << T << ", ";
         if (!M.plan_wave.empty()) {
@@ -250,14 +254,14 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD || op == JOP_IMPLICIT_IFT);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if (op == JOP_ROLLOUT && M.cas_nb > 1) {          // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp), one wavefront per block + the IO wavefront
-            const int ns = rule == RDHIP_EULER ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4, R = 4, S = 4;
+        else if ((op == JOP_ROLLOUT || op == JOP_IMPLICIT_ROLLOUT_CAS) && M.cas_nb > 1) {          // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp), one wavefront per block + the IO wavefront
+            const int ns = (op == JOP_IMPLICIT_ROLLOUT_CAS || rule == RDHIP_EULER) ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4, R = 4, S = 4;
             int npub = 0; for (int i = 0; i < M.n; ++i) npub += M.cas_state[i] < M.cas_nb - 1 ? 1 : 0;
             const size_t ring_slot = (size_t)ns * npub * 64, in_elems = (size_t)S * 64 * (M.m | 1), out_elems = (size_t)S * 64 * (M.n | 1), ts_elems = (size_t)2 * S * 64;
             const size_t in_off = a16(R * ring_slot * ts), ts_off = in_off + a16(2 * in_elems * ts), out_off = ts_off + 2 * ts_elems * 8, flag_off = out_off + a16(2 * out_elems * ts);
             jk.block = (M.cas_nb + 1) * 64; jk.lds = flag_off + 64;
         }
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op != JOP_IMPLICIT_IFT)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
+        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op != JOP_IMPLICIT_IFT && op != JOP_IMPLICIT_ROLLOUT_CAS)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
@@ -524,6 +528,27 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
             void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&J, &iters, &tol, &gate2, &tile_flags};
             return launch(M, k, tile_grid(k->lds, 64, nblk), a.stream, args);
         }
+    }
+    // mode 3 with a declared cascade: the rollout along the cascade (dispatch.hpp launch_implicit does the same for the compiled-in rigid bodies), then
+    // the exact kernel gated on the flag word
+    if (mode == 3 && a.flag && M.cas_nb > 1 && K < (1LL << 26) && N < (1LL << 26)) {
+        if (K == 0) return RDHIP_OK;
+        JitKernel* kc; rc = jit_get(M, JOP_IMPLICIT_ROLLOUT_CAS, RDHIP_IMPLICIT_MIDPOINT, dtype, &kc); if (rc) return rc;
+        int* flag = a.flag;
+        if (hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
+        // ImplicitRollFun<UserModel<T>> = { UserModel m; int iters; double tol; int* flag; } with the natural alignment of its members
+        std::vector<unsigned char> rf(fn);
+        rf.resize((rf.size() + 3) / 4 * 4);
+        const size_t o_it = rf.size();
+        rf.resize((o_it + 4 + 7) / 8 * 8);
+        const size_t o_tol = rf.size();
+        rf.resize(o_tol + 16, 0);
+        std::memcpy(rf.data() + o_it, &iters, 4); std::memcpy(rf.data() + o_tol, &tol, 8); std::memcpy(rf.data() + o_tol + 8, &flag, 8);
+        long long sj = K, sk = 1;
+        { void* ar[] = {rf.data(), &K, &N, &sj, &sk, &Z, &t, &dt, &X0}; rc = launch(M, kc, (unsigned)((N + 63) / 64), a.stream, ar); if (rc) return rc; }
+        const int* gate3 = flag;
+        void* args[] = {fn.data(), &K, &N, &Z, &t, &dt, &X0, &iters, &tol, &gate3};
+        return launch(M, k, grid, a.stream, args);
     }
     if (a.flag && M.n <= 14) {
         JitKernel* kr; rc = jit_get(M, mode == 0 ? JOP_IMPLICIT_X_REG : mode == 1 ? JOP_IMPLICIT_J_REG : JOP_IMPLICIT_ROLLOUT_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;

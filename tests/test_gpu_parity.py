@@ -1450,6 +1450,16 @@ def test_custom_model_with_a_declared_cascade_gets_the_cascade_kernels():
     Xo, Jo, _ = om.implicit_midpoint(Zn, t, dt)
     np.testing.assert_allclose(host(Y), Xo, rtol=0, atol=TOL)
     np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+    # implicit rollout along the declared cascade (one wavefront per block solving its block per step), a ragged group and a full one
+    for M, K in ((70, 12), (128, 9)):
+        data = H.rand_rigid(rng, M * K, 6).reshape(M, K, 19)
+        tt, dd = np.tile(np.arange(K) * 0.05, (M, 1)), np.full((M, K), 0.05)
+        ref = data.copy()
+        for k in range(1, K):
+            ref[:, k, :13] = om.implicit_midpoint(ref[:, k - 1], tt[:, k - 1], dd[:, k - 1], want_jacobian=False)[0]
+        stack = {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(tt).cuda(), "dt": torch.as_tensor(dd).cuda()}
+        RD.rollout_(RD.StaticReturn(), dmi, stack)
+        np.testing.assert_allclose(host(stack["data"]), ref, rtol=0, atol=TOL)
     # a false promise: the attitude placed UPSTREAM of the angular velocity it depends on
     liar = mk()
     liar.set_cascade([2, 2, 2, 0, 0, 0, 0, 2, 2, 2, 1, 1, 1], [2, 2, 2, 1, 1, 1])

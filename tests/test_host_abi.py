@@ -262,6 +262,7 @@ def test_custom_model_jit_compiles_without_a_gpu():
     tvs.precompile("FiniteDifference", RD.RK4)
     tvs.precompile("rollout", RD.RK3, np.float32)
     tvs.precompile("implicit_solve", RD.ImplicitMidpoint)
+    assert RD.lib().rdhip_model_precompile(tvs._handle, 17, 4, 0) == 0          # the implicit rollout along the declared cascade
     # a rigid body defined the reference's way -- `forces` and `moments` (src/rigidbody.jl:244-258) -- as two snippets of HIP source
     crb = RD.CustomRigidBody(6, "quat_rotate(q, u, F);", "tau[0] = u[3]; tau[1] = u[4]; tau[2] = u[5] * P[0];", mass=2.0, J=np.diag([2.0, 3.0, 1.0]), params=(1.0,),
                              bodyframe=True, force_only_controls=(0, 1, 2))
