@@ -38,7 +38,21 @@ template <class Fn, class Cas, int R_> struct CascadeLds {
     static constexpr int NPUB = pub_index(NX);
     static constexpr size_t a16(size_t b) { return (b + 15) / 16 * 16; }
     static constexpr int NUP = NU | 1, NXP = NX | 1;                         // odd row strides: lane-strided reads / writes hit distinct banks
-    static constexpr size_t RING_SLOT = (size_t)NS * NPUB * TILE;            // elements per ring slot
+    // ring slot layout [stage][lane][NPP]: the published components of one lane are ADJACENT, so a block's stage point moves as one or two 16-byte LDS
+    // instructions instead of one instruction per component (the hand-off is LDS-instruction-issue bound: 14 / 17 / 28 cycles per b32 / b64 / b128
+    // instruction, measured); the lane stride is an odd number of 16-byte units, which keeps 16 consecutive lanes of a b128 access on distinct banks
+    // (where the padded layout does not fit the CU's LDS next to the IO tiles -- a rigid body in fp64 -- the ring stays [stage][component][lane])
+    static constexpr int npp() { int u = (int)((NPUB * sizeof(T) + 15) / 16); if (u % 2 == 0) ++u; return u * 16 / (int)sizeof(T); }
+    static constexpr size_t a16_(size_t b) { return (b + 15) / 16 * 16; }
+    static constexpr size_t bytes_with(size_t ring_slot) {
+        return a16_(R * ring_slot * sizeof(T)) + a16_(2 * (size_t)S * TILE * (NU | 1) * sizeof(T)) + 2 * (size_t)2 * S * TILE * sizeof(double) + a16_(2 * (size_t)S * TILE * (NX | 1) * sizeof(T)) + 64;
+    }
+    static constexpr bool LANE_MAJOR = NPUB > 0 && bytes_with((size_t)NS * TILE * npp()) <= 160 * 1024;
+    static constexpr int NPP = LANE_MAJOR ? npp() : NPUB;
+    static constexpr size_t RING_SLOT = (size_t)NS * TILE * NPP;             // elements per ring slot
+    // element index of (stage s, published component p, lane l) inside a slot
+    static constexpr size_t ring_index(int s, int p, int l) { return LANE_MAJOR ? ((size_t)s * TILE + l) * NPP + p : ((size_t)s * NPUB + p) * TILE + l; }
+    static constexpr size_t lane_offset(int l) { return LANE_MAJOR ? (size_t)l * NPP : (size_t)l; }
     static constexpr size_t IN_ELEMS = (size_t)S * TILE * NUP, OUT_ELEMS = (size_t)S * TILE * NXP, TS_ELEMS = (size_t)2 * S * TILE;
     static constexpr size_t IN_OFF = a16(R * RING_SLOT * sizeof(T));         // IN[2]: controls of a chunk, [s][trajectory][NUP]
     static constexpr size_t TS_OFF = IN_OFF + a16(2 * IN_ELEMS * sizeof(T)); // TS[2]: t[s][trajectory], dt[s][trajectory] (fp64)
@@ -56,14 +70,15 @@ template <class Fn, class Cas, int B> struct CascadeHook {
     static constexpr int pub_index(int i) { int p = 0; for (int j = 0; j < i; ++j) p += published(j) ? 1 : 0; return p; }
     static constexpr int NPUB = pub_index(NX);
     const T (&U)[NS][NX];                             // stage points of the upstream blocks (entries of other blocks are never touched)
-    T __attribute__((address_space(3)))* slot;        // ring slot of this step, already offset by the lane: [stage][published component][64]
+    using LL = CascadeLds<Fn, Cas, 4>;
+    T __attribute__((address_space(3)))* slot;        // ring slot of this step, already offset by the lane (CascadeLds::ring_index / lane_offset)
     // this block's stage points go to the ring AS THEY ARE FORMED: the LDS writes (~29 cycles of LDS pipe per 16 B/lane instruction, measured)
     // then drain under the remaining arithmetic instead of queueing up behind it
     template <int S> RD_DEV void at(T (&xs)[NX]) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             if (Cas::block_of(i) < B) xs[i] = U[S][i];
-            else if (Cas::block_of(i) == B) { if constexpr (B < NB - 1) slot[(S * NPUB + pub_index(i)) * TILE] = xs[i]; }
+            else if (Cas::block_of(i) == B) { if constexpr (B < NB - 1) slot[LL::ring_index(S, pub_index(i), 0)] = xs[i]; }
             else xs[i] = T(0);                              // downstream components: this block's derivative does not read them
         }
     }
@@ -114,7 +129,7 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int i = 0; i < NX; ++i)
-                if (Cas::block_of(i) < B) dst[s][i] = slot[(s * L::NPUB + L::pub_index(i)) * TILE + lane];
+                if (Cas::block_of(i) < B) dst[s][i] = slot[L::ring_index(s, L::pub_index(i), 0) + L::lane_offset(lane)];
         RD_LDS_ORDER();
     };
     T UA[NS][NX], UB[NS][NX];                                 // upstream stage points of this / the next step (roles alternate)
@@ -145,7 +160,7 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         if constexpr (B > 0) { if (more) { fl = prod[B - 1]; RD_LDS_ORDER(); read_slot(k + 1, Un); } }
         if constexpr (B < NB - 1) cfc = *cons;
         __builtin_amdgcn_sched_barrier(0);                    // keep the requests above the arithmetic
-        CascadeHook<Fn, Cas, B> hk{Uc, ring + (size_t)(k & (R - 1)) * L::RING_SLOT + lane};
+        CascadeHook<Fn, Cas, B> hk{Uc, ring + (size_t)(k & (R - 1)) * L::RING_SLOT + L::lane_offset(lane)};
         if constexpr (Fn::RULE_ID == RULE_IMPLICIT_MIDPOINT) fn.template block_step<Cas, B>(x, u, tk, (T)h, y, hk);      // implicit.hpp ImplicitRollFun
         else rk_hooked<Fn::RULE_ID>(fn.m, x, u, tk, (T)h, y, hk);
         // next step's upstream flag is LOOKED AT here, before the last writes -- lgkmcnt is a 4-bit counter: behind ~20 LDS instructions the

@@ -257,7 +257,11 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         else if ((op == JOP_ROLLOUT || op == JOP_IMPLICIT_ROLLOUT_CAS) && M.cas_nb > 1) {          // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp), one wavefront per block + the IO wavefront
             const int ns = (op == JOP_IMPLICIT_ROLLOUT_CAS || rule == RDHIP_EULER) ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4, R = 4, S = 4;
             int npub = 0; for (int i = 0; i < M.n; ++i) npub += M.cas_state[i] < M.cas_nb - 1 ? 1 : 0;
-            const size_t ring_slot = (size_t)ns * npub * 64, in_elems = (size_t)S * 64 * (M.m | 1), out_elems = (size_t)S * 64 * (M.n | 1), ts_elems = (size_t)2 * S * 64;
+            size_t units = ((size_t)npub * ts + 15) / 16; if (units % 2 == 0) ++units;               // lane-major ring: lane stride = an odd number of 16-byte units ...
+            const size_t in_e = (size_t)S * 64 * (M.m | 1), out_e = (size_t)S * 64 * (M.n | 1);
+            const size_t padded = (size_t)ns * 64 * (units * 16 / ts);
+            const bool lane_major = npub > 0 && a16(R * padded * ts) + a16(2 * in_e * ts) + 2 * (size_t)2 * S * 64 * 8 + a16(2 * out_e * ts) + 64 <= 160 * 1024;   // ... where it fits (CascadeLds::LANE_MAJOR)
+            const size_t ring_slot = lane_major ? padded : (size_t)ns * npub * 64, in_elems = (size_t)S * 64 * (M.m | 1), out_elems = (size_t)S * 64 * (M.n | 1), ts_elems = (size_t)2 * S * 64;
             const size_t in_off = a16(R * ring_slot * ts), ts_off = in_off + a16(2 * in_elems * ts), out_off = ts_off + 2 * ts_elems * 8, flag_off = out_off + a16(2 * out_elems * ts);
             jk.block = (M.cas_nb + 1) * 64; jk.lds = flag_off + 64;
         }
