@@ -1537,6 +1537,28 @@ def test_implicit_midpoint_fp32_against_the_fp64_oracle():
             np.testing.assert_allclose(got[:, k + 1, :13], Xk, rtol=2e-4, atol=2e-4)
 
 
+def test_flagship_at_a_million_knot_points_walks_xcd_tile_ranges():
+    """From 64 tiles per workgroup on (1 M knot points on a whole MI355X) every XCD walks its own contiguous eighth of the tiles (kernels.hpp
+    jac_split_loop); the smaller parity tests never reach that branch.  1 048 653 satellite knot points (a ragged last tile), outputs pre-filled with
+    NaN: every element must be written, and every 997th knot point, the first two tiles and the last 70 knot points must match the oracle."""
+    rng = np.random.default_rng(91)
+    N = (1 << 20) + 77
+    Zn = H.rand_rigid(rng, N, 6)
+    t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+    model = RD.Satellite(); dm = RD.DiscretizedDynamics(model, RD.RK4)
+    Z = traj(model, Zn, t, dt, "cuda")
+    J = RD.alloc_jacobians(dm, N, Z.data); J.fill_(float("nan"))
+    Y = torch.full((N, 13), float("nan"), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(J).any()) and not bool(torch.isnan(Y).any())
+    idx = np.unique(np.concatenate([np.arange(0, N, 997), np.arange(N - 70, N), np.arange(0, 130)]))
+    Jo, Yo = O.satellite().jacobian(O.RK4, O.FORWARD_AD, Zn[idx], t[idx], dt[idx])
+    ix = torch.as_tensor(idx).cuda()
+    np.testing.assert_allclose(host(J[ix]), Jo, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y[ix]), Yo, rtol=0, atol=TOL)
+
+
 def test_native_gather_really_calls_rccl_on_one_gpu():
     """The RCCL calls of csrc/comm.hip (dlopen of librccl, ncclGetUniqueId, ncclCommInitAll / ncclCommInitRank, ncclAllGather, grouped ncclSend /
     ncclRecv, ncclCommDestroy) cannot meet a second GPU on the test box; RDHIP_COMM_FORCE_RCCL=1 sends a 1-rank communicator through them anyway
