@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="sustained load (the same launches, untimed) before the W warm-up steps: clocks and TLBs settle over ~100 ms, "
                          "a short W alone measures the ramp (0.62 instead of 0.65-0.68 of the roofline)")
-    ap.add_argument("--streams", type=int, default=1, help="N=1 only, opt-in: also report independent batches issued round-robin on this many streams (extra object, never `value`)")
+    ap.add_argument("--streams", type=int, default=4, help="N=1 only: also report independent batches issued round-robin on this many streams (extra object, never `value`; 1 = skip)")
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
@@ -287,6 +287,7 @@ def main():
     # launch's workgroups start on the CUs the previous launch has already left, so its prologue runs under the previous launch's tail
     overlapped = None
     if world == 1 and args.streams > 1:
+      try:
         streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
         scalls = []
         for b in range(NBUF):
@@ -305,6 +306,8 @@ def main():
         overlapped = {"streams": args.streams, "value": N * args.steps / sel, "ms_per_step": 1e3 * sel / args.steps,
                       "frac_of_hbm_peak": N * BYTES_PER_KNOT * args.steps / sel / 1e9 / HBM_PEAK_GBS,
                       "note": "independent batches round-robin on several streams; not the contract's `value`"}
+      except Exception as e:                                 # an extra: never lose the bench line over it
+        overlapped = {"streams": args.streams, "error": f"{type(e).__name__}: {e}"[:200]}
 
     gather = None
     if world > 1 and args.gather != "none":
