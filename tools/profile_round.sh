@@ -1,4 +1,4 @@
-tag=r02n
+tag=r02p
 bash tools/gpu_profile.sh $tag > gpurun_out/$tag.log 2>&1
 out=gpurun_out/$tag
 python tools/bench_configs.py --sweep > $out/configs.jsonl 2> $out/configs.err
