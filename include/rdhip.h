@@ -141,14 +141,19 @@ int rdhip_model_balance_columns(rdhip_model* model);
  * block may read blocks 0 .. b only; control_block[j] is the first block whose derivative reads control j.  With a declaration the model gets the
  * kernels that exploit it: FiniteDifference that re-integrates only what a column can change, rollout! with one wavefront per block, Newton's method
  * block by block for ImplicitMidpoint.  The declaration is verified on first use on a GPU (the continuous ForwardAD Jacobian at 32 points must have exact
- * zeros wherever it promises them; RDHIP_ERR_INVALID_ARG with the offending entry otherwise).  2 <= nblocks <= 6, at most 8 state components per block;
- * nblocks <= 1 removes the declaration.  Kernels compiled before the call are recompiled on next use. */
+ * zeros wherever it promises them; RDHIP_ERR_INVALID_ARG with the offending entry otherwise; the check allocates and synchronises, so the first use
+ * must not sit inside a graph capture -- it is refused there).  2 <= nblocks <= 6, at most 8 state components per block; nblocks <= 1 removes the
+ * declaration.  The one-wavefront-per-block rollout kernels additionally need their LDS ring (stage points of all blocks but the last x 4 steps)
+ * plus the I/O tiles to fit the 160 KiB of a CU and K, M < 2^26: a declaration that does not fit (e.g. 16 fp64 states with a 12-state upstream part
+ * under RK4) keeps the plain one-lane-per-trajectory rollout; FiniteDifference and Newton's method use the declaration regardless.
+ * Kernels compiled before the call are recompiled on next use. */
 int rdhip_model_set_cascade(rdhip_model* model, int nblocks, const int* state_block, const int* control_block);
 /* compile (no GPU needed) the kernel of one operation: op 0 = dynamics / discrete dynamics, 1 = rollout, 2 = ForwardAD Jacobian,
  * 3 = FiniteDifference Jacobian, 4 = UserDefined chain-rule Jacobian, 7 / 8 / 9 / 10 = ImplicitMidpoint solve / solve + Jacobian /
  * dynamics error / rollout (rule = RDHIP_IMPLICIT_MIDPOINT), 12 = fused error-state expansion (LieState models), 13 / 14 / 15 = the register-matrix
  * forms of 7 / 8 / 10 (n <= 14; run first, 7 / 8 / 10 only when a row exchange is needed), 16 = the implicit-function-theorem Jacobian as a tile
- * kernel (n + m > 10: runs between 13 and 8), 17 = the implicit rollout along a declared cascade (rdhip_model_set_cascade); custom models only */
+ * kernel (n + m > 10: runs between 13 and 8), 17 = the implicit rollout along a declared cascade (rdhip_model_set_cascade), 18 = the plain rollout
+ * whatever is declared, 32 + op (op = 2 .. 6, 11) = the Jacobian kernels of rdhip_jacobian_multi; custom models only */
 int rdhip_model_precompile(rdhip_model* model, int op, int rule, int dtype);
 /* dims(model) = (n, m, p) and errstate_dim: src/functionbase.jl:130-135, src/dynamics.jl:3, src/liestate.jl:24,124,207 */
 int rdhip_model_dims(const rdhip_model* model, int* n, int* m, int* p, int* e);
@@ -188,12 +193,19 @@ int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff,
  * or multiple-shooting segments: `for p in problems, k in 1:N[p]; jacobian!(sig, diff, model, J[p][k], y, Z[p][k]); end`, src/functionbase.jl:242)
  * in ONE kernel launch: N[b], Z[b], t[b], dt[b], J[b], Y[b] are the arguments rdhip_jacobian would take for batch b (Y or any Y[b] may be NULL).
  * A trajectory of a few thousand knot points is launch-bound on its own; enumerated together by the same persistent tile loop, 16 x 4 096 knot
- * points cost what one 65 536-knot batch costs.  The tables N / Z / t / dt / J / Y themselves are HOST arrays of nbatch entries (they travel in
- * the kernel arguments and are not retained); memspace describes the data pointers inside them.  Fused for ForwardAD on the compiled-in models
- * with device pointers (16-byte aligned J / Y for n + m > 10); every other combination runs the batches one rdhip_jacobian call at a time with
- * the same results.  Batches must not overlap. */
+ * points cost what one 65 536-knot batch costs, and 1 024 trajectories of 101 knot points (examples/cartpole.jl:46) are one bandwidth-regime launch.
+ * The tables N / Z / t / dt / J / Y themselves are HOST arrays of nbatch entries (not retained); memspace describes the data pointers inside them.
+ * Up to 32 non-empty batches travel in the kernel arguments; more are copied into a device table owned by the context (a binary search per tile,
+ * none when all batches have the same length).  Fused -- ONE launch -- for every explicit rule and diff method (ForwardAD, FiniteDifference,
+ * UserDefined) of the compiled-in and the custom (hipRTC) models with device pointers, aligned or not; RDHIP_IMPLICIT_MIDPOINT (three passes per batch)
+ * and host arrays run the batches one rdhip_jacobian call at a time with the same results, and so does a capturing stream with more than 32 batches
+ * in groups of 32 launches (no allocation inside a capture).  rdhip_ctx_last_multi_launches tells which happened; RDHIP_VERBOSE=1 logs the fallback.
+ * Batches must not overlap. */
 int rdhip_jacobian_multi(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, int nbatch, const long long* N,
                          const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace);
+/* kernel launches the last rdhip_jacobian_multi call on this context issued: 1 = fused into one launch (the per-trajectory loops of
+ * src/functionbase.jl:242 callers collapsed), nbatch (3 x nbatch for the implicit rule) = the batch-by-batch fallback */
+int rdhip_ctx_last_multi_launches(rdhip_ctx* ctx, int* launches);
 
 /* dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2) (src/discrete_dynamics.jl:134-135; in-place :146-156) for
  * the N-1 consecutive knot-point pairs (z1, z2) = (Z[k], Z[k+1]) of a packed trajectory: E[:, k] = f(z_k) - x_{k+1}, k = 0..N-2.

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -21,12 +22,20 @@ struct rdhip_ctx {
     bool own_stream;
     hipEvent_t ev0, ev1;
     bool capturing = false;               // between rdhip_graph_begin_capture and rdhip_graph_end_capture
-    int epoch = 0;                        // implicit calls on this context so far (mod 2^23, never 0): LaunchArgs::epoch
+    int epoch = 0;                        // implicit calls on this context so far (1 .. 2^22, never 0; `epoch << 8` must stay a positive int): LaunchArgs::epoch
     int* d_flag = nullptr;                // device words "a row exchange was needed" of the implicit kernels (allocated with the context: never inside a capture)
     std::string err;
     // grow-only device workspace slots for RDHIP_HOST staging
     void* ws[8];
     size_t ws_bytes[8];
+    // batch tables of rdhip_jacobian_multi calls with more batches than fit the kernel arguments: pinned host image + device copy, a ring of
+    // slots so that a call never overwrites a table a kernel of an earlier call may still be reading (the slot's event says when it is free)
+    // A solver re-issues the same call on the same arrays every iteration: a slot whose image equals the new table is reused without a copy.
+    struct TableSlot { void* host = nullptr; void* dev = nullptr; size_t cap = 0, used = 0; hipEvent_t done = nullptr; bool pending = false; };
+    static constexpr int NTSLOT = 8;
+    TableSlot tslot[NTSLOT];
+    unsigned tnext = 0;
+    int last_multi_launches = 0;          // kernel launches the last rdhip_jacobian_multi call on this context issued (rdhip_ctx_last_multi_launches)
 };
 struct rdhip_model {
     ModelDesc d;
@@ -110,6 +119,7 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -265,7 +275,7 @@ int rdhip_model_set_cascade(rdhip_model* M, int nblocks, const int* state_block,
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || op > 17 || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || (op > 18 && !(op >= 32 && (op - 32 == 11 || (op - 32 >= 2 && op - 32 <= 6)))) || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
@@ -419,7 +429,7 @@ static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype
     a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
     if (mode != 2) {     // Newton kernels: register pass + gated LDS pass communicate through a device word
         a.flag = c->d_flag;
-        c->epoch = c->epoch >= (1 << 23) ? 1 : c->epoch + 1;
+        c->epoch = c->epoch >= (1 << 22) ? 1 : c->epoch + 1;
         a.epoch = c->epoch;
     }
     switch (d.kind) {
@@ -482,43 +492,127 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
 }
 
 // jacobian! over several independent packed trajectories in one launch.  TrajectoryOptimization-sized problems hold 101 ... 4 096 knot points
-// per trajectory (examples/cartpole.jl:46): one such batch is launch-bound (9 MB of output takes 1.2 us at 8 TB/s, a launch ~8 us), sixteen of
-// them enumerated by one persistent tile loop are one bandwidth-regime launch.
+// per trajectory (examples/cartpole.jl:46): one such batch is launch-bound (9 MB of output takes 1.2 us at 8 TB/s, a launch ~8 us); a thousand
+// of them enumerated by one persistent tile loop are one bandwidth-regime launch.
+static bool stream_is_capturing(rdhip_ctx* c) {
+    if (c->capturing) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;          // a borrowed stream may be captured by its owner (torch.cuda.graph)
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+// device table of `nb` batches in the next ring slot; returns the slot (its event is recorded by the caller behind the kernel) or nullptr
+static rdhip_ctx::TableSlot* upload_table(rdhip_ctx* c, const std::vector<MultiRecPod>& recs, const std::vector<unsigned>& tile0) {
+    const size_t rec_bytes = recs.size() * sizeof(MultiRecPod), t0_bytes = tile0.size() * sizeof(unsigned), bytes = rec_bytes + t0_bytes;
+    for (auto& sl : c->tslot)                              // the same table as an earlier call (same arrays, same lengths): its device copy is still valid
+        if (sl.used == bytes && sl.host && std::memcmp(sl.host, recs.data(), rec_bytes) == 0 && std::memcmp(static_cast<char*>(sl.host) + rec_bytes, tile0.data(), t0_bytes) == 0) return &sl;
+    rdhip_ctx::TableSlot& sl = c->tslot[c->tnext++ % rdhip_ctx::NTSLOT];
+    if (sl.pending) { if (hipEventSynchronize(sl.done) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: hipEventSynchronize failed"); return nullptr; } sl.pending = false; }
+    sl.used = 0;
+    if (sl.cap < bytes) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.host = sl.dev = nullptr; sl.cap = 0;
+        const size_t cap = bytes + bytes / 2;
+        if (hipHostMalloc(&sl.host, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&sl.dev, cap) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: allocation of %zu bytes failed", cap); return nullptr; }
+        sl.cap = cap;
+    }
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: hipEventCreate failed"); return nullptr; }
+    std::memcpy(sl.host, recs.data(), rec_bytes);
+    std::memcpy(static_cast<char*>(sl.host) + rec_bytes, tile0.data(), t0_bytes);
+    if (hipMemcpyAsync(sl.dev, sl.host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: H2D copy failed"); return nullptr; }
+    sl.used = bytes;
+    return &sl;
+}
 int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, int nbatch, const long long* N,
                          const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace) {
     const char* what = "rdhip_jacobian_multi";
     int rc = check_common(c, M, dtype, 0, memspace); if (rc) return rc;
+    c->last_multi_launches = 0;
     if (nbatch < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative nbatch", what);
     if (nbatch == 0) return RDHIP_OK;
     if (!N || !Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL table", what);
     if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
+    std::vector<int> live;
+    bool aligned = true, equal = true;
     for (int b = 0; b < nbatch; ++b) {
         if (N[b] < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has negative N", what, b);
-        if (N[b] > 0 && (!Z[b] || !t[b] || !dt[b] || !J[b])) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has a NULL data pointer", what, b);
+        if (N[b] == 0) continue;
+        if (!Z[b] || !t[b] || !dt[b] || !J[b]) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: batch %d has a NULL data pointer", what, b);
+        aligned = aligned && !(reinterpret_cast<uintptr_t>(J[b]) & 15) && !(Y && (reinterpret_cast<uintptr_t>(Y[b]) & 15));
+        if (!live.empty() && N[b] != N[live[0]]) equal = false;
+        live.push_back(b);
     }
     rc = check_rotation(c, M, 0); if (rc) return rc;
+    if (live.empty()) return RDHIP_OK;
     const ModelDesc& d = M->d;
-    bool fused = memspace == RDHIP_DEVICE && rule != RDHIP_IMPLICIT_MIDPOINT && d.kind != RDHIP_MODEL_CUSTOM;
-    for (int b0 = 0; fused && b0 < nbatch; b0 += 32) {          // the kernel-argument table holds 32 batches: more go out in groups
-        MultiDesc md{}; md.nb = 0;
-        for (int b = b0; b < nbatch && b < b0 + 32; ++b) {
-            if (N[b] == 0) continue;
-            const int i = md.nb++;
-            md.N[i] = N[b]; md.Z[i] = Z[b]; md.t[i] = t[b]; md.dt[i] = dt[b]; md.J[i] = J[b]; md.Y[i] = Y ? Y[b] : nullptr;
+    // fused: explicit rules on device pointers (compiled-in and custom models, every diff method, aligned or not).  Implicit rules (a Newton
+    // pass, the Jacobian pass and a gated exact pass per batch) and host arrays run the batches one rdhip_jacobian call at a time.
+    bool fused = memspace == RDHIP_DEVICE && rule != RDHIP_IMPLICIT_MIDPOINT;
+    if (fused) {
+        const int nl = (int)live.size();
+        const bool table = nl > MULTI_INLINE && !stream_is_capturing(c);      // (a capturing stream: groups of MULTI_INLINE in the kernel arguments -- no allocation, no event)
+        const int group = table ? nl : MULTI_INLINE;
+        for (int g0 = 0; fused && g0 < nl; g0 += group) {
+            const int ng = nl - g0 < group ? nl - g0 : group;
+            MultiDesc md{}; MultiPod& p = md.pod;
+            md.aligned16 = aligned; p.nb = ng; p.uniform = 0; p.ext = nullptr; p.ext_tile0 = nullptr;
+            rdhip_ctx::TableSlot* slot = nullptr;
+            long long acc = 0;
+            for (int i = 0; i < ng; ++i) acc += (N[live[g0 + i]] + 63) / 64;
+            if (acc >= (1LL << 31)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: more than 2^31 tiles of 64 knot points in one call", what);
+            acc = 0;
+            p.group = 1; p.pad_ = 0;
+            if (table) {
+                std::vector<MultiRecPod> recs(ng); std::vector<unsigned> tile0(ng + 1);
+                for (int i = 0; i < ng; ++i) {
+                    const int b = live[g0 + i];
+                    recs[i] = MultiRecPod{Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, N[b], {0, 0}};
+                    tile0[i] = (unsigned)acc; acc += (N[b] + 63) / 64;
+                }
+                tile0[ng] = (unsigned)acc;
+                slot = upload_table(c, recs, tile0);
+                if (!slot) return RDHIP_ERR_HIP;
+                p.ext = static_cast<const MultiRecPod*>(slot->dev);
+                p.ext_tile0 = reinterpret_cast<const unsigned*>(static_cast<const char*>(slot->dev) + recs.size() * sizeof(MultiRecPod));
+                p.uniform = equal ? (int)((N[live[0]] + 63) / 64) : 0;
+                p.group = (ng + MULTI_INLINE - 1) / MULTI_INLINE;
+                for (int i = 0; i <= MULTI_INLINE; ++i) p.tile0[i] = (long long)i * p.group < ng ? tile0[(size_t)i * p.group] : (unsigned)acc;     // coarse level
+                for (int i = 0; i < MULTI_INLINE; ++i) { p.N[i] = 0; p.Z[i] = nullptr; p.t[i] = nullptr; p.dt[i] = nullptr; p.J[i] = nullptr; p.Y[i] = nullptr; }
+            } else {
+                for (int i = 0; i < MULTI_INLINE; ++i) {
+                    const bool on = i < ng; const int b = on ? live[g0 + i] : 0;
+                    p.tile0[i] = (unsigned)acc;
+                    p.N[i] = on ? N[b] : 0; p.Z[i] = on ? Z[b] : nullptr; p.t[i] = on ? t[b] : nullptr; p.dt[i] = on ? dt[b] : nullptr;
+                    p.J[i] = on ? J[b] : nullptr; p.Y[i] = (on && Y) ? Y[b] : nullptr;
+                    if (on) acc += (N[b] + 63) / 64;
+                }
+                p.tile0[MULTI_INLINE] = (unsigned)acc;
+                for (int i = ng; i <= MULTI_INLINE; ++i) p.tile0[i] = (unsigned)acc;
+            }
+            p.total = acc;
+            LaunchArgs a{}; a.stream = c->stream; a.multi = &md;
+            const int k = family_jacobian(d, rule, diff, dtype, a);
+            if (k == RDHIP_ERR_UNSUPPORTED && g0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff): decided before anything was launched
+            if (k) return kernel_status(c, k, what);
+            ++c->last_multi_launches;
+            if (slot) { if (hipEventRecord(slot->done, c->stream) != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: hipEventRecord failed", what); slot->pending = true; }
         }
-        if (md.nb == 0) continue;
-        LaunchArgs a{}; a.stream = c->stream; a.multi = &md;
-        const int k = family_jacobian(d, rule, diff, dtype, a);
-        if (k == RDHIP_ERR_UNSUPPORTED && b0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff) or unaligned outputs
-        if (k) return kernel_status(c, k, what);
     }
     if (fused) return RDHIP_OK;
-    for (int b = 0; b < nbatch; ++b) {                            // same results, one call per batch
+    static const bool verbose = getenv("RDHIP_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[rdhip] %s: no fused kernel for (model kind %d, rule %d, diff %d, %s pointers): %d batches run as separate rdhip_jacobian calls\n",
+                         what, d.kind, rule, diff, memspace == RDHIP_DEVICE ? "device" : "host", (int)live.size());
+    for (int b : live) {                                          // same results, one call per batch
         rc = rdhip_jacobian(c, M, rule, diff, dtype, N[b], Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, memspace);
         if (rc) return rc;
+        c->last_multi_launches += (rule == RDHIP_IMPLICIT_MIDPOINT) ? 3 : 1;
     }
     return RDHIP_OK;
+}
+int rdhip_ctx_last_multi_launches(rdhip_ctx* c, int* launches) {
+    if (!c || !launches) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *launches = c->last_multi_launches; return RDHIP_OK;
 }
 
 // dynamics_error / dynamics_error_jacobian!: the discrete dynamics (Jacobian) of the first N-1 knot points, minus the next state

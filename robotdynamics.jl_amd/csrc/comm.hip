@@ -22,7 +22,33 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
+// The library is dlopen()ed at run time; the header is only needed for the handful of types and prototypes below.  A ROCm install without the RCCL
+// development headers still builds librdhip (the declarations follow RCCL's stable C ABI, nccl.h 2.x); -DRDHIP_NO_RCCL_HEADER forces this branch.
+#if !defined(RDHIP_NO_RCCL_HEADER) && defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define RDHIP_HAVE_RCCL_HEADER 1
+#endif
+#endif
+#ifndef RDHIP_HAVE_RCCL_HEADER
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;              // (other values are only ever handed back to ncclGetErrorString)
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include "../../include/rdhip.h"
 

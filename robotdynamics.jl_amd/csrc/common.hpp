@@ -76,11 +76,26 @@ struct ModelDesc {
     double newton_tol;
 };
 
-// rdhip_jacobian_multi: up to 32 independent packed trajectories for ONE launch (kernels.hpp MultiBatch)
-struct MultiDesc {
+// rdhip_jacobian_multi: several independent packed trajectories for ONE launch.  MultiPod is the byte image of kernels.hpp MultiBatch<T> (typed
+// pointers there; dispatch.hpp asserts the sizes agree): up to MULTI_INLINE batches inline (they travel in the kernel arguments), any number
+// through the device table `ext` / `ext_tile0` (then the inline arrays are unused).
+constexpr int MULTI_INLINE = 32;
+struct MultiRecPod { const void* Z; const double* t; const double* dt; void* J; void* Y; long long N; long long pad[2]; };   // 64 bytes
+struct MultiPod {
     int nb;
-    long long N[32];
-    const void* Z[32]; const double* t[32]; const double* dt[32]; void* J[32]; void* Y[32];
+    int uniform;                 // > 0: every batch has this many 64-knot tiles
+    long long total;             // tiles of all batches (< 2^31)
+    const MultiRecPod* ext;      // device table (nb records) or nullptr
+    const unsigned* ext_tile0;   // device: nb + 1 entries
+    int group;                   // ext: batches per entry of the coarse inline table
+    int pad_;
+    unsigned tile0[MULTI_INLINE + 1];
+    long long N[MULTI_INLINE];
+    const void* Z[MULTI_INLINE]; const double* t[MULTI_INLINE]; const double* dt[MULTI_INLINE]; void* J[MULTI_INLINE]; void* Y[MULTI_INLINE];
+};
+struct MultiDesc {
+    MultiPod pod;
+    bool aligned16;              // every J / Y of every batch is 16-byte aligned (the split-role kernels copy 16-byte units)
 };
 
 struct LaunchArgs {
@@ -98,9 +113,12 @@ struct LaunchArgs {
     double newton_tol;
     int time_major;     // rollout: knot k of trajectory j at k*M + j instead of j*K + k
     int* flag;          // implicit rules: device word of the context ("a row exchange was needed"); NULL = LDS kernels only
-    int epoch;          // implicit rules: 1 .. 2^23, different for consecutive calls on a context (0: none); see implicit_midpoint_kernel
+    int epoch;          // implicit rules: 1 .. 2^22, different for consecutive calls on a context (0: none); see implicit_midpoint_kernel.  A captured
+                        // graph bakes ONE epoch into its kernel arguments: replays stay correct (the tile words are rewritten by every call) but may lose
+                        // the gated pass's one-load early exit when a stale gate[0] happens to equal that epoch (it then scans its tile words)
     const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
-                              // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED and the caller loops over the batches
+                              // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED BEFORE launching anything and the caller
+                              // loops over the batches
 };
 
 // per-family entry points (one translation unit each so they compile in parallel)

@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "kernels.hpp"
 #include "cascade.hpp"
@@ -89,53 +90,76 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// host MultiDesc -> the kernel-argument table (tile prefix sums); returns the total number of tiles
-template <class T> long long fill_multi(const MultiDesc& md, MultiBatch<T>& mb) {
-    mb.nb = md.nb;
-    long long acc = 0;
-    for (int b = 0; b < MULTI_MAXB; ++b) {
-        const bool live = b < md.nb;
-        mb.tile0[b] = acc;
-        mb.N[b] = live ? md.N[b] : 0;
-        mb.Z[b] = live ? (const T*)md.Z[b] : nullptr; mb.t[b] = live ? md.t[b] : nullptr; mb.dt[b] = live ? md.dt[b] : nullptr;
-        mb.J[b] = live ? (T*)md.J[b] : nullptr; mb.Y[b] = live ? (T*)md.Y[b] : nullptr;
-        if (live) acc += (md.N[b] + TILE - 1) / TILE;
-    }
-    mb.tile0[MULTI_MAXB] = acc;
-    for (int b = md.nb; b <= MULTI_MAXB; ++b) mb.tile0[b] = acc;
-    return acc;
+// host MultiDesc -> the kernel argument (same bytes: MultiPod is the image of MultiBatch<T>)
+template <class T> MultiBatch<T> to_multi_batch(const MultiDesc& md) {
+    static_assert(sizeof(MultiBatch<T>) == sizeof(MultiPod) && sizeof(MultiRec<T>) == sizeof(MultiRecPod) && MULTI_MAXB == MULTI_INLINE, "MultiPod is the byte image of MultiBatch<T>");
+    MultiBatch<T> mb;
+    std::memcpy(static_cast<void*>(&mb), &md.pod, sizeof mb);
+    return mb;
 }
-inline bool multi_aligned16(const MultiDesc& md) {
-    for (int b = 0; b < md.nb; ++b) if (!aligned16(md.J[b]) || !aligned16(md.Y[b])) return false;
-    return true;
+template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int launch_split_multi(const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+    constexpr int threads = (Plan::NG + NC) * TILE;
+    hipLaunchKernelGGL(kern, dim3(tile_grid(lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    return hip_status(hipGetLastError());
 }
-// several packed trajectories, one launch: the ForwardAD kernels only (the path BASELINE's small-batch configs take)
+template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = JacLds<Fn, T, Plan>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    auto kern = jac_tile_multi_kernel<Fn, T, Plan, Body>;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(tile_grid(lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    return hip_status(hipGetLastError());
+}
+// several packed trajectories, one launch: the same kernel choice as launch_jacobian below, every body on a MultiBatch
 template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff, const LaunchArgs& a) {
     using Fn = Fun<Mdl, RULE>;
     using T = typename Fn::T;
     constexpr int NZ = Fn::NX + Fn::NU;
-    if (diff != RDHIP_FORWARD_AD) return RDHIP_ERR_UNSUPPORTED;
+    using DefPlan = ContiguousPlan<NZ, (NZ >= 4 ? 4 : NZ)>;
+    constexpr bool split_fits = NZ > 10 && SplitLds<Fn, T, DefPlan, 4>::BYTES <= 160 * 1024;
     Fn fn{m};
-    MultiBatch<T> mb;
-    const long long ntiles = fill_multi<T>(*a.multi, mb);
+    const long long ntiles = a.multi->pod.total;
     if (ntiles == 0) return RDHIP_OK;
-    if constexpr (NZ <= 10) {
-        constexpr size_t lds = SmallLds<Fn, T>::BYTES;
-        auto kern = jac_ad_small_multi_kernel<Fn, T>;
-        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, mb);
-        return hip_status(hipGetLastError());
-    } else if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
-        using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
-        constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
-        if (!multi_aligned16(*a.multi)) return RDHIP_ERR_UNSUPPORTED;
-        constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
-        auto kern = jac_ad_split_multi_kernel<Fn, T, Plan, NC>;
-        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        constexpr int threads = (Plan::NG + NC) * TILE;
-        hipLaunchKernelGGL(kern, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, mb);
-        return hip_status(hipGetLastError());
-    } else return RDHIP_ERR_UNSUPPORTED;
+    const bool al = a.multi->aligned16;
+    if (diff == RDHIP_FORWARD_AD) {
+        if constexpr (NZ <= 10) {
+            constexpr size_t lds = SmallLds<Fn, T>::BYTES;
+            auto kern = jac_ad_small_multi_kernel<Fn, T>;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+            return hip_status(hipGetLastError());
+        } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
+            using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+            constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+            if constexpr (NC > 0) { if (al) return launch_split_multi<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>, (sizeof(T) == 4 ? 4 : 1)>(fn, a); }
+            return launch_tile_multi<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, a);
+        } else {
+            if constexpr (split_fits) { if (al) return launch_split_multi<Fn, T, DefPlan, 4, AdLoopBody<Fn, T, DefPlan>>(fn, a); }
+            return launch_tile_multi<Fn, T, DefPlan, AdLoopBody<Fn, T, DefPlan>>(fn, a);
+        }
+    } else if (diff == RDHIP_FINITE_DIFF) {
+        if constexpr (RULE != RULE_CONTINUOUS && Cascade<Mdl>::NB > 1 && FdPlanOf<Mdl>::value) {
+            using Plan = typename FdPlanOf<Mdl>::Plan;
+            if (al) return launch_split_multi<Fn, T, Plan, 4, FdCascadeBody<Fn, T, Plan, Cascade<Mdl>>>(fn, a);
+        }
+        if constexpr (split_fits) { if (al) return launch_split_multi<Fn, T, DefPlan, 4, FdBody<Fn, T, DefPlan>>(fn, a); }
+        return launch_tile_multi<Fn, T, DefPlan, FdBody<Fn, T, DefPlan>>(fn, a);
+    } else if (diff == RDHIP_USER_DEFINED) {
+        if constexpr (Mdl::HAS_USER_JACOBIAN) {
+            if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
+                using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+                constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+                if (al) return launch_split_multi<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, a);
+            }
+            return launch_tile_multi<Fn, T, DefPlan, ChainBody<Fn, T, DefPlan>>(fn, a);
+        }
+        else return RDHIP_ERR_NOT_IMPLEMENTED;
+    }
+    return RDHIP_ERR_INVALID_ARG;
 }
 
 template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const LaunchArgs& a) {

@@ -48,12 +48,38 @@ struct JitModel {
     // declared block structure (jit_set_cascade; models.hpp Cascade<>): state component -> block, control -> first block that reads it
     int cas_nb = 0;
     std::vector<int> cas_state, cas_control;
-    bool cas_checked = false;                             // the declaration has been verified against the model's Jacobian pattern (first GPU use)
+    // the declaration has been verified against the model's Jacobian pattern (first GPU use).  Read and written under `vmu` only: a second host
+    // thread that arrives while the check is running waits for its verdict instead of launching cascade kernels on an unverified declaration.
+    bool cas_checked = false;
+    std::mutex vmu;
 };
 
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
        JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12,
-       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16, JOP_IMPLICIT_ROLLOUT_CAS = 17 };   // 5, 6, 11: element-wise fallbacks for unaligned outputs
+       JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16, JOP_IMPLICIT_ROLLOUT_CAS = 17,
+       JOP_ROLLOUT_PLAIN = 18,
+       JOP_MULTI = 32 };           // + JOP_MULTI: the same Jacobian operation over a MultiBatch (rdhip_jacobian_multi), ops 2 - 6 and 11   // 5, 6, 11: element-wise fallbacks for unaligned outputs; 18: one lane per trajectory whatever the model declares
+
+// CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp) of a declared block structure for a rule with `ns` stage points: ring of published stage points +
+// the IO wavefront's double-buffered control / time / state tiles + flags.  The cascade kernels exist for 1 <= m <= 8, n <= 16 (the IO wavefront's lane
+// groups) and only while this fits the 160 KiB of a gfx950 CU; a declaration that does not fit keeps the plain kernels (cascade_fits).
+static size_t cascade_lds_bytes(const JitModel& M, int ns, int dtype) {
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4;
+    auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
+    const int R = 4, S = 4;
+    int npub = 0; for (int i = 0; i < M.n; ++i) npub += M.cas_state[i] < M.cas_nb - 1 ? 1 : 0;
+    size_t units = ((size_t)npub * ts + 15) / 16; if (units % 2 == 0) ++units;               // lane-major ring: lane stride = an odd number of 16-byte units ...
+    const size_t in_e = (size_t)S * 64 * (M.m | 1), out_e = (size_t)S * 64 * (M.n | 1);
+    const size_t padded = (size_t)ns * 64 * (units * 16 / ts);
+    const bool lane_major = npub > 0 && a16(R * padded * ts) + a16(2 * in_e * ts) + 2 * (size_t)2 * S * 64 * 8 + a16(2 * out_e * ts) + 64 <= 160 * 1024;   // ... where it fits (CascadeLds::LANE_MAJOR)
+    const size_t ring_slot = lane_major ? padded : (size_t)ns * npub * 64, ts_elems = (size_t)2 * S * 64;
+    const size_t in_off = a16(R * ring_slot * ts), ts_off = in_off + a16(2 * in_e * ts), out_off = ts_off + 2 * ts_elems * 8, flag_off = out_off + a16(2 * out_e * ts);
+    return flag_off + 64;
+}
+static int rule_stage_count(int rule) { return (rule == RDHIP_EULER || rule == RDHIP_IMPLICIT_MIDPOINT) ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4; }
+static bool cascade_fits(const JitModel& M, int rule, int dtype) {
+    return M.cas_nb > 1 && M.m >= 1 && M.m <= 8 && M.n <= 16 && cascade_lds_bytes(M, rule_stage_count(rule), dtype) <= 160 * 1024;
+}
 
 static std::string rot_start_expr(const JitModel& M) {
     std::ostringstream e;
@@ -73,8 +99,9 @@ static std::string program_source(const JitModel& M) {
         s << "template <class T_> struct Cascade<UserModel<T_> > {\n    static constexpr int NB = " << M.cas_nb << ";\n"
           << "    static constexpr int block_of(int i) { constexpr int b[" << M.n << "] = {";
         for (int i = 0; i < M.n; ++i) s << (i ? ", " : "") << M.cas_state[i];
-        s << "}; return b[i]; }\n    static constexpr int control_block(int j) { constexpr int b[" << M.m << "] = {";
+        s << "}; return b[i]; }\n    static constexpr int control_block(int j) { constexpr int b[" << (M.m > 0 ? M.m : 1) << "] = {";
         for (int j = 0; j < M.m; ++j) s << (j ? ", " : "") << M.cas_control[j];
+        if (M.m == 0) s << "0";
         s << "}; return b[j]; }\n};\n";
     }
     s << "}\n";
@@ -99,7 +126,7 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
         s << ", 4>";
         return s.str();
     }
-    if (op >= JOP_IMPLICIT_X_REG) {          // Newton matrix in registers (implicit.hpp)
+    if (op >= JOP_IMPLICIT_X_REG && op <= JOP_IMPLICIT_ROLLOUT_REG) {          // Newton matrix in registers (implicit.hpp)
         s << "rd::" << (op == JOP_IMPLICIT_ROLLOUT_REG ? "implicit_rollout_reg_kernel" : "implicit_midpoint_reg_kernel") << "<rd::UserModel<" << T << ">, " << T;
         if (op == JOP_IMPLICIT_X_REG) s << ", false"; else if (op == JOP_IMPLICIT_J_REG) s << ", true";
         s << ">";
@@ -131,16 +158,44 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
     fn << "rd::Fun<rd::UserModel<" << T << ">, " << rule << ">";
     const int ng = nz >= 4 ? 4 : nz;
     std::ostringstream plan;
-    if (!M.plan_wave.empty() && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || (op == JOP_JAC_FD && M.cas_nb > 1 && rule != RDHIP_CONTINUOUS)) && nz > 10) {     // cost-balanced column -> wave table
+    const int bop = op >= JOP_MULTI ? op - JOP_MULTI : op;
+    if (!M.plan_wave.empty() && (bop == JOP_JAC_AD || bop == JOP_JAC_CHAIN || (bop == JOP_JAC_FD && M.cas_nb > 1 && rule != RDHIP_CONTINUOUS)) && nz > 10) {     // cost-balanced column -> wave table
         if (M.plan_split > 0) plan << "rd::TablePlanS<" << nz << ", 4, " << M.plan_value_wave << ", " << M.plan_split;
         else plan << "rd::TablePlan<" << nz << ", 4, " << M.plan_value_wave;
         for (int c = 0; c < nz; ++c) plan << ", " << M.plan_wave[c];
         plan << ">";
     } else plan << "rd::ContiguousPlan<" << nz << ", " << ng << ">";
+    if (op >= JOP_MULTI) {           // several packed trajectories, one launch: the generic multi kernels on the body the single-batch kernel uses
+        const int base = op - JOP_MULTI;
+        const std::string F = fn.str(), P = plan.str(), cont = "rd::ContiguousPlan<" + std::to_string(nz) + ", " + std::to_string(ng) + ">";
+        const std::string cas = std::string("rd::Cascade<rd::UserModel<") + T + "> >";
+        auto split = [&](const std::string& body) { s << "rd::jac_split_multi_kernel<" << F << ", " << T << ", " << P << ", 4, " << body << ", 1>"; };
+        auto tile = [&](const std::string& body_name) { s << "rd::jac_tile_multi_kernel<" << F << ", " << T << ", " << cont << ", rd::" << body_name << "<" << F << ", " << T << ", " << cont << "> >"; };
+        switch (base) {
+            case JOP_JAC_AD:
+                if (nz <= 10) s << "rd::jac_ad_small_multi_kernel<" << F << ", " << T << ">";
+                else split("rd::AdUnrolledBody<" + F + ", " + T + ", " + P + ">");
+                break;
+            case JOP_JAC_FD:
+                if (nz <= 10) tile("FdBody");
+                else if (M.cas_nb > 1 && rule != RDHIP_CONTINUOUS) split("rd::FdCascadeBody<" + F + ", " + T + ", " + P + ", " + cas + ">");
+                else split("rd::FdBody<" + F + ", " + T + ", " + P + ">");
+                break;
+            case JOP_JAC_CHAIN:
+                if (nz <= 10) tile("ChainBody");
+                else split("rd::ChainUnrolledBody<" + F + ", " + T + ", " + P + ">");
+                break;
+            case JOP_JAC_AD_LOOP: tile("AdLoopBody"); break;
+            case JOP_JAC_FD_LOOP: tile("FdBody"); break;
+            default: tile("ChainBody"); break;
+        }
+        return s.str();
+    }
     switch (op) {
         case JOP_EVAL: s << "rd::eval_kernel<" << fn.str() << ", " << T << ">"; break;
+        case JOP_ROLLOUT_PLAIN: s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">"; break;
         case JOP_ROLLOUT:
-            if (M.cas_nb > 1) s << "rd::rollout_cascade_kernel<" << fn.str() << ", " << T << ", rd::Cascade<rd::UserModel<" << T << "> >, 4>";
+            if (cascade_fits(M, rule, dtype)) s << "rd::rollout_cascade_kernel<" << fn.str() << ", " << T << ", rd::Cascade<rd::UserModel<" << T << "> >, 4>";
             else s << "rd::rollout_kernel<" << fn.str() << ", " << T << ">";
             break;
         case JOP_JAC_AD:       // small models: all columns per lane; larger ones: the split-role kernel with compile-time columns
@@ -237,11 +292,12 @@ static int jit_compile(JitModel& M, int op, int rule, int dtype, const std::stri
     return RDHIP_OK;
 }
 
-static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
+static int jit_get(JitModel& M, int op_, int rule, int dtype, JitKernel** out) {
     std::lock_guard<std::mutex> g(M.mu);
-    std::ostringstream k; k << op << ":" << rule << ":" << dtype;
+    std::ostringstream k; k << op_ << ":" << rule << ":" << dtype;
     const std::string key = k.str();
-    int rc = jit_compile(M, op, rule, dtype, key); if (rc) return rc;
+    int rc = jit_compile(M, op_, rule, dtype, key); if (rc) return rc;
+    const int op = op_ >= JOP_MULTI ? op_ - JOP_MULTI : op_;        // block size / LDS bytes: those of the single-batch kernel with the same body
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { M.err = "hipGetDevice failed"; return RDHIP_ERR_NO_DEVICE; }
     std::ostringstream kd; kd << key << "@" << dev;
     auto it = M.loaded.find(kd.str());
@@ -254,18 +310,11 @@ static int jit_get(JitModel& M, int op, int rule, int dtype, JitKernel** out) {
         const bool split = nz > 10 && (op == JOP_JAC_AD || op == JOP_JAC_CHAIN || op == JOP_JAC_FD || op == JOP_IMPLICIT_IFT);
         auto a16 = [](size_t b) { return (b + 15) / 16 * 16; };
         if (op == JOP_EVAL) jk.block = 256;
-        else if ((op == JOP_ROLLOUT || op == JOP_IMPLICIT_ROLLOUT_CAS) && M.cas_nb > 1) {          // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp), one wavefront per block + the IO wavefront
-            const int ns = (op == JOP_IMPLICIT_ROLLOUT_CAS || rule == RDHIP_EULER) ? 1 : rule == RDHIP_RK2 ? 2 : rule == RDHIP_RK3 ? 3 : 4, R = 4, S = 4;
-            int npub = 0; for (int i = 0; i < M.n; ++i) npub += M.cas_state[i] < M.cas_nb - 1 ? 1 : 0;
-            size_t units = ((size_t)npub * ts + 15) / 16; if (units % 2 == 0) ++units;               // lane-major ring: lane stride = an odd number of 16-byte units ...
-            const size_t in_e = (size_t)S * 64 * (M.m | 1), out_e = (size_t)S * 64 * (M.n | 1);
-            const size_t padded = (size_t)ns * 64 * (units * 16 / ts);
-            const bool lane_major = npub > 0 && a16(R * padded * ts) + a16(2 * in_e * ts) + 2 * (size_t)2 * S * 64 * 8 + a16(2 * out_e * ts) + 64 <= 160 * 1024;   // ... where it fits (CascadeLds::LANE_MAJOR)
-            const size_t ring_slot = lane_major ? padded : (size_t)ns * npub * 64, in_elems = (size_t)S * 64 * (M.m | 1), out_elems = (size_t)S * 64 * (M.n | 1), ts_elems = (size_t)2 * S * 64;
-            const size_t in_off = a16(R * ring_slot * ts), ts_off = in_off + a16(2 * in_elems * ts), out_off = ts_off + 2 * ts_elems * 8, flag_off = out_off + a16(2 * out_elems * ts);
-            jk.block = (M.cas_nb + 1) * 64; jk.lds = flag_off + 64;
+        else if ((op == JOP_ROLLOUT || op == JOP_IMPLICIT_ROLLOUT_CAS) && cascade_fits(M, op == JOP_IMPLICIT_ROLLOUT_CAS ? RDHIP_IMPLICIT_MIDPOINT : rule, dtype)) {
+            // one wavefront per block + the IO wavefront
+            jk.block = (M.cas_nb + 1) * 64; jk.lds = cascade_lds_bytes(M, rule_stage_count(op == JOP_IMPLICIT_ROLLOUT_CAS ? RDHIP_IMPLICIT_MIDPOINT : rule), dtype);
         }
-        else if (op == JOP_ROLLOUT || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op != JOP_IMPLICIT_IFT && op != JOP_IMPLICIT_ROLLOUT_CAS)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
+        else if (op == JOP_ROLLOUT || op == JOP_ROLLOUT_PLAIN || op == JOP_IMPLICIT_ERR || (op >= JOP_IMPLICIT_X_REG && op <= JOP_IMPLICIT_ROLLOUT_REG)) { jk.block = 64; if (op == JOP_IMPLICIT_J_REG) jk.lds = (size_t)64 * ((4 * ny) | 1) * ts; }    // ImplicitRegOps::LDS_BYTES
         else if (op >= JOP_IMPLICIT_X && op <= JOP_IMPLICIT_ROLLOUT) {      // ImplicitLds<Mdl,T>: KP knot points per wave, BYTES
             const size_t lane_bytes = (size_t)((ny * ny + ny) | 1) * ts + 16 * 4;
             int kp = 64;
@@ -310,6 +359,7 @@ static void retire_compiled(JitModel& M) {
 // control_block is <= b.  nb <= 1 removes the declaration.  The declaration is VERIFIED against the model on first GPU use (jit_verify_cascade).
 int jit_set_cascade(void* h, int nb, const int* state_block, const int* control_block) {
     JitModel& M = *static_cast<JitModel*>(h);
+    std::lock_guard<std::mutex> vg(M.vmu);
     std::lock_guard<std::mutex> g(M.mu);
     if (nb <= 1) { M.cas_nb = 0; M.cas_state.clear(); M.cas_control.clear(); M.cas_checked = false; retire_compiled(M); return RDHIP_OK; }
     if (nb > 6 || !state_block || !control_block) { M.err = "cascade: 2..6 blocks, non-NULL tables"; return RDHIP_ERR_INVALID_ARG; }
@@ -412,9 +462,18 @@ int jit_eval(void* h, int rule, int dtype, const LaunchArgs& a) {
 // continuous ForwardAD Jacobian is evaluated at 32 points and every entry that the declaration says is structurally zero -- a row of block a
 // against a state column of a block > a, or against a control whose control_block is > a -- must be exactly zero (tangents propagate exact
 // zeros; non-finite entries are skipped).
+static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const LaunchArgs& a);
 static int jit_verify_cascade(JitModel& M, hipStream_t stream) {
-    if (M.cas_nb <= 1 || M.cas_checked) return RDHIP_OK;
-    M.cas_checked = true;                                  // (the check itself goes through jit_jacobian)
+    if (M.cas_nb <= 1) return RDHIP_OK;
+    std::lock_guard<std::mutex> vg(M.vmu);                 // (M.mu is taken inside by jit_get; set_cascade resets cas_checked under both)
+    if (M.cas_checked) return RDHIP_OK;
+    // the check allocates, copies and synchronises: none of that may happen on a capturing stream (it would invalidate the capture)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        M.err = "the declared cascade has not been verified yet and the stream is capturing: run this call (or any rollout / Jacobian of the model) once before rdhip_graph_begin_capture";
+        return RDHIP_ERR_INVALID_ARG;
+    }
+    (void)hipGetLastError();
     const int n = M.n, m = M.m, nz = n + m, NP = 32;
     std::vector<double> Z((size_t)NP * nz), t(NP, 0.3), dt(NP, 0.1), J((size_t)NP * n * nz);
     unsigned long long st = 0x9E3779B97F4A7C15ull;
@@ -425,11 +484,11 @@ static int jit_verify_cascade(JitModel& M, hipStream_t stream) {
         hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dT, t.data(), NP * 8, hipMemcpyHostToDevice) == hipSuccess &&
         hipMemcpy(dD, dt.data(), NP * 8, hipMemcpyHostToDevice) == hipSuccess) {
         LaunchArgs a{}; a.stream = stream; a.N = NP; a.Z = dZ; a.t = (const double*)dT; a.dt = (const double*)dD; a.J = dJ;
-        rc = jit_jacobian(&M, RDHIP_CONTINUOUS, RDHIP_FORWARD_AD, RDHIP_F64, a);
+        rc = jit_jacobian_impl(M, RDHIP_CONTINUOUS, RDHIP_FORWARD_AD, RDHIP_F64, a);
         if (rc == RDHIP_OK && (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(J.data(), dJ, J.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = RDHIP_ERR_HIP;
     } else M.err = "cascade check: device allocation failed";
     (void)hipFree(dZ); (void)hipFree(dT); (void)hipFree(dD); (void)hipFree(dJ);
-    if (rc) { M.cas_checked = false; return rc; }
+    if (rc) return rc;
     for (int k = 0; k < NP; ++k)
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < nz; ++c) {
@@ -441,17 +500,20 @@ static int jit_verify_cascade(JitModel& M, hipStream_t stream) {
                     char msg[256];
                     snprintf(msg, sizeof msg, "the declared cascade is not one: d xdot[%d] / d %s[%d] = %g, but xdot[%d] is in block %d and that %s in block %d",
                              i, c < n ? "x" : "u", c < n ? c : c - n, v, i, M.cas_state[i], c < n ? "state" : "control enters", col_block);
-                    M.err = msg; M.cas_checked = false;
+                    M.err = msg;
                     return RDHIP_ERR_INVALID_ARG;
                 }
             }
+    M.cas_checked = true;
     return RDHIP_OK;
 }
 int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
-    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
-    JitKernel* k; int rc = jit_get(M, JOP_ROLLOUT, rule, dtype, &k); if (rc) return rc;
+    // the cascade kernel where the declaration fits it (cascade_fits) and the IO wavefront's 32-bit lane offsets reach (launch_rollout applies the same bound)
+    const bool cas = cascade_fits(M, rule, dtype) && a.K < (1LL << 26) && a.N < (1LL << 26);
+    if (cas) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
+    JitKernel* k; int rc = jit_get(M, cas ? JOP_ROLLOUT : JOP_ROLLOUT_PLAIN, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long K = a.K, Mt = a.N, sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
     const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; const void* X0 = a.X0;
@@ -460,11 +522,25 @@ int jit_rollout(void* h, int rule, int dtype, const LaunchArgs& a) {
 }
 int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
-    if (a.N == 0) return RDHIP_OK;
-    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
+    if (a.N == 0 && !a.multi) return RDHIP_OK;
+    if (M.cas_nb > 1) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
+    return jit_jacobian_impl(M, rule, diff, dtype, a);
+}
+static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const LaunchArgs& a) {
     int op = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.J) | reinterpret_cast<uintptr_t>(a.Y)) & 15) == 0;
     if (M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);   // the split-role kernels copy 16-B units
+    if (a.multi) {                    // rdhip_jacobian_multi: the same body over a MultiBatch (kernel argument = the MultiPod image)
+        if (a.multi->pod.total == 0) return RDHIP_OK;
+        int mop = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
+        if (M.n + M.m > 10 && !a.multi->aligned16) mop = (mop == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (mop == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);
+        JitKernel* km; int rcm = jit_get(M, JOP_MULTI + mop, rule, dtype, &km); if (rcm) return rcm;
+        std::vector<unsigned char> fnm; pack_params(M, dtype, fnm);
+        MultiPod pod = a.multi->pod;
+        void* margs[] = {fnm.data(), &pod};
+        const unsigned gridm = km->small ? (unsigned)((pod.total + 3) / 4) : tile_grid(km->lds, km->block, pod.total);
+        return launch(M, km, gridm, a.stream, margs);
+    }
     JitKernel* k; int rc = jit_get(M, op, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* J = a.J; void* Y = a.Y;
@@ -493,7 +569,7 @@ int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a) {
 int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     JitModel& M = *static_cast<JitModel*>(h);
     if (a.N == 0) return RDHIP_OK;
-    if (M.cas_nb > 1 && !M.cas_checked) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
+    if (M.cas_nb > 1) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
     const int op = mode == 0 ? JOP_IMPLICIT_X : mode == 1 ? JOP_IMPLICIT_J : mode == 2 ? JOP_IMPLICIT_ERR : JOP_IMPLICIT_ROLLOUT;
     JitKernel* k; int rc = jit_get(M, op, RDHIP_IMPLICIT_MIDPOINT, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
@@ -535,7 +611,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
     }
     // mode 3 with a declared cascade: the rollout along the cascade (dispatch.hpp launch_implicit does the same for the compiled-in rigid bodies), then
     // the exact kernel gated on the flag word
-    if (mode == 3 && a.flag && M.cas_nb > 1 && K < (1LL << 26) && N < (1LL << 26)) {
+    if (mode == 3 && a.flag && cascade_fits(M, RDHIP_IMPLICIT_MIDPOINT, dtype) && K < (1LL << 26) && N < (1LL << 26)) {
         if (K == 0) return RDHIP_OK;
         JitKernel* kc; rc = jit_get(M, JOP_IMPLICIT_ROLLOUT_CAS, RDHIP_IMPLICIT_MIDPOINT, dtype, &kc); if (rc) return rc;
         int* flag = a.flag;

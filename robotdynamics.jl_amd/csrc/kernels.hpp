@@ -180,6 +180,90 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
 // No inter-workgroup data reuse exists, so no XCD-aware remap is needed: each tile is touched by exactly one workgroup.
 // ------------------------------------------------------------------------------------------------------------
 
+// ---- where a tile lives ---------------------------------------------------------------------------------------------
+// The tile loops walk GLOBAL tile indices; a batch descriptor maps one to the arrays it belongs to.  SingleBatch: one packed trajectory
+// (rdhip_jacobian).  MultiBatch: any number of independent packed trajectories -- different arrays, e.g. 1 024 trajectories of 101 knot points
+// -- enumerated back to back by the same persistent loop, so that many small batches cost one bandwidth-regime launch instead of one
+// launch-bound kernel each (rdhip_jacobian_multi).  Up to MULTI_MAXB batches travel in the kernel arguments (no device-side table to keep
+// alive, and a captured graph node carries it); more than that sit in a device table (`ext`: one 64-byte record per batch, `ext_tile0`: the
+// first global tile of every batch, compact so that the binary search stays inside the scalar cache).  Batches of equal size (the common
+// case: M trajectories of K knot points each) need no search at all: batch = tile / tiles-per-batch.  Everything here is wave-uniform
+// (scalar loads / SALU).
+template <class T> struct TileRef {
+    const T* Z; const double* t; const double* dt; T* J; T* Y;
+    long long N;      // knot points of the batch the tile belongs to
+    long long k0;     // first knot point of the tile inside that batch
+};
+template <class T> struct SingleBatch {
+    static constexpr bool RING = false;    // at() is arithmetic
+    long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
+    RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
+    RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
+};
+constexpr int MULTI_MAXB = 32;
+template <class T> struct MultiRec { const T* Z; const double* t; const double* dt; T* J; T* Y; long long N; long long pad[2]; };   // 64 bytes: one scalar load
+template <class T> struct MultiBatch {
+    // at() is two dependent memory round trips: the split-role loop resolves the tiles of a workgroup's first iterations IN PARALLEL before its
+    // first barrier (one copy-wave lane per iteration) and hands them to everybody through an LDS table (jac_split_loop), so that no lookup sits
+    // in front of a compute wave's input prefetch or between a copy wave's stores
+#if defined(RD_MULTI_NO_RING)     // tuning: every wave resolves its own tiles
+    static constexpr bool RING = false;
+#else
+    static constexpr bool RING = true;
+#endif
+    int nb;
+    int uniform;                           // > 0: every batch has this many tiles (no search)
+    long long total;                       // tiles of all batches (< 2^31)
+    const MultiRec<T>* ext;                // device table of nb records, or nullptr: the inline table below
+    const unsigned* ext_tile0;             // device: first global tile of batch b, nb + 1 entries
+    int group;                             // ext: batches per entry of the coarse inline table (ceil(nb / MULTI_MAXB))
+    int pad_;
+    unsigned tile0[MULTI_MAXB + 1];        // inline: first global tile of batch b; ext: of batch b * group; entries past the end = total
+    long long N[MULTI_MAXB];
+    const T* Z[MULTI_MAXB]; const double* t[MULTI_MAXB]; const double* dt[MULTI_MAXB]; T* J[MULTI_MAXB]; T* Y[MULTI_MAXB];
+    RD_DEV long long ntiles() const { return total; }
+    // Two memory round trips whatever the number of batches: all entries of a level are requested at once and counted branch-free (a
+    // compare-and-advance loop would be one DEPENDENT scalar load per batch passed -- microseconds on a cold scalar cache, in front of the
+    // first input load of a workgroup)
+    RD_DEV TileRef<T> at(long long tile) const {
+        const unsigned tl = (unsigned)tile;
+        int c = 0;
+#pragma unroll
+        for (int i = 1; i <= MULTI_MAXB; ++i) c += (tl >= tile0[i]) ? 1 : 0;
+        if (!ext) return TileRef<T>{Z[c], t[c], dt[c], J[c], Y[c], N[c], (long long)(tl - tile0[c]) * TILE};
+        // The device table is read through CONSTANT-address-space pointers: it does not change while the kernel runs, and only loads the
+        // compiler knows to be invariant become scalar loads.  As plain global loads (the kernel stores to global memory, so nothing proves
+        // them unclobbered) every field of the TileRef -- and, through the merge with the inline path, of every TileRef -- lived in VECTOR
+        // registers: 14 more VGPRs across the column code, which is at the 256-register limit and spilled 92 bytes per lane.
+        typedef const unsigned __attribute__((address_space(4))) * CU32;
+        typedef const MultiRec<T> __attribute__((address_space(4))) * CRec;
+        CU32 et0 = (CU32)(unsigned long long)ext_tile0;
+        CRec er = (CRec)(unsigned long long)ext;
+        int b; unsigned first;
+        if (uniform > 0) { b = (int)(tl / (unsigned)uniform); first = (unsigned)b * (unsigned)uniform; }
+        else {
+            const int lo = c * group;
+            if (group <= MULTI_MAXB) {                                 // nb <= 1 024: the group's entries in one go
+                int k = 0;
+#pragma unroll
+                for (int i = 1; i < MULTI_MAXB; ++i) {                 // (fixed trip count: independent loads, requested together)
+                    const int j = lo + i; const bool in = i < group && j < nb;
+                    const unsigned v = et0[in ? j : lo];
+                    k += (in && tl >= v) ? 1 : 0;
+                }
+                b = lo + k;
+            } else {
+                int l = lo, h = lo + group < nb ? lo + group : nb;     // tile0[l] <= tile < tile0[h]
+                while (h - l > 1) { const int mid = (l + h) >> 1; if (tl >= et0[mid]) l = mid; else h = mid; }
+                b = l;
+            }
+            first = et0[b];
+        }
+        const T* rZ = er[b].Z; const double* rt = er[b].t; const double* rdt = er[b].dt; T* rJ = er[b].J; T* rY = er[b].Y; const long long rN = er[b].N;
+        return TileRef<T>{rZ, rt, rdt, rJ, rY, rN, (long long)(tl - first) * TILE};
+    }
+};
+
 // Default plan: one chunk, contiguous column ranges per wave, f(z) emitted by wave 0.
 template <int NZ, int NG_> struct ContiguousPlan {
     static constexpr int NG = NG_, NCHUNK = 1;
@@ -276,9 +360,8 @@ template <class T> RD_DEV void row_copy(const T* __restrict__ src, T* __restrict
 // loads of an iteration -- the prefetch of the NEXT tile's z/t/dt -- are issued at the top of the iteration and
 // consumed right before the copy-out; the copy-out stores are the last VMEM operations of the iteration and nobody
 // waits for them until the next iteration's prefetch is consumed, i.e. they drain behind a whole compute phase.
-template <class Fn, class T, class Plan, class Body>
-RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                          T* __restrict__ J, T* __restrict__ Y) {
+template <class Fn, class T, class Plan, class Body, class BT>
+RD_DEV void jac_tile_loop(const Fn& fn, const BT& bt) {
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, NG = Plan::NG, NT = NG * TILE;
     using L = JacLds<Fn, T, Plan>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,43 +369,47 @@ RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, co
     T* zs = out + L::OUT_ELEMS;                                          // z tile
     double* ts = reinterpret_cast<double*>(zs + L::Z_ELEMS);             // t[64], dt[64]
     const int lane = threadIdx.x & 63;
-    const long long ntiles = (N + TILE - 1) / TILE;
+    const long long ntiles = bt.ntiles();
     constexpr int ZPT = (TILE * NZ + NT - 1) / NT;   // z elements each thread stages per tile
 
     JacFrame<Fn, T> fr;
     fr.g = threadIdx.x >> 6;
     fr.row = out + lane * L::RS;
     fr.yrow = nullptr;
-    fr.want_y = (Y != nullptr);
     fr.first = false;                                // (no early part in this loop: every wave computes and copies)
 
     long long tile = blockIdx.x;
     if (tile >= ntiles) return;
+    TileRef<T> cur = bt.at(tile);
     {   // first tile: stage z, t, dt
-        const long long k0 = tile * TILE;
-        const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
-        const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+        const long long k0 = cur.k0;
+        const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
+        const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
         const int idx = threadIdx.x & (TILE - 1);
         const double t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
-        stage_in<T, TILE * NZ, NT>(Z + k0 * NZ, zs, nk * NZ, threadIdx.x);
+        stage_in<T, TILE * NZ, NT>(cur.Z + k0 * NZ, zs, nk * NZ, threadIdx.x);
         if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
-        const long long k0 = tile * TILE;
-        const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
+        const long long k0 = cur.k0;
+        const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
+        fr.want_y = (cur.Y != nullptr);
         // ---- issue the prefetch of the next tile's inputs (registers; consumed after the compute phase)
         const long long nxt = tile + gridDim.x;
-        const long long k1 = nxt * TILE;
-        const int nk1 = (nxt < ntiles) ? (int)((N - k1) < TILE ? (N - k1) : TILE) : 0;
+        const bool more = nxt < ntiles;
+        const TileRef<T> nx = bt.at(more ? nxt : tile);
+        const long long k1 = nx.k0;
+        const T* __restrict__ Zn = nx.Z;
+        const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
         // The loads are UNCONDITIONAL (out-of-range lanes re-read element 0): a load inside an exec-masked branch leaves a
         // "maybe pending" load at the loop back-edge, and the compiler then drains vmcnt(0) -- i.e. every store of the
         // previous copy-out -- at the top of the loop.
         T zpre[ZPT]; double tpre;
 #pragma unroll
-        for (int r = 0; r < ZPT; ++r) { const int e = r * NT + threadIdx.x; zpre[r] = Z[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
+        for (int r = 0; r < ZPT; ++r) { const int e = r * NT + threadIdx.x; zpre[r] = Zn[(e < nk1 * NZ) ? k1 * NZ + e : 0]; }
         {
-            const double* tp = (threadIdx.x < TILE) ? tt : dtt;
+            const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
             const int idx = threadIdx.x & (TILE - 1);
             tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
         }
@@ -332,8 +419,8 @@ RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, co
         const double hd = ts[TILE + kl];
         fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
         read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
-        T* Jt = J + k0 * (NY * NZ);
-        T* Yt = Y ? Y + k0 * NY : nullptr;
+        T* Jt = cur.J + k0 * (NY * NZ);
+        T* Yt = cur.Y ? cur.Y + k0 * NY : nullptr;
 #pragma unroll
         for (int ch = 0; ch < Plan::NCHUNK; ++ch) {
             switch (ch) {   // compile-time chunk index for the body
@@ -361,6 +448,7 @@ RD_DEV void jac_tile_loop(const Fn& fn, long long N, const T* __restrict__ Z, co
             }
             __syncthreads();                              // LDS output tile free again; next inputs visible
         }
+        cur = nx;
     }
 }
 
@@ -423,7 +511,7 @@ template <class Fn, class T, class Plan> struct AdUnrolledBody {
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_unrolled_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                          const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_tile_loop<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_tile_loop<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 // one Jacobian column of one knot point per lane, nothing else: the hipRTC plug-in compiles this per column and uses the code size as
@@ -469,35 +557,23 @@ template <class Fn, class T, class Plan, int NC> struct SplitLds {
     static_assert(J_ELEMS * sizeof(T) % 16 == 0 && Y_ELEMS * sizeof(T) % 16 == 0, "tile slabs must be multiples of 16 bytes");
 };
 
-// ---- where a tile lives ---------------------------------------------------------------------------------------------
-// The tile loops walk GLOBAL tile indices; a batch descriptor maps one to the arrays it belongs to.  SingleBatch: one packed trajectory
-// (rdhip_jacobian).  MultiBatch: up to MAXB independent packed trajectories -- different arrays, e.g. 16 trajectories of 4 096 knot points
-// -- enumerated back to back by the same persistent loop, so that many small batches cost one bandwidth-regime launch instead of one
-// launch-bound kernel each (rdhip_jacobian_multi).  The table travels in the kernel arguments: no device-side table to keep alive, and a
-// captured graph node carries it.  Everything here is wave-uniform (scalar loads / SALU).
-template <class T> struct TileRef {
-    const T* Z; const double* t; const double* dt; T* J; T* Y;
-    long long N;      // knot points of the batch the tile belongs to
-    long long k0;     // first knot point of the tile inside that batch
-};
-template <class T> struct SingleBatch {
-    long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
-    RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
-    RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
-};
-constexpr int MULTI_MAXB = 32;
-template <class T> struct MultiBatch {
-    int nb;
-    long long tile0[MULTI_MAXB + 1];       // first global tile of batch b; tile0[nb] = total
-    long long N[MULTI_MAXB];
-    const T* Z[MULTI_MAXB]; const double* t[MULTI_MAXB]; const double* dt[MULTI_MAXB]; T* J[MULTI_MAXB]; T* Y[MULTI_MAXB];
-    RD_DEV long long ntiles() const { return tile0[nb]; }
-    RD_DEV TileRef<T> at(long long tile) const {
-        int b = 0;
-        while (b + 1 < nb && tile >= tile0[b + 1]) ++b;
-        return TileRef<T>{Z[b], t[b], dt[b], J[b], Y[b], N[b], (tile - tile0[b]) * TILE};
-    }
-};
+// LDS table of resolved tiles (descriptors with RING): one 64-byte entry per iteration of the workgroup.  Values are wave-uniform for the
+// reader, who turns them back into scalars (v_readfirstlane) so that addresses stay "scalar base + lane offset".
+RD_DEV long long uniform64(long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+template <class T> RD_DEV void ring_put(long long* slot, const TileRef<T>& r) {
+    slot[0] = (long long)r.Z; slot[1] = (long long)r.t; slot[2] = (long long)r.dt; slot[3] = (long long)r.J; slot[4] = (long long)r.Y; slot[5] = r.N; slot[6] = r.k0;
+}
+template <class T> RD_DEV TileRef<T> ring_get(const long long* slot) {
+    long long v[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] = slot[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] = uniform64(v[i]);
+    return TileRef<T>{(const T*)v[0], (const double*)v[1], (const double*)v[2], (T*)v[3], (T*)v[4], v[5], v[6]};
+}
 
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
@@ -518,6 +594,10 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
     T* yt = reinterpret_cast<T*>(smem + L::J_BYTES);
     T* zs = reinterpret_cast<T*>(smem + L::J_BYTES + L::Y_BYTES);
     double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
+    // resolved tiles of this workgroup's iterations 0 .. RING_N - 1 (static LDS next to the dynamic tile, as many entries as fit the CU's 160 KiB)
+    constexpr int RING_FREE = (int)((160 * 1024 - L::BYTES) / 64);
+    constexpr int RING_N = !BT::RING ? 0 : RING_FREE >= 64 ? 64 : RING_FREE >= 32 ? 32 : RING_FREE >= 16 ? 16 : RING_FREE >= 8 ? 8 : 0;
+    __shared__ long long ring[RING_N > 0 ? RING_N : 1][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = bt.ntiles();
     // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  For long
@@ -575,12 +655,15 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
         }
         __syncthreads();                                   // barrier 0
-        for (; tile < tend; tile += tstep) {
+        for (int it = 0; tile < tend; tile += tstep, ++it) {
             const int nk = (int)((cur.N - cur.k0) < TILE ? (cur.N - cur.k0) : TILE);
             fr.want_y = (cur.Y != nullptr);
             const long long nxt = tile + tstep;
             const bool more = nxt < tend;
-            const TileRef<T> nx = bt.at(more ? nxt : tile);   // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
+            // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
+            TileRef<T> nx;
+            if (RING_N > 0 && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
+            else nx = bt.at(more ? nxt : tile);
             const long long k1 = nx.k0;
             const T* __restrict__ Z = nx.Z;
             const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
@@ -626,6 +709,10 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
         const V4* jsrc = reinterpret_cast<const V4*>(jt);
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
         __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
+        if constexpr (RING_N > 0) {                        // one lane per iteration, all lookups in flight together, while the compute waves fetch the first inputs
+            const long long ti = tile + (long long)ct * tstep;
+            if (ct < RING_N && ti < tend) ring_put<T>(ring[ct], bt.at(ti));
+        }
         __syncthreads();                                   // barrier 0
         bool first = ES > 0;
         // 16-byte unit u of the tile slab lies in a 128-byte line that is covered by the early columns [0, ES) of ONE row
@@ -634,8 +721,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
             const int l0 = (u >> 3) << 7, k = l0 / RB;
             return l0 + 128 <= k * RB + EB;
         };
-        for (; tile < tend; tile += tstep) {
-            const TileRef<T> cur = bt.at(tile);
+        TileRef<T> cur = bt.at(tile);
+        for (int it = 0; tile < tend; tile += tstep, ++it) {
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
@@ -666,6 +753,13 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
             for (int r = 0; r < L::YPL; ++r) { const int u = r * (NC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the tile is in registers
             __syncthreads();                               // barrier B
+            // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
+            // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
+            const long long nxt_tile = tile + tstep;
+            TileRef<T> nxt;
+            if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
+            else nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
+            __builtin_amdgcn_sched_barrier(0);
             // number of valid bytes of a ragged last tile is nk*OW*sizeof(T), a multiple of sizeof(T) only
             const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
             V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
@@ -693,6 +787,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
                     }
                 }
             }
+            cur = nxt;
         }
     }
 }
@@ -701,10 +796,16 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
-// the same kernel over several independent packed trajectories (rdhip_jacobian_multi)
-template <class Fn, class T, class Plan, int NC>
-__global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_multi_kernel(Fn fn, MultiBatch<T> mb) {
-    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, mb);
+// the same loops over several independent packed trajectories (rdhip_jacobian_multi), for ANY body: ForwardAD with compile-time or run-time columns,
+// FiniteDifference (plain or along the cascade), the UserDefined chain rule, the implicit-function-theorem columns.  MINB: minimum workgroups per
+// CU the register allocation must allow (the ForwardAD flagship keeps the occupancy of its single-batch kernel)
+template <class Fn, class T, class Plan, int NC, class Body, int MINB>
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE, MINB) jac_split_multi_kernel(Fn fn, MultiBatch<T> mb) {
+    jac_split_loop<Fn, T, Plan, NC, Body>(fn, mb);
+}
+template <class Fn, class T, class Plan, class Body>
+__global__ void __launch_bounds__(Plan::NG * TILE) jac_tile_multi_kernel(Fn fn, MultiBatch<T> mb) {
+    jac_tile_loop<Fn, T, Plan, Body>(fn, mb);
 }
 
 // ---- small batches: one tile's columns over FOUR workgroups -----------------------------------------------------------------------------
@@ -1019,7 +1120,7 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_loop_split_kern
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                      const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_tile_loop<Fn, T, Plan, AdLoopBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_tile_loop<Fn, T, Plan, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 // ---- UserDefined: the integrators' chain rule over continuous stage Jacobians -----------------------------------------
@@ -1113,7 +1214,7 @@ template <class Fn, class T, class Plan> struct ChainBody {
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_chain_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                    const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_tile_loop<Fn, T, Plan, ChainBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_tile_loop<Fn, T, Plan, ChainBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 // compile-time-column form of the chain rule for the split-role kernel: the direction w = e_C is a constant, so the stage
@@ -1260,7 +1361,7 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_split_kernel(Fn
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                 const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_tile_loop<Fn, T, Plan, FdBody<Fn, T, Plan>>(fn, N, Z, tt, dtt, J, Y);
+    jac_tile_loop<Fn, T, Plan, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 }  // namespace rd

@@ -902,6 +902,13 @@ function jacobian_multi!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.Ab
                    c.ptr, handle(fun), rulecode(fun), diffcode(diff), dtypecode(T), nb, Ns, pZ, pt, pdt, pJ, pY, sp)
     end
     check(c, rc)
+    last_multi_launches(c)
+end
+"kernel launches the last `jacobian_multi!` on `ctx` issued: 1 = fused into one launch, one (three for ImplicitMidpoint) per trajectory = the fallback"
+function last_multi_launches(c::Context)
+    k = Ref{Cint}(0)
+    check(c, ccall((:rdhip_ctx_last_multi_launches, librdhip), Cint, (Ptr{Cvoid}, Ref{Cint}), c.ptr, k))
+    Int(k[])
 end
 
 # ------------------------------------------------------------------------------------------------ several GPUs

@@ -74,6 +74,7 @@ _SIGS = {
     "rdhip_discrete_dynamics": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_jacobian_multi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_LL), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_int]),
+    "rdhip_ctx_last_multi_launches": (C.c_int, [_P, _IP]),
     "rdhip_dynamics_error": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_dynamics_error_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_error_expansion": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),

@@ -1460,6 +1460,17 @@ class PreparedJacobianMulti:
         rc = L.lib().rdhip_jacobian_multi(ctx.handle, *self._args)
         if rc:
             L.check(rc, ctx.handle)
+        self._last_ctx = ctx
+
+    @property
+    def launches(self):
+        """kernel launches the last call issued (rdhip_ctx_last_multi_launches): 1 = fused, one per trajectory = the batch-by-batch fallback"""
+        ctx = getattr(self, "_last_ctx", None)
+        if ctx is None:
+            return 0
+        k = C.c_int(0)
+        L.check(L.lib().rdhip_ctx_last_multi_launches(ctx.handle, C.byref(k)), ctx.handle)
+        return k.value
 
 
 def prepare_jacobian_multi(sig, diff, fun, Js, ys, Zs):
@@ -1467,9 +1478,11 @@ def prepare_jacobian_multi(sig, diff, fun, Js, ys, Zs):
 
 
 def jacobian_multi_(sig, diff, fun, Js, ys, Zs):
-    """One launch for the Jacobians of several independent packed trajectories: see PreparedJacobianMulti."""
-    PreparedJacobianMulti(sig, diff, fun, Js, ys, Zs)()
-    return None
+    """One launch for the Jacobians of several independent packed trajectories: see PreparedJacobianMulti.  Returns the number of kernel
+    launches the call issued (1 = fused)."""
+    call = PreparedJacobianMulti(sig, diff, fun, Js, ys, Zs)
+    call()
+    return call.launches
 
 
 def discrete_jacobian_(Q, J, model, z):

@@ -902,16 +902,21 @@ def test_baseline_config_sizes_c1_c2():
 def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
     """rdhip_jacobian_multi: several independent packed trajectories (different arrays, ragged lengths) through ONE persistent tile loop must
     give exactly what one rdhip_jacobian call per trajectory gives -- and both must match the oracle.  Covers the split-role kernel (satellite,
-    quadrotor), the all-columns-per-lane kernel (cartpole), > 32 trajectories (several table-sized launches), empty trajectories, optional
-    f(z) outputs, and the combinations without a fused kernel (FiniteDifference, implicit rule, host memory), which run batch by batch."""
+    quadrotor), the all-columns-per-lane kernel (cartpole), > 32 trajectories (the device table: ragged lengths -> binary search, equal
+    lengths -> no search), empty trajectories, optional f(z) outputs, FiniteDifference / UserDefined / unaligned slabs (fused since round 3), and
+    the combinations without a fused kernel (implicit rule, host memory), which run batch by batch."""
     rng = np.random.default_rng(123)
     sig, AD = RD.StaticReturn(), RD.ForwardAD()
     cases = ((RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6), [4096, 101, 64, 1, 65, 0, 777]),
+             (RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6), [101] * 70),                        # equal lengths, device table
+             (RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6), [37, 0, 129] * 13 + [64]),          # ragged, device table, empty batches
              (RD.Quadrotor(), O.quadrotor(), lambda N: H.rand_rigid(rng, N, 4, 0.6, 1.9), [130, 63]),
              (RD.Cartpole(), O.cartpole(), lambda N: rng.random((N, 5)), [101] * 40 + [4096, 1, 0, 65]))
-    for model, om, gen, sizes in cases:
+    for ci, (model, om, gen, sizes) in enumerate(cases):
         n, m = RD.state_dim(model), RD.control_dim(model)
         for Q, rule in ((RD.RK4, O.RK4), (RD.RK3, O.RK3)):
+            if ci in (1, 2) and Q is RD.RK3:
+                continue
             dm = RD.DiscretizedDynamics(model, Q)
             Zn = [gen(N) for N in sizes]
             ts = [0.1 * b + np.arange(N) * 0.05 for b, N in enumerate(sizes)]
@@ -922,7 +927,7 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
             Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
             Js = [RD.alloc_jacobians(dm, N, Zs[0].data).fill_(7.0) for N in sizes]
             Ys = [torch.full((N, n), 7.0, dtype=torch.float64, device="cuda") if b % 3 else None for b, N in enumerate(sizes)]
-            RD.jacobian_multi_(sig, AD, dm, Js, Ys, Zs)
+            assert RD.jacobian_multi_(sig, AD, dm, Js, Ys, Zs) == 1              # ONE launch
             for b, N in enumerate(sizes):
                 if N == 0:
                     continue
@@ -930,6 +935,8 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
                 np.testing.assert_allclose(host(Js[b]), Jo, rtol=0, atol=TOL)
                 if Ys[b] is not None:
                     np.testing.assert_allclose(host(Ys[b]), Yo, rtol=0, atol=TOL)
+                if ci in (1, 2) and b > 4:
+                    continue
                 J1 = RD.alloc_jacobians(dm, N, Zs[b].data)
                 RD.jacobian_(sig, AD, dm, J1, None, Zs[b])
                 # the same arithmetic per column as the single-batch launch; batches of <= 8 192 knot points take the column-split kernel there
@@ -939,33 +946,74 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
                     assert torch.equal(J1, Js[b])
                 else:
                     np.testing.assert_allclose(host(J1), host(Js[b]), rtol=0, atol=1e-13)
-    # no fused kernel: FiniteDifference, ImplicitMidpoint, host arrays, unaligned slabs -> batch by batch, same answers
+    # FiniteDifference, the UserDefined chain rule and unaligned slabs: fused as well (the same bodies on the batch table) -- bit-identical to
+    # the per-trajectory calls; > 32 trajectories of a rigid body and of the cartpole
+    for model, om, gen in ((RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6)), (RD.Cartpole(), O.cartpole(), lambda N: rng.random((N, 5)))):
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        sizes = [70, 33, 0, 101] + [65] * 31
+        Zn = [gen(N) for N in sizes]; ts = [np.arange(N) * 0.05 for N in sizes]; dts = [np.full(N, 0.05) for N in sizes]
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
+        for diff, odiff, tol in ((RD.FiniteDifference(), O.FORWARD_AD, 1e-6), (RD.UserDefined(), O.USER, TOL)):
+            Js = [RD.alloc_jacobians(dm, N, Zs[0].data).fill_(7.0) for N in sizes]
+            Ys = [torch.full((N, n), 7.0, dtype=torch.float64, device="cuda") for N in sizes]
+            assert RD.jacobian_multi_(sig, diff, dm, Js, Ys, Zs) == 1
+            for b in (0, 1, 3, 4, 34):
+                Jo, Yo = om.jacobian(O.RK4, odiff, Zn[b], ts[b], dts[b])
+                np.testing.assert_allclose(host(Js[b]), Jo, rtol=0, atol=tol)
+                np.testing.assert_allclose(host(Ys[b]), Yo, rtol=0, atol=TOL)
+                J1 = RD.alloc_jacobians(dm, sizes[b], Zs[b].data)
+                RD.jacobian_(sig, diff, dm, J1, None, Zs[b])
+                assert torch.equal(J1, Js[b])
     model, om = RD.Satellite(), O.satellite()
     sizes = [70, 33]
     Zn = [H.rand_rigid(rng, N, 6) for N in sizes]; ts = [np.arange(N) * 0.05 for N in sizes]; dts = [np.full(N, 0.05) for N in sizes]
     dm = RD.DiscretizedDynamics(model, RD.RK4)
     Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
     Js = [RD.alloc_jacobians(dm, N, Zs[0].data) for N in sizes]
-    RD.jacobian_multi_(sig, RD.FiniteDifference(), dm, Js, None, Zs)
+    buf = torch.zeros(sizes[0] * 247 + 1, dtype=torch.float64, device="cuda")
+    Ju = [buf[1:].view(sizes[0], 19, 13).transpose(1, 2), Js[1]]                  # 8-byte aligned slab: the run-time-row copy kernel, still one launch
+    assert RD.jacobian_multi_(sig, AD, dm, Ju, None, Zs) == 1
     for b in range(2):
-        np.testing.assert_allclose(host(Js[b]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[b], ts[b], dts[b])[0], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(Ju[b]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[b], ts[b], dts[b])[0], rtol=0, atol=TOL)
+    assert float(buf[0]) == 0.0
+    # no fused kernel: ImplicitMidpoint, host arrays -> batch by batch, same answers, and the call says so
     dmi = RD.DiscretizedDynamics(model, RD.ImplicitMidpoint)
     Ys = [torch.empty((N, 13), dtype=torch.float64, device="cuda") for N in sizes]
-    RD.jacobian_multi_(sig, RD.ImplicitFunctionTheorem(AD), dmi, Js, Ys, Zs)
+    assert RD.jacobian_multi_(sig, RD.ImplicitFunctionTheorem(AD), dmi, Js, Ys, Zs) == 3 * len(sizes)
     for b in range(2):
         Xo, Jio, _ = om.implicit_midpoint(Zn[b], ts[b], dts[b])
         np.testing.assert_allclose(host(Ys[b]), Xo, rtol=0, atol=1e-9)
         np.testing.assert_allclose(host(Js[b]), Jio, rtol=0, atol=1e-8 * max(1.0, np.abs(Jio).max()))
     Zh = [traj(model, z, t, d) for z, t, d in zip(Zn, ts, dts)]
     Jh = [RD.alloc_jacobians(dm, N, Zh[0].data) for N in sizes]
-    RD.jacobian_multi_(sig, AD, dm, Jh, None, Zh)
+    assert RD.jacobian_multi_(sig, AD, dm, Jh, None, Zh) == len(sizes)
     for b in range(2):
         np.testing.assert_allclose(host(Jh[b]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[b], ts[b], dts[b])[0], rtol=0, atol=TOL)
-    buf = torch.zeros(sizes[0] * 247 + 1, dtype=torch.float64, device="cuda")
-    Ju = [buf[1:].view(sizes[0], 19, 13).transpose(1, 2), Js[1]]                  # 8-byte aligned slab: the fused kernel copies 16-byte units
-    RD.jacobian_multi_(sig, AD, dm, Ju, None, Zs)
-    np.testing.assert_allclose(host(Ju[0]), om.jacobian(O.RK4, O.FORWARD_AD, Zn[0], ts[0], dts[0])[0], rtol=0, atol=TOL)
-    assert float(buf[0]) == 0.0
+    # a capturing context with more trajectories than fit the kernel arguments: groups of 32 launches (nothing may be allocated inside a capture)
+    from rdhip import _lib as L
+    sizes = [64] * 40
+    Zn = [H.rand_rigid(rng, N, 6) for N in sizes]; ts = [np.arange(N) * 0.05 for N in sizes]; dts = [np.full(N, 0.05) for N in sizes]
+    s1 = torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        Zs = [traj(model, z, t, d, "cuda") for z, t, d in zip(Zn, ts, dts)]
+        Js = [RD.alloc_jacobians(dm, N, Zs[0].data).zero_() for N in sizes]
+        call = RD.prepare_jacobian_multi(sig, AD, dm, Js, None, Zs)
+        call()
+        assert call.launches == 1
+        torch.cuda.synchronize()
+        ref = [j.clone() for j in Js]
+        for j in Js:
+            j.zero_()
+        ctx = L.context_for(0, s1.cuda_stream)
+        ctx.begin_capture()
+        call()
+        g = ctx.end_capture()
+        assert call.launches == 2
+        ctx.launch(g)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, Js):
+            assert torch.equal(a, b)
 
 
 def test_time_dependent_dynamics_receive_the_stage_times():

@@ -221,23 +221,25 @@ def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
              {"trajectories": M, "knots": K})
 
 
-def multi_case(name, model, gen, nbatch, per, rule, dtype, reps):
+def multi_case(name, model, gen, nbatch, per, rule, dtype, reps, singles=True, diff=None):
     """`nbatch` independent trajectories of `per` knot points (separate arrays): (a) one rdhip_jacobian call each, (b) ONE rdhip_jacobian_multi launch."""
     n, m = RD.state_dim(model), RD.control_dim(model)
     T = 8 if dtype == np.float64 else 4
     fun = RD.DiscretizedDynamics(model, rule)
-    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    sig, AD = RD.StaticReturn(), (diff or RD.ForwardAD())
     Zs = [RD.PackedTrajectory(n, m, gen(per).astype(dtype), np.arange(per) * 0.1, np.full(per, 0.1)).to(DEV) for _ in range(nbatch)]
     nb = nbuf_for(nbatch * per * n * (n + m) * T)
     Js = [[RD.alloc_jacobians(fun, per, Zs[0].data) for _ in range(nbatch)] for _ in range(nb)]
     Ys = [[torch.empty((per, n), dtype=Zs[0].data.dtype, device=DEV) for _ in range(nbatch)] for _ in range(nb)]
     alg = nbatch * per * ((n + m) * T + 16 + n * (n + m) * T + n * T)
-    singles = [[RD.prepare_jacobian(sig, AD, fun, Js[k][b], Ys[k][b], Zs[b]) for b in range(nbatch)] for k in range(nb)]
-    us = timed(lambda i: [c() for c in singles[i % nb]], reps)
-    emit(name + f": {nbatch} separate launches", nbatch * per, "f64" if T == 8 else "f32", us, alg, {"batches": nbatch, "knots_per_batch": per})
+    if singles:
+        one = [[RD.prepare_jacobian(sig, AD, fun, Js[k][b], Ys[k][b], Zs[b]) for b in range(nbatch)] for k in range(nb)]
+        us = timed(lambda i: [c() for c in one[i % nb]], reps)
+        emit(name + f": {nbatch} separate launches", nbatch * per, "f64" if T == 8 else "f32", us, alg, {"batches": nbatch, "knots_per_batch": per})
     fused = [RD.prepare_jacobian_multi(sig, AD, fun, Js[k], Ys[k], Zs) for k in range(nb)]
     us = timed(lambda i: fused[i % nb](), reps)
-    emit(name + ": ONE launch (rdhip_jacobian_multi)", nbatch * per, "f64" if T == 8 else "f32", us, alg, {"batches": nbatch, "knots_per_batch": per})
+    emit(name + ": ONE call (rdhip_jacobian_multi)", nbatch * per, "f64" if T == 8 else "f32", us, alg,
+         {"batches": nbatch, "knots_per_batch": per, "kernel_launches_per_call": fused[0].launches})
 
 
 def main():
@@ -261,9 +263,14 @@ def main():
         errexp_case("satellite pair RK4 error-state expansion fused", pair, Zp, RD.RK4, f64, a.reps)
         return
     if a.only in ("multi", ""):
+        if a.only == "multi":
+            jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship, same box]", sat, rigid_inputs(65536, 6, rng), RD.RK4, AD, f64, a.reps)
         multi_case("16 x 4096 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 16, 4096, RD.RK4, f64, a.reps)
         multi_case("64 x 1024 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 64, 1024, RD.RK4, f64, a.reps)
         multi_case("32 x 101 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 32, 101, RD.RK4, f64, a.reps)
+        multi_case("1024 x 101 satellite RK4 jacobian ForwardAD (the reference's unit at scale)", sat, lambda N: rigid_inputs(N, 6, rng), 1024, 101, RD.RK4, f64, a.reps, singles=False)
+        multi_case("1024 x 101 satellite RK4 jacobian FiniteDifference", sat, lambda N: rigid_inputs(N, 6, rng), 1024, 101, RD.RK4, f64, a.reps, singles=False, diff=FD)
+        multi_case("1024 x 101 cartpole RK4 jacobian ForwardAD", cart, lambda N: rng.random((N, 5)), 1024, 101, RD.RK4, f64, a.reps, singles=False)
         multi_case("16 x 4096 cartpole RK4 jacobian ForwardAD (C2 x 16)", cart, lambda N: rng.random((N, 5)), 16, 4096, RD.RK4, f64, a.reps)
         if a.only == "multi":
             return
