@@ -36,6 +36,9 @@ import torch.distributed as dist  # noqa: E402
 import rdhip as RD  # noqa: E402
 from rdhip import parallel as P  # noqa: E402
 
+import subprocess  # noqa: E402
+import threading  # noqa: E402
+
 N_PER_GPU = 65536
 NX, NU = 13, 6
 NZ = NX + NU
@@ -185,6 +188,93 @@ def secondary_metrics(dev, reps):
     return out, small
 
 
+class Watchdog:
+    """Every failure mode must end in ONE JSON line, never in a hang (an RCCL communicator whose peer never arrives blocks inside
+    ncclCommInitRank / a grouped send-recv for ever).  Phases register what is known so far; if a phase outlives its deadline the watchdog prints
+    the line with the phase's name as the error and leaves the process."""
+
+    def __init__(self):
+        self.partial, self.timer, self.lock = None, None, threading.Lock()
+
+    def arm(self, seconds, phase, rank):
+        self.disarm()
+
+        def fire():
+            with self.lock:
+                out = dict(self.partial or {"metric": "knot-point Jacobians/sec (RK4 discrete_jacobian!, n=13)", "value": None})
+                out["error"] = f"rank {rank}: phase '{phase}' exceeded {seconds:.0f} s (watchdog)"
+                # (only rank 0 owns stdout's JSON line; another rank that gives up says so on stderr and leaves -- rank 0's own watchdog then
+                # fires in whatever collective it is waiting in)
+                print(json.dumps(out), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+            os._exit(3 if self.partial is None else 0)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def sharded_extras(dev, rank, world, comm, red_dev):
+    """N > 1: BASELINE config 4 (Quadrotor errstate_jacobian!, 262 144 knot points split over the ranks, gathered to rank 0 through the library's
+    RCCL exchange: rdhip_errstate_jacobian_sharded_gather's shape) and this rank's share of config 5 (8 192 / world trajectories x 256 knots,
+    half Cartpole / half Satellite, fp32, rollouts + Jacobians in one rdhip_rollout_jacobian_multi call).  Returns per-rank values; rank 0
+    gathers them into the line."""
+    import ctypes as C
+    from rdhip import _lib as L
+    out = {}
+    quad = RD.Quadrotor()
+    Ntot = 262144
+    lo, hi = P.shard_range(Ntot, rank, world)
+    n_loc = hi - lo
+    rng = np.random.default_rng(40 + rank)
+    q = rng.standard_normal((n_loc, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    X = torch.as_tensor(np.concatenate([rng.random((n_loc, 3)), q, rng.random((n_loc, 6))], axis=1)).to(dev)
+    G = RD.alloc_errstate_jacobians(quad, n_loc, X)
+    stack = torch.empty((Ntot * 13 * 12) if rank == 0 else 1, dtype=torch.float64, device=dev)
+    sizes = [(P.shard_range(Ntot, r, world)[1] - P.shard_range(Ntot, r, world)[0]) * 13 * 12 * 8 for r in range(world)]
+    lib, ctx = L.lib(), comm.ctxs[0]
+
+    def c4(i):
+        L.check(lib.rdhip_errstate_jacobian(ctx.handle, quad._handle, L.F64, n_loc, X.data_ptr(), 13, 1, G.data_ptr(), L.DEVICE), ctx.handle)
+        comm.gather("root", [G], sizes, [stack], root=0)
+    c4(0); comm.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = _time.perf_counter()
+    reps = 5
+    for i in range(reps):
+        c4(i)
+    comm.synchronize()
+    el = torch.tensor([_time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms = 1e3 * float(el.item()) / reps
+    out["c4_errstate_sharded_gather_root"] = {"knot_points_total": Ntot, "knot_points_this_rank": n_loc, "ms_per_pass_incl_gather": ms,
+                                             "value": Ntot / (ms * 1e-3), "unit": "error-state Jacobians/s (stacked on rank 0)", "bytes_into_root": sum(sizes) - sizes[0]}
+    # C5 share
+    Mr, K = max(4, (8192 // world // 2) // 4 * 4), 256
+    funs, stacks, Js = [], [], []
+    for model, mctl in ((RD.Cartpole(), 1), (RD.Satellite(), 6)):
+        n = RD.state_dim(model)
+        if n == 13:
+            zr, _, _ = synthetic_inputs(Mr * K, 50 + rank)
+        else:
+            zr = np.random.default_rng(60 + rank).random((Mr * K, n + mctl))
+        fun = RD.DiscretizedDynamics(model, RD.RK4)
+        st = {"data": torch.as_tensor(zr.astype(np.float32).reshape(K, Mr, n + mctl)).to(dev),
+              "t": torch.as_tensor(np.ascontiguousarray(np.broadcast_to((np.arange(K) * 0.01)[:, None], (K, Mr)))).to(dev),
+              "dt": torch.full((K, Mr), 0.01, dtype=torch.float64, device=dev)}
+        funs.append(fun); stacks.append(st); Js.append(RD.alloc_jacobians(fun, Mr * K, st["data"]))
+    call = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Js, stacks, None, time_major=True)
+    us = _timed_us(lambda i: call(), 20, warm=2)
+    out["c5_share_rollouts_and_jacobians_one_call"] = {"trajectories_this_rank": 2 * Mr, "knot_points_per_trajectory": K, "us_per_call": us,
+                                                      "value": 2 * Mr * K / (us * 1e-6), "unit": "simulated + linearised knot points/s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,9 +291,13 @@ def main():
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
+    ap.add_argument("--phase-timeout", type=float, default=240.0, help="seconds any single phase (rendezvous, timed region, RCCL exchange, extras) may take before the "
+                                                                        "watchdog prints the JSON line with an error and exits")
     args = ap.parse_args()
 
     rank, local_rank, world = P.env_rank_world()
+    wd = Watchdog()
+    wd.arm(args.phase_timeout, "process-group rendezvous / first RCCL collective", rank)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if args.same_device:
@@ -231,6 +325,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    wd.arm(args.phase_timeout, "set-up, warm-up and timed region", rank)
     N = args.knots
     Zn, t, dt = synthetic_inputs(N, seed=3 + rank)
     model = RD.Satellite()                       # mass 1, J = I3 (examples/single_satellite.jl:33-35)
@@ -282,6 +377,38 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     value = world * N * args.steps / elapsed
+
+    achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
+    traffic = tsrc = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived HBM bytes per launch, measured in a separate rocprofv3 run
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            traffic = tj.get("bytes_per_launch")
+            try:
+                commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles/hbm_traffic.json"], capture_output=True, text=True, timeout=10).stdout.strip()
+            except Exception:
+                commit = ""
+            tsrc = "profiles/hbm_traffic.json" + (f"@{commit}" if commit else "") + " (" + str(tj.get("source", "rocprofv3 --pmc, separate passes")) + "); not measured in this run"
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "knot-point Jacobians/sec (RK4 discrete_jacobian!, n=13)",
+        "value": value, "unit": "knot-point Jacobians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "prewarm_ms": args.prewarm_ms,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Satellite RigidBody{QuatRotation} (n=13,m=6) RK4 discrete dynamics + ForwardAD Jacobian (BASELINE configs[2])",
+                   "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
+                   "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": tsrc,
+                     "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
+                     "kernel_source": "the kernel rdhip_jacobian dispatches to for this configuration (csrc/dispatch.hpp launch_jacobian); name as in profiles/r03/kernel_stats.csv",
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
+    }
+    if rank == 0:
+        wd.partial = line            # from here on a stuck extra costs the extra, not the line
+    wd.arm(args.phase_timeout, "extras (multi-stream / RCCL exchange / secondary metrics)", rank)
 
     # extra (never `value`): the same K independent batches issued round-robin on 4 HIP streams, one rdhip context per stream -- the next
     # launch's workgroups start on the CUs the previous launch has already left, so its prologue runs under the previous launch's tail
@@ -361,6 +488,21 @@ def main():
                 except Exception as e2:
                     gather["torch_distributed_error"] = f"{type(e2).__name__}: {e2}"[:200]
 
+    sharded = None
+    if world > 1 and args.gather != "none" and not args.no_extras:
+        # C4 / C5 per rank (one RCCL communicator for C4's gather-to-root); every rank reports, rank 0 prints
+        try:
+            wd.arm(args.phase_timeout, "C4 sharded errstate gather / C5 per-rank share", rank)
+            comm2 = P.Comm.from_torch_distributed(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream)
+            mine = sharded_extras(dev, rank, world, comm2, red_dev)
+            comm2.close()
+            box = [None] * world
+            dist.all_gather_object(box, {"rank": rank, **{k: v.get("value") for k, v in mine.items()}})
+            sharded = dict(mine); sharded["per_rank_values"] = box
+        except Exception as e:
+            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+    wd.arm(args.phase_timeout, "secondary metrics / CPU baseline", rank)
+
     extras = small = None
     if rank == 0 and not args.no_extras:
         try:
@@ -369,28 +511,11 @@ def main():
             extras = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
-        achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived HBM bytes per launch, if measured
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "knot-point Jacobians/sec (RK4 discrete_jacobian!, n=13)",
-            "value": value, "unit": "knot-point Jacobians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "prewarm_ms": args.prewarm_ms,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Satellite RigidBody{QuatRotation} (n=13,m=6) RK4 discrete dynamics + ForwardAD Jacobian (BASELINE configs[2])",
-                       "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
-                       "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
-        }
+        out = line
         if gather:
             out["gather"] = gather
+        if sharded:
+            out["sharded_configs"] = sharded
         if extras:
             out["extras"] = extras
         if small:
@@ -398,8 +523,11 @@ def main():
         if overlapped:
             out["independent_batches_multi_stream"] = overlapped
         if not args.no_cpu_baseline and world == 1:
+            wd.arm(max(args.phase_timeout, 120.0), "CPU baseline", rank)
             out["cpu_baseline"] = cpu_baseline(Zn, t, dt)
+        wd.disarm()
         print(json.dumps(out), flush=True)
+    wd.disarm()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -268,10 +268,27 @@ int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype,
 
 /* rollout!(sig, dmodel, Z, x0) followed by jacobian!(sig, diff, dmodel, J[k], y, Z[k]) at every knot point of the simulated trajectories
  * (the forward pass + linearisation of a shooting method; rollout!: src/trajectories.jl:436-441, jacobian!: src/functionbase.jl:242-257).
- * Same result as rdhip_rollout + rdhip_jacobian on the K*M knot points.  Z: (n+m) x (K*M), J: n x (n+m) x (K*M), t, dt: K*M, X0: n x M or NULL.
- * Implicit rules take RDHIP_TRAJECTORY_MAJOR data only. */
+ * Same result as rdhip_rollout + rdhip_jacobian on the K*M knot points (the states bit for bit: rdhip_rollout runs the same kernel; the Jacobians to the
+ * last bit or two: the same column code compiled into another kernel).  Z: (n+m) x (K*M), J: n x (n+m) x (K*M), t, dt: K*M, X0: n x M or NULL.
+ * ONE launch in which the two overlap -- rollout workgroups (one per 64 trajectories) announce every finished chunk of 4 steps in a progress
+ * word, Jacobian workgroups on the rest of the chip consume the chunks a few steps behind, so the Jacobian store stream runs under the rollout's
+ * latency chain -- for the RigidBody{QuatRotation} models (satellite, quadrotor), explicit rules, RDHIP_FORWARD_AD, RDHIP_TIME_MAJOR data with
+ * 16-byte aligned J and M * n * (n+m) * sizeof(T) a multiple of 16 (M even in fp64, a multiple of 4 in fp32) and at most half as many 64-trajectory
+ * groups as the device has compute units; every other combination runs the two launches back to back.  rdhip_ctx_last_rollout_jacobian_launches
+ * says which (1 = overlapped).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only. */
 int rdhip_rollout_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long K, long long M, int layout,
                            void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace);
+int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
+/* rdhip_rollout_jacobian for up to four MODELS in one call -- the mixed-model Monte-Carlo batch (even trajectories one model, odd ones another;
+ * `for p in models: rollout!(sig, dmodel[p], Z[p], x0[p]); jacobian! along it`, src/trajectories.jl:436-441 + src/functionbase.jl:242-257): model p has
+ * its own stack (K[p] knots x M[p] trajectories, arrays Z[p], t[p], dt[p], X0[p] or NULL, J[p]; rule[p] its quadrature rule; X0 itself may be NULL).
+ * With device pointers every model runs on its own internal stream between one fork and one join on the context's stream: the rollouts' latency
+ * chains (a handful of compute units each) run side by side and the Jacobian workgroups share the rest of the chip; results are those of the
+ * single-model calls, and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
+ * the other. */
+int rdhip_rollout_jacobian_multi(rdhip_ctx* ctx, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype,
+                                 const long long* K, const long long* M, int layout, void* const* Z, const double* const* t, const double* const* dt,
+                                 const void* const* X0, void* const* J, int memspace);
 
 /* ---- several GPUs in ONE process (hosts without torch.distributed / RCCL, e.g. the Julia wrapper) ----
  * The multi-GPU layout of this library is one context per device and contiguous blocks of knot points per device (knot points are

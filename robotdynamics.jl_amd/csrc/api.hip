@@ -36,7 +36,16 @@ struct rdhip_ctx {
     TableSlot tslot[NTSLOT];
     unsigned tnext = 0;
     int last_multi_launches = 0;          // kernel launches the last rdhip_jacobian_multi call on this context issued (rdhip_ctx_last_multi_launches)
+    // fused rollout -> Jacobians (fused.hpp): one 64-bit progress word per 64-trajectory group, zero at allocation; a call's words carry its epoch in
+    // the upper half, so nothing is cleared between calls
+    unsigned long long* d_progress = nullptr;
+    unsigned long long roll_epoch = 0;
+    int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
+    // rdhip_rollout_jacobian_multi: one child context (own stream, own progress words) per additional model, created on first use
+    rdhip_ctx* child[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
 };
+static constexpr int PROGRESS_WORDS = 4096;
 struct rdhip_model {
     ModelDesc d;
     LieDesc lie;
@@ -111,6 +120,8 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, (size_t)(1 + IMPLICIT_FLAG_WORDS) * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));          // word 0 = epoch of the last call that raised a tile word (0: none yet)
+    if (e == hipSuccess) e = hipMalloc(&c->d_progress, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_progress, 0, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
@@ -121,6 +132,10 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_progress) (void)hipFree(c->d_progress);
+    for (auto& ch : c->child) if (ch) { (void)rdhip_ctx_destroy(ch); ch = nullptr; }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    for (auto& e : c->join_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c; return RDHIP_OK;
@@ -421,6 +436,17 @@ static int family_rollout(const ModelDesc& d, int rule, int dtype, const LaunchA
         case RDHIP_MODEL_SATELLITE: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_rollout(d, rule, dtype, a) : fam_satellite_rollout(d, rule, dtype, a);
         case RDHIP_MODEL_QUADROTOR: return d.rot != RDHIP_ROT_QUAT ? fam_rigid3_rollout(d, rule, dtype, a) : fam_quadrotor_rollout(d, rule, dtype, a);
         default: return fam_lie_rollout(d, rule, dtype, a);
+    }
+}
+
+// rollout + Jacobians in one launch, or RDHIP_ERR_UNSUPPORTED before anything has been launched (models without a cascade structure, custom models)
+static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& a) {
+    g_jit_model = nullptr;
+    if (d.rot != RDHIP_ROT_QUAT) return RDHIP_ERR_UNSUPPORTED;
+    switch (d.kind) {
+        case RDHIP_MODEL_SATELLITE: return fam_satellite_rolljac(d, rule, diff, dtype, a);
+        case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_rolljac(d, rule, diff, dtype, a);
+        default: return RDHIP_ERR_UNSUPPORTED;
     }
 }
 
@@ -794,9 +820,64 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     }
     LaunchArgs j{}; j.stream = c->stream; j.N = N; j.Z = r.Z; j.t = r.t; j.dt = r.dt; j.J = dJ;
     if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
+    c->last_rolljac_launches = 0;
+    if (!implicit) {
+        // ONE launch: rollout workgroups + Jacobian workgroups that consume finished chunks through progress words (fused.hpp)
+        LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS;
+        const bool capturing = stream_is_capturing(c);
+        // a captured launch is replayed with the epoch it was recorded with: its words are cleared by a memset node in front of it instead
+        if (capturing) HIP_TRY(c, hipMemsetAsync(c->d_progress, 0, (size_t)PROGRESS_WORDS * sizeof(unsigned long long), c->stream));
+        c->roll_epoch = (c->roll_epoch + 1) & 0x7fffffffULL; if (c->roll_epoch == 0) c->roll_epoch = 1;
+        f.pbase = c->roll_epoch << 32;
+        const int kf = family_rolljac(d, rule, diff, dtype, f);
+        if (kf != RDHIP_ERR_UNSUPPORTED) { c->last_rolljac_launches = 1; const int k = kernel_status(c, kf, what); return memspace == RDHIP_HOST ? s.finish(k) : k; }
+    }
     int k = kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
     if (!k) k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
+    c->last_rolljac_launches = 2;
     return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
+// The mixed-model Monte-Carlo batch (BASELINE config 5: even trajectories Cartpole, odd Satellite): every model's rollout + Jacobians is issued on its
+// own stream between one fork and one join on the context's stream, so that the latency chains of the rollouts run side by side (each occupies a
+// handful of compute units) and the Jacobian workgroups of the fused kernels fill the rest.
+int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype, const long long* K, const long long* Mt,
+                                 int layout, void* const* Z, const double* const* t, const double* const* dt, const void* const* X0, void* const* J, int memspace) {
+    const char* what = "rdhip_rollout_jacobian_multi";
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (nmodels < 0 || nmodels > 4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: 0 .. 4 models per call (got %d)", what, nmodels);
+    if (nmodels == 0) return RDHIP_OK;
+    if (!models || !rule || !K || !Mt || !Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL table", what);
+    for (int p = 0; p < nmodels; ++p) if (!models[p]) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: model %d is NULL", what, p);
+    const bool concurrent = memspace == RDHIP_DEVICE && nmodels > 1 && !stream_is_capturing(c);
+    if (!concurrent) {                                      // host arrays (each call copies and synchronises) or a capturing stream: one after the other
+        for (int p = 0; p < nmodels; ++p) {
+            const int rc = rdhip_rollout_jacobian(c, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
+            if (rc) return rc;
+        }
+        return RDHIP_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int p = 1; p < nmodels; ++p) {
+        if (!c->child[p - 1]) { const int rc = rdhip_ctx_create(c->device, nullptr, RDHIP_STREAM_OWN, &c->child[p - 1]); if (rc) return fail(c, rc, "%s: %s", what, rdhip_last_error(nullptr)); }
+        if (!c->join_ev[p - 1]) HIP_TRY(c, hipEventCreateWithFlags(&c->join_ev[p - 1], hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));      // the children start behind the work already queued on this context
+    int rc0 = RDHIP_OK;
+    for (int p = 1; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes model 0 last
+        rdhip_ctx* ch = c->child[p - 1];
+        HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
+        rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
+        if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
+        HIP_TRY(c, hipEventRecord(c->join_ev[p - 1], ch->stream));
+    }
+    if (rc0 == RDHIP_OK) rc0 = rdhip_rollout_jacobian(c, models[0], rule[0], diff, dtype, K[0], Mt[0], layout, Z[0], t[0], dt[0], X0 ? X0[0] : nullptr, J[0], memspace);
+    for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results
+    return rc0;
+}
+int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* c, int* launches) {
+    if (!c || !launches) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *launches = c->last_rolljac_launches; return RDHIP_OK;
 }
 
 // ---- several GPUs in ONE process (hosts without torch.distributed / RCCL) --------------------------------------------------------

@@ -92,11 +92,21 @@ template <class Fn, class Cas, int B> struct CascadeHook {
 #define RD_LDS_DRAIN() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define RD_LDS_T(TYPE) TYPE __attribute__((address_space(3)))*
 RD_DEV int lds_flag(volatile int __attribute__((address_space(3)))* f) { return __builtin_amdgcn_readfirstlane(*f); }
+// PUB (the fused rollout -> Jacobians kernel, fused.hpp): the simulated states are read by OTHER workgroups of the same launch, possibly on another XCD
+// (each XCD has its own L2).  They are stored as agent-scope atomics -- written through to memory -- and announced through a 64-bit progress word per
+// 64-trajectory group, (call epoch << 32) | knots available, stored once the data stores it covers have been acknowledged (vmcnt).
+template <bool PUB, class T> RD_DEV void pub_store(T* p, T v) {
+    if constexpr (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+RD_DEV void pub_progress(unsigned long long* word, unsigned long long base, long long knots) {
+    if (word) __hip_atomic_store(word, base | (unsigned long long)knots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- compute wavefront of block B -------------------------------------------------------------------------------------------------------
-template <class Fn, class T, class Cas, int R, int B>
-RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long long sj, long long sk, T* __restrict__ Z, const double* __restrict__ tt,
-                                 const double* __restrict__ dtt, const T* __restrict__ X0, int nfull) {
+template <class Fn, class T, class Cas, int R, int B, bool PUB>
+RD_DEV void cascade_compute_wave_body(const Fn& fn, long long K, long long M, long long sj, long long sk, T* __restrict__ Z, const double* __restrict__ tt,
+                                      const double* __restrict__ dtt, const T* __restrict__ X0, int nfull) {
     using L = CascadeLds<Fn, Cas, R>;
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NS = L::NS, NB = Cas::NB, S = L::S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // (declared here, not passed in: the accesses must stay LDS instructions)
@@ -121,7 +131,8 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         for (int i = 0; i < NX; ++i) x[i] = (Cas::block_of(i) == B) ? xs[i] : T(0);
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) if (Cas::block_of(i) == B) Z[ip * NZ + i] = x[i];
+    for (int i = 0; i < NX; ++i) if (Cas::block_of(i) == B) pub_store<PUB>(Z + ip * NZ + i, x[i]);
+    if constexpr (PUB) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): knot 0 is announced together with the first chunk (cascade_io_wave)
     if (K < 2) return;
     auto read_slot = [&](int step, T (&dst)[NS][NX]) {
         LdsT slot = ring + (size_t)(step & (R - 1)) * L::RING_SLOT;
@@ -223,8 +234,8 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         }
 #pragma unroll
         for (int d = 0; d + 1 < S; d += 2) {
-            if (k + d < nsteps) { T* Zk = Z + (ip + (long long)(k + d + 1) * sk) * NZ; step(k + d, uin[d], hh[d], (T)tk[d], UA, UB, [&](int i, T v) { Zk[i] = v; }); }
-            if (d + 2 < S) { if (k + d + 1 < nsteps) { T* Zk = Z + (ip + (long long)(k + d + 2) * sk) * NZ; step(k + d + 1, uin[d + 1], hh[d + 1], (T)tk[d + 1], UB, UA, [&](int i, T v) { Zk[i] = v; }); } }
+            if (k + d < nsteps) { T* Zk = Z + (ip + (long long)(k + d + 1) * sk) * NZ; step(k + d, uin[d], hh[d], (T)tk[d], UA, UB, [&](int i, T v) { pub_store<PUB>(Zk + i, v); }); }
+            if (d + 2 < S) { if (k + d + 1 < nsteps) { T* Zk = Z + (ip + (long long)(k + d + 2) * sk) * NZ; step(k + d + 1, uin[d + 1], hh[d + 1], (T)tk[d + 1], UB, UA, [&](int i, T v) { pub_store<PUB>(Zk + i, v); }); } }
         }
         return;
     }
@@ -248,7 +259,7 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
         for (int i = 0; i < NU; ++i) uk[i] = un[d][i];
         { const long long kn = (long long)kk + D; fetch(d, kn < last ? kn : last); }
         T* Zk = Z + (ip + ((long long)kk + 1) * sk) * NZ;
-        step(kk, uk, h, tk, Uc, Un, [&](int i, T v) { Zk[i] = v; });
+        step(kk, uk, h, tk, Uc, Un, [&](int i, T v) { pub_store<PUB>(Zk + i, v); });
     };
     for (; k + D <= nsteps; k += D) {
 #pragma unroll
@@ -261,13 +272,21 @@ RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long lo
     }
 }
 
+template <class Fn, class T, class Cas, int R, int B, bool PUB = false>
+RD_DEV void cascade_compute_wave(const Fn& fn, long long K, long long M, long long sj, long long sk, T* __restrict__ Z, const double* __restrict__ tt,
+                                 const double* __restrict__ dtt, const T* __restrict__ X0, int nfull) {
+    cascade_compute_wave_body<Fn, T, Cas, R, B, PUB>(fn, K, M, sj, sk, Z, tt, dtt, X0, nfull);
+    if constexpr (PUB) __builtin_amdgcn_s_waitcnt(0x0F70);     // the wave's direct stores are acknowledged before the workgroup announces the whole trajectory
+}
+
 // ---- IO wavefront ---------------------------------------------------------------------------------------------------------------------
 // Lane groups: 8 lanes per control row (NU <= 8 of them active), 16 lanes per state row (NX <= 16 active), 64 lanes over 64 time stamps.
 // The rows one instruction touches are adjacent in memory for the layout at hand (TM = time-major: knot k of all trajectories contiguous;
 // otherwise the knots of one trajectory are contiguous), and instruction `it` of a chunk differs from instruction 0 by a wave-uniform
 // stride, so an address is (uniform base + it * uniform stride) + a per-lane constant computed once.
-template <class Fn, class T, class Cas, int R, bool TM>
-RD_DEV void cascade_io_wave(long long K, long long M, T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt, int nfull) {
+template <class Fn, class T, class Cas, int R, bool TM, bool PUB = false>
+RD_DEV void cascade_io_wave(long long K, long long M, T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt, int nfull,
+                            unsigned long long* pword = nullptr, unsigned long long pbase = 0) {
     using L = CascadeLds<Fn, Cas, R>;
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NB = Cas::NB, S = L::S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -369,12 +388,16 @@ RD_DEV void cascade_io_wave(long long K, long long M, T* __restrict__ Z, const d
         // the inputs go into LDS BEFORE the stores are issued: the loads are then the youngest memory operations in flight and waiting for
         // them waits only for the previous chunk's stores (a chunk old), not for stores just issued
         write_in(n & 1, n + 3 < nfull ? n + 3 : nfull);
+        // (the inputs just written were requested at the top of this iteration: their arrival says that the stores of chunk n - 1, which are
+        // older, have been acknowledged -- knots 0 .. 4 n are complete)
+        if constexpr (PUB) pub_progress(pword, pbase, (long long)n * S + 1);
 #pragma unroll
         for (int it = 0; it < NXI; ++it) {
             const long long g = TM ? ((long long)(it >> 4) * M + (it & 15) * 4) * NZ : (long long)it * K * NZ;
-            zb[g + x_goff] = rx[it];
+            pub_store<PUB>(zb + g + x_goff, rx[it]);
         }
     }
+    if constexpr (PUB) { __builtin_amdgcn_s_waitcnt(0x0F70); pub_progress(pword, pbase, (long long)nfull * S + 1); }
 }
 
 // ---- FiniteDifference along the cascade ---------------------------------------------------------------------------------------------
@@ -468,15 +491,15 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_cascade_kernel(
     jac_split_loop<Fn, T, Plan, NC, FdCascadeBody<Fn, T, Plan, Cas>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
-template <class Fn, class T, class Cas, int R, int B> struct CascadeWaves {
+template <class Fn, class T, class Cas, int R, int B, bool PUB = false> struct CascadeWaves {
     static RD_DEV void run(int wave, const Fn& fn, long long K, long long M, long long sj, long long sk, T* Z, const double* tt, const double* dtt,
-                           const T* X0, int nfull) {
+                           const T* X0, int nfull, unsigned long long* pword = nullptr, unsigned long long pbase = 0) {
         if constexpr (B < Cas::NB) {
-            if (wave == B) cascade_compute_wave<Fn, T, Cas, R, B>(fn, K, M, sj, sk, Z, tt, dtt, X0, nfull);
-            else CascadeWaves<Fn, T, Cas, R, B + 1>::run(wave, fn, K, M, sj, sk, Z, tt, dtt, X0, nfull);
+            if (wave == B) cascade_compute_wave<Fn, T, Cas, R, B, PUB>(fn, K, M, sj, sk, Z, tt, dtt, X0, nfull);
+            else CascadeWaves<Fn, T, Cas, R, B + 1, PUB>::run(wave, fn, K, M, sj, sk, Z, tt, dtt, X0, nfull, pword, pbase);
         } else {
-            if (sk == 1) cascade_io_wave<Fn, T, Cas, R, false>(K, M, Z, tt, dtt, nfull);
-            else cascade_io_wave<Fn, T, Cas, R, true>(K, M, Z, tt, dtt, nfull);
+            if (sk == 1) cascade_io_wave<Fn, T, Cas, R, false, PUB>(K, M, Z, tt, dtt, nfull, pword, pbase);
+            else cascade_io_wave<Fn, T, Cas, R, true, PUB>(K, M, Z, tt, dtt, nfull, pword, pbase);
         }
     }
 };

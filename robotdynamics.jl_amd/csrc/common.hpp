@@ -116,6 +116,9 @@ struct LaunchArgs {
     int epoch;          // implicit rules: 1 .. 2^22, different for consecutive calls on a context (0: none); see implicit_midpoint_kernel.  A captured
                         // graph bakes ONE epoch into its kernel arguments: replays stay correct (the tile words are rewritten by every call) but may lose
                         // the gated pass's one-load early exit when a stale gate[0] happens to equal that epoch (it then scans its tile words)
+    unsigned long long* progress;   // fused rollout -> Jacobians: one progress word per 64-trajectory group (context workspace, zero at allocation)
+    unsigned long long pbase;       //   (call epoch << 32): words of earlier calls compare below
+    int progress_words;             //   capacity of `progress`
     const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
                               // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED BEFORE launching anything and the caller
                               // loops over the batches
@@ -126,7 +129,8 @@ struct LaunchArgs {
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                  \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);    \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);       \
-    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs, 3: rollout */
+    int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs, 3: rollout */ \
+    int name##_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);   /* rollout + Jacobians in one launch (fused.hpp) or RDHIP_ERR_UNSUPPORTED before anything is launched */
 RD_DECLARE_FAMILY(fam_cartpole)
 RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)

@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "cascade.hpp"
 #include "implicit.hpp"
+#include "fused.hpp"
 
 namespace rd {
 
@@ -43,6 +44,22 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
         const bool plain = mode && mode[0] == 'p';
         if (!plain && a.K < (1LL << 26) && a.N < (1LL << 26)) {            // (the IO wave's per-lane offsets are 32-bit)
             constexpr int R = 4;
+            // models whose rollout + Jacobians can run as one launch (fused.hpp) roll out through THAT kernel (rollout workgroups only): the two-call
+            // and the one-call path then execute the same machine code and agree to the last bit
+            if constexpr (Fn::RULE_ID != RULE_IMPLICIT_MIDPOINT) {
+                using Mdl = typename std::remove_cv<decltype(Fn::m)>::type;
+                if constexpr (UnrollPolicy<Mdl, Fn::RULE_ID>::value && UnrollPolicy<Mdl, Fn::RULE_ID>::NC == 4) {
+                    using Plan = typename UnrollPolicy<Mdl, Fn::RULE_ID>::Plan;
+                    if constexpr (Plan::NG == 4) {
+                        constexpr size_t ldsf = FusedLds<Fn, T, Cas, R, Plan, 4>::BYTES;
+                        auto kf = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, 4>;
+                        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), ldsf) != hipSuccess) return RDHIP_ERR_HIP;
+                        hipLaunchKernelGGL(kf, dim3(grid), dim3(FUSED_THREADS), ldsf, a.stream, fn, a.K, a.N, (int)grid, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0,
+                                           (T*)nullptr, (unsigned long long*)nullptr, 0ULL);
+                        return hip_status(hipGetLastError());
+                    }
+                }
+            }
             constexpr size_t lds = CascadeLds<Fn, Cas, R>::BYTES;
             auto kern = rollout_cascade_kernel<Fn, T, Cas, R>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
@@ -130,7 +147,8 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_multi_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+            constexpr int W = SmallLds<Fn, T>::WAVES;
+            hipLaunchKernelGGL(kern, dim3(tile_grid(lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
@@ -179,7 +197,8 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             auto kern = jac_ad_small_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             const long long ntiles = (a.N + TILE - 1) / TILE;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+            constexpr int W = SmallLds<Fn, T>::WAVES;
+            hipLaunchKernelGGL(kern, dim3(tile_grid(lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
@@ -232,6 +251,54 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
         }
         else return RDHIP_ERR_NOT_IMPLEMENTED;           // jacobian!(fun, J, y, x, u) not defined for this model (src/functionbase.jl:257)
     }
+    return RDHIP_ERR_INVALID_ARG;
+}
+
+// rollout! + Jacobians along it in one launch (fused.hpp): models with a cascade structure and a compile-time column plan, ForwardAD, time-major
+// data whose 64-trajectory tiles start on 16-byte boundaries; anything else -> RDHIP_ERR_UNSUPPORTED (the caller issues the two launches)
+template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, int diff, const LaunchArgs& a) {
+    using Fn = Fun<Mdl, RULE>;
+    using T = typename Fn::T;
+    using Cas = Cascade<Mdl>;
+    if constexpr (Cas::NB > 1 && UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC == 4) {
+        using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+        constexpr int NC = 4, R = 4;
+        if constexpr (Plan::NG == 4) {
+            static const char* mode = getenv("RDHIP_ROLLJAC");              // tuning switch: "split" keeps the two launches
+            if (mode && mode[0] == 's') return RDHIP_ERR_UNSUPPORTED;
+            const long long K = a.K, M = a.N;
+            if (diff != RDHIP_FORWARD_AD || !a.time_major || !a.progress || K < 1 || M < 1 || K >= (1LL << 26) || M >= (1LL << 26)) return RDHIP_ERR_UNSUPPORTED;
+            if (!aligned16(a.J) || (M * Fn::NY * (Fn::NX + Fn::NU) * (long long)sizeof(T)) % 16 != 0) return RDHIP_ERR_UNSUPPORTED;   // every knot's row of tiles starts aligned
+            const long long G = (M + TILE - 1) / TILE;
+            using FL = FusedLds<Fn, T, Cas, R, Plan, NC>;
+            constexpr size_t lds = FL::BYTES;
+            static_assert(lds <= 160 * 1024, "fused kernel: LDS");
+            const long long cus = dev_info().cus;
+            // the rollout workgroups must leave most of the chip to the Jacobians (and all of them must be resident together with consumers)
+            if (G > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
+            auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC>;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+            const long long ntiles = K * G;
+            long long nj = cus - G; if (nj > ntiles) nj = ntiles;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                               a.progress, a.pbase);
+            return hip_status(hipGetLastError());
+        }
+    }
+    return RDHIP_ERR_UNSUPPORTED;
+}
+template <class Mdl> int dispatch_rolljac_rule(const Mdl& m, int rule, int diff, const LaunchArgs& a) {
+    switch (rule) {
+        case RDHIP_EULER: return launch_rollout_jacobian_fused<Mdl, RULE_EULER>(m, diff, a);
+        case RDHIP_RK2: return launch_rollout_jacobian_fused<Mdl, RULE_RK2>(m, diff, a);
+        case RDHIP_RK3: return launch_rollout_jacobian_fused<Mdl, RULE_RK3>(m, diff, a);
+        case RDHIP_RK4: return launch_rollout_jacobian_fused<Mdl, RULE_RK4>(m, diff, a);
+    }
+    return RDHIP_ERR_UNSUPPORTED;
+}
+template <template <class> class MT> int dispatch_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) {
+    if (dtype == RDHIP_F64) return dispatch_rolljac_rule(MT<double>::make(md.params), rule, diff, a);
+    if (dtype == RDHIP_F32) return dispatch_rolljac_rule(MT<float>::make(md.params), rule, diff, a);
     return RDHIP_ERR_INVALID_ARG;
 }
 

@@ -6,6 +6,7 @@ namespace rd {
 int fam_quadrotor_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(eval, md, rule, dtype, a); }
 int fam_quadrotor_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return RD_PICK(jacobian, md, rule, diff, dtype, a); }
 int fam_quadrotor_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(rollout, md, rule, dtype, a); }
+int fam_quadrotor_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return RD_PICK(rolljac, md, rule, diff, dtype, a); }
 int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return RD_PICK(errexp, md, rule, dtype, a); }
 int fam_quadrotor_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) { return RD_PICK(implicit, md, mode, dtype, a); }
 }  // namespace rd

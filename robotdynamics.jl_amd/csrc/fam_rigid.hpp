@@ -37,12 +37,14 @@ template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR
     int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);                   \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                       \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);         \
-    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
+    int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                    \
+    int name##_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);
 #define RD_RIGID_VARIANT_DEFINE(name, WRENCH, BODY, DIAG)                                                 \
     template <class T> using name##_M = RigidBody<T, WRENCH, BODY, DIAG>;                                 \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_eval<name##_M>(md, rule, dtype, a); } \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_jacobian<name##_M>(md, rule, diff, dtype, a); } \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); } \
+    int name##_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_rolljac<name##_M>(md, rule, diff, dtype, a); } \
     int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_errexp<name##_M>(md, rule, dtype, a); } \
     int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) { return dispatch_implicit<name##_M>(md, mode, dtype, a); }
 RD_RIGID_VARIANT_DECL(sat_wd) RD_RIGID_VARIANT_DECL(sat_wf) RD_RIGID_VARIANT_DECL(sat_bd) RD_RIGID_VARIANT_DECL(sat_bf)

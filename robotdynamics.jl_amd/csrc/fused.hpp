@@ -1,0 +1,78 @@
+// fused.hpp -- rollout! and the Jacobians along the rollout in ONE launch (src/trajectories.jl:436-441 followed by
+// src/functionbase.jl:242-257 at every simulated knot point: the forward pass + linearisation of a shooting method).
+//
+// A rollout is a latency chain that occupies ceil(M / 64) workgroups (one per 64 trajectories: cascade.hpp) for K - 1 dependent steps while the rest
+// of the chip idles, and the Jacobians of the simulated knot points are a bandwidth-bound stream that needs the whole chip.  Launched one after the
+// other they add up (C5's share of one GPU: 117 + 26 us; 4 096 x 101 fp64: 62 + 156 us).  Here they overlap inside one grid:
+//
+//   workgroups 0 .. G-1      the cascade rollout of one 64-trajectory group each (compute wavefronts per state block + the IO wavefront); the IO
+//                            wavefront stores every finished chunk of 4 steps as agent-scope (write-through) atomics and then announces it in the
+//                            group's 64-bit progress word, (call epoch << 32) | knots available;
+//   workgroups G ..          the flagship's split-role Jacobian tile loop (kernels.hpp jac_split_loop) over tiles enumerated in the order in
+//                            which they become available -- with time-major data tile (k, g) is knot k of group g's 64 trajectories, one
+//                            contiguous slab -- whose compute waves poll the producer's progress word before they request a tile's inputs.
+//
+// Producers never wait for consumers and lower workgroup indices are dispatched first, so the launch cannot deadlock however many workgroups are
+// resident.  The Jacobian store stream then runs UNDER the rollout chain, a few steps behind it, and what is left after the last step is the tail
+// of one chunk.  Results are bit-identical to rdhip_rollout followed by rdhip_jacobian: the same rollout waves, the same column code.
+#pragma once
+#include "cascade.hpp"
+
+namespace rd {
+
+// tiles of the knot points of M trajectories x K knots in TIME-MAJOR order (knot k of trajectory j at flat index k M + j): item i = (knot i / G,
+// group i % G), G = ceil(M / 64) -- the order in which the rollout workgroups produce them
+template <class T> struct RolloutTilesTM {
+    static constexpr bool RING = false, WAITS = true;
+    long long K, M; int G;
+    const T* Z; const double* t; const double* dt; T* J;
+    const unsigned long long* progress; unsigned long long pbase;
+    RD_DEV long long ntiles() const { return K * G; }
+    RD_DEV TileRef<T> at(long long item) const {
+        const long long k = item / G; const long long g = item - k * G;
+        const long long k0 = k * M + g * TILE, end = k * M + ((g + 1) * TILE < M ? (g + 1) * TILE : M);
+        return TileRef<T>{Z, t, dt, J, nullptr, end, k0};       // (nk = end - k0; slabs are addressed by the flat knot index k0)
+    }
+    // every wave that is about to request the tile's inputs polls the word itself (a scalar-uniform load; words of earlier calls carry a smaller
+    // epoch and compare below).  The consumer has never touched these lines before, and the producer's stores were written through before the
+    // word was: no cache invalidation is needed on this side.
+    RD_DEV void wait(long long item) const {
+        const long long k = item / G; const long long g = item - k * G;
+        const unsigned long long need = pbase | (unsigned long long)(k + 1);
+        while (__hip_atomic_load(progress + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+    }
+};
+
+constexpr int FUSED_THREADS = 8 * TILE;
+template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedLds {
+    static constexpr size_t ROLL = CascadeLds<Fn, Cas, R>::BYTES, JAC = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static constexpr size_t BYTES = ROLL > JAC ? ROLL : JAC;
+    static_assert((Cas::NB + 1) * TILE <= FUSED_THREADS && (Plan::NG + NC) * TILE == FUSED_THREADS, "both roles live in one 512-thread workgroup");
+};
+// (sj, sk): strides of the rollout's data, (K, 1) = the knots of a trajectory contiguous, (1, M) = time-major.  The SAME kernel serves rdhip_rollout
+// for these models (grid = G, no Jacobian workgroups, any strides): "rollout, then Jacobians" in two calls and in one are the same machine code
+// and give the same bits.  Jacobian workgroups (grid > G) need time-major data.
+template <class Fn, class T, class Cas, int R, class Plan, int NC>
+__global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
+                                                                            const double* __restrict__ tt, const double* __restrict__ dtt, const T* __restrict__ X0,
+                                                                            T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase) {
+    if ((int)blockIdx.x < G) {
+        // ---- rollout of trajectories 64 blockIdx.x ..: the waves of rollout_cascade_kernel, publishing (progress == nullptr: nobody listens) ----
+        using L = CascadeLds<Fn, Cas, R>;
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+        if (threadIdx.x < 16) reinterpret_cast<int*>(smem + L::FLAG_OFF)[threadIdx.x] = 0;
+        __syncthreads();
+        const bool whole = ((long long)blockIdx.x + 1) * TILE <= M;
+        const int nfull = (whole && K >= 2) ? (int)((K - 1) / L::S) : 0;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        unsigned long long* pword = progress ? progress + blockIdx.x : nullptr;
+        if (wave <= Cas::NB) CascadeWaves<Fn, T, Cas, R, 0, true>::run(wave, fn, K, M, sj, sk, Z, tt, dtt, X0, nfull, pword, pbase);
+        __syncthreads();                                   // every wave has seen its own stores acknowledged
+        if (threadIdx.x == 0) pub_progress(pword, pbase, K);
+        return;
+    }
+    const RolloutTilesTM<T> rt{K, M, G, Z, tt, dtt, J, progress, pbase};
+    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
+}
+
+}  // namespace rd

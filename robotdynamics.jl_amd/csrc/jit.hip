@@ -326,7 +326,11 @@ static int jit_get(JitModel& M, int op_, int rule, int dtype, JitKernel** out) {
             jk.block = (ng + 4) * 64; jk.persistent = true;
             jk.lds = a16((size_t)64 * ne * nc * ts) + a16((size_t)64 * ny * ts) + a16((size_t)65 * nz * ts) + 2 * 64 * 8;
         }
-        else if (jk.small) { jk.block = 256; jk.lds = (size_t)4 * 64 * ((ny * nz + ny) | 1) * ts; }             // SmallLds<Fn,T>::BYTES
+        else if (jk.small) {             // SmallLds<Fn,T>: WAVES independent waves per workgroup, as many (4, 2, 1) as fit the LDS
+            const size_t wave_bytes = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts);
+            const int waves = 4 * wave_bytes <= 160 * 1024 ? 4 : 2 * wave_bytes <= 160 * 1024 ? 2 : 1;
+            jk.block = 64 * waves; jk.persistent = true; jk.lds = waves * wave_bytes;
+        }
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
         if (jk.lds > 64 * 1024) {
@@ -538,7 +542,8 @@ static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const L
         std::vector<unsigned char> fnm; pack_params(M, dtype, fnm);
         MultiPod pod = a.multi->pod;
         void* margs[] = {fnm.data(), &pod};
-        const unsigned gridm = km->small ? (unsigned)((pod.total + 3) / 4) : tile_grid(km->lds, km->block, pod.total);
+        const int wm = km->block / 64;
+        const unsigned gridm = km->small ? tile_grid(km->lds, km->block, (pod.total + wm - 1) / wm) : tile_grid(km->lds, km->block, pod.total);
         return launch(M, km, gridm, a.stream, margs);
     }
     JitKernel* k; int rc = jit_get(M, op, rule, dtype, &k); if (rc) return rc;
@@ -547,7 +552,7 @@ static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const L
     void* args[] = {fn.data(), &N, &Z, &t, &dt, &J, &Y};
     const long long ntiles = (N + 63) / 64;
     unsigned grid;
-    if (k->small) grid = (unsigned)((ntiles + 3) / 4);
+    if (k->small) { const int w = k->block / 64; grid = tile_grid(k->lds, k->block, (ntiles + w - 1) / w); }      // persistent: one tile per wave and pass
     else grid = tile_grid(k->lds, k->block, ntiles);   // persistent tile loop: as many workgroups as fit at once, never more than tiles
     return launch(M, k, grid, a.stream, args);
 }

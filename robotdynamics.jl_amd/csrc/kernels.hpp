@@ -575,8 +575,13 @@ template <class T> RD_DEV TileRef<T> ring_get(const long long* slot) {
     return TileRef<T>{(const T*)v[0], (const double*)v[1], (const double*)v[2], (T*)v[3], (T*)v[4], v[5], v[6]};
 }
 
+// a descriptor with WAITS = true makes the compute waves call bt.wait(tile) before they request a tile's inputs (tiles produced by other
+// workgroups of the same launch: the fused rollout -> Jacobians kernel, fused.hpp)
+template <class BT, class = void> struct WaitsOf { static constexpr bool value = false; };
+template <class BT> struct WaitsOf<BT, decltype((void)BT::WAITS)> { static constexpr bool value = BT::WAITS; };
+// wg / nwg: this workgroup's index among the nwg workgroups that share the tiles (the whole grid unless the launch has other roles as well)
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
-RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
+RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg) {
     // per batch: N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
     constexpr int NA = AuxOf<Fn>::N;
@@ -610,14 +615,14 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
 #if defined(RD_TILE_MAP) && RD_TILE_MAP == 0     // tuning: the plain order
     if (false) {
 #elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: XCD ranges at every size
-    if ((gridDim.x & 7) == 0) {
+    if ((nwg & 7) == 0 && !WaitsOf<BT>::value) {
 #else
-    if ((gridDim.x & 7) == 0 && ntiles >= 64 * (long long)gridDim.x) {
+    if ((nwg & 7) == 0 && ntiles >= 64 * (long long)nwg && !WaitsOf<BT>::value) {     // (tiles that are waited for keep the order in which they become available)
 #endif
-        const long long ntx = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
-        tile = xcd * ntx + (blockIdx.x >> 3);
-        tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = gridDim.x >> 3;
-    } else { tile = blockIdx.x; tend = ntiles; tstep = gridDim.x; }
+        const long long ntx = (ntiles + 7) / 8, xcd = wg & 7;
+        tile = xcd * ntx + (wg >> 3);
+        tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
+    } else { tile = wg; tend = ntiles; tstep = nwg; }
     if (tile >= tend) return;
 
     if (wave < NG) {
@@ -630,6 +635,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
         TileRef<T> cur = bt.at(tile);
+        if constexpr (WaitsOf<BT>::value) bt.wait(tile);
         {   // first tile: all of a thread's loads are issued before any is waited for (a load -> wait -> LDS-write loop costs one memory
             // round trip per pass: five of them in front of the first arithmetic of the kernel)
             const long long k0 = cur.k0, N = cur.N, NIN = N + Fn::NEXT;
@@ -664,6 +670,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
             TileRef<T> nx;
             if (RING_N > 0 && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
             else nx = bt.at(more ? nxt : tile);
+            if constexpr (WaitsOf<BT>::value) { if (more) bt.wait(nxt); }
             const long long k1 = nx.k0;
             const T* __restrict__ Z = nx.Z;
             const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
@@ -791,6 +798,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) {
         }
     }
 }
+template <class Fn, class T, class Plan, int NC, class Body, class BT>
+RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) { jac_split_loop<Fn, T, Plan, NC, Body, BT>(fn, bt, blockIdx.x, gridDim.x); }
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
@@ -1012,67 +1021,120 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_errexp_split_kerne
 // compile-time constants so structural zeros fold), the wave's 64 x (n x (n+m) + n) results are transposed through a
 // wave-private LDS region and leave as linear 16-B-per-lane sweeps (a wave's J and f(z) tiles are contiguous slabs).
 // Four independent waves per workgroup (no workgroup barrier), one-shot grid.
+// Persistent: wave w of workgroup b walks tiles 4 b + w, + 4 gridDim, ...; the next tile's inputs are requested before the current tile is
+// computed.  The wave's LDS region holds the J tile and the f(z) tile in their GLOBAL layout (a tile is a contiguous slab of each array), so the
+// copy-out is a linear sweep of 16-byte units -- ds_read_b128 + non-temporal global store, whole 128-byte lines, the LDS offsets fixed per lane --
+// instead of one 8-byte store with a division per element (which was 15 % of the kernel's instructions, and the kernel is VALU-bound: the cartpole's
+// RK4 Jacobian is ~1 450 fp64 instructions per 64 knot points against 12 KB of output).
 template <class Fn, class T> struct SmallLds {
-    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY;
-    static constexpr int RS = (NY * NZ + NY) | 1;                       // J then f(z) per lane, odd stride
-    static constexpr size_t WAVE_ELEMS = (size_t)TILE * RS;
-    static constexpr size_t BYTES = 4 * WAVE_ELEMS * sizeof(T);
+    static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY, JN = NY * NZ;
+    static constexpr size_t a16(size_t b) { return (b + 15) / 16 * 16; }
+    static constexpr size_t J_BYTES = a16((size_t)TILE * JN * sizeof(T)), Y_BYTES = a16((size_t)TILE * NY * sizeof(T)), Z_BYTES = a16((size_t)TILE * NZ * sizeof(T));
+    static constexpr size_t WAVE_BYTES = J_BYTES + Y_BYTES + Z_BYTES;
+    static constexpr int WAVES = 4 * WAVE_BYTES <= 160 * 1024 ? 4 : 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;     // independent waves per workgroup (block size = 64 WAVES)
+    static constexpr size_t BYTES = WAVES * WAVE_BYTES;
+    static constexpr int JU = (int)((size_t)TILE * JN * sizeof(T) / 16), YU = (int)((size_t)TILE * NY * sizeof(T) / 16);     // whole 16-byte units of a full tile
+    static_assert(((size_t)TILE * JN * sizeof(T)) % 16 == 0 && ((size_t)TILE * NY * sizeof(T)) % 16 == 0, "64-knot slabs are multiples of 16 bytes");
 };
 template <class Fn, class T, class BT>
 RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, JN = NY * NZ;
     using L = SmallLds<Fn, T>;
     using D = Dual<T, NZ>;
+    using V4 = __attribute__((ext_vector_type(4))) unsigned int;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    T* lds = reinterpret_cast<T*>(smem) + wave * L::WAVE_ELEMS;
-    const long long tile = (long long)blockIdx.x * 4 + wave;
-    if (tile >= bt.ntiles()) return;
-    const TileRef<T> ref = bt.at(tile);
-    const long long k0 = ref.k0, N = ref.N;
-    const T* __restrict__ Z = ref.Z; const double* __restrict__ tt = ref.t; const double* __restrict__ dtt = ref.dt;
-    T* __restrict__ J = ref.J; T* __restrict__ Y = ref.Y;
-    const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
-    const int kl = lane < nk ? lane : nk - 1;
-    // stage z: lane-contiguous loads of the tile's nk*NZ values -> LDS -> one knot point per lane
-    const double hd = dtt[k0 + kl];
-    const double td = tt[k0 + kl];
-    stage_in<T, TILE * NZ, TILE>(Z + k0 * NZ, lds, nk * NZ, lane);
-    const T t = (T)td, h = (T)hd;
-    const bool term = is_terminal_dt(hd);
-    wave_sync();
-    D xd[NX], ud[NU], yd[NY];
+    unsigned char* base = smem + wave * L::WAVE_BYTES;
+    T* jt = reinterpret_cast<T*>(base);
+    T* yt = reinterpret_cast<T*>(base + L::J_BYTES);
+    T* zs = reinterpret_cast<T*>(base + L::J_BYTES + L::Y_BYTES);
+    const long long ntiles = bt.ntiles(), tstep = (long long)gridDim.x * L::WAVES;
+    long long tile = (long long)blockIdx.x * L::WAVES + wave;
+    if (tile >= ntiles) return;
+    constexpr int ZPT = (TILE * NZ + TILE - 1) / TILE;        // = NZ
+    TileRef<T> cur = bt.at(tile);
+    T zpre[ZPT]; double tpre, hpre;
+    auto request = [&](const TileRef<T>& r, bool live) {       // the tile's inputs -> registers (lane-contiguous; lanes past the end re-read element 0)
+        const int nkr = live ? (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE) : 0;
+        const T* __restrict__ Zr = r.Z + r.k0 * NZ;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        xd[i].v = lds[kl * NZ + i];
+        for (int i = 0; i < ZPT; ++i) { const int e = i * TILE + lane; zpre[i] = Zr[e < nkr * NZ ? e : 0]; }
+        const int kl = lane < nkr ? lane : (nkr > 0 ? nkr - 1 : 0);
+        tpre = r.t[r.k0 + kl]; hpre = r.dt[r.k0 + kl];
+    };
+    request(cur, true);
+    for (; tile < ntiles; tile += tstep) {
+        const long long k0 = cur.k0;
+        const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
+        const int kl = lane < nk ? lane : nk - 1;
+        // this tile's inputs: registers -> LDS -> one knot point per lane
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) xd[i].d[j] = (i == j) ? T(1) : T(0);
-    }
+        for (int i = 0; i < ZPT; ++i) { const int e = i * TILE + lane; if (e < TILE * NZ) zs[e] = zpre[i]; }
+        const T t = (T)tpre, h = (T)hpre;
+        const bool term = is_terminal_dt(hpre);
+        wave_sync();
+        D xd[NX], ud[NU], yd[NY];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        ud[i].v = term ? T(0) : lds[kl * NZ + NX + i];
+        for (int i = 0; i < NX; ++i) {
+            xd[i].v = zs[kl * NZ + i];
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) ud[i].d[j] = (NX + i == j) ? T(1) : T(0);
-    }
-    wave_sync();                                            // everybody has read its inputs: the region becomes the output tile
-    fn.eval(xd, ud, t, h, yd);
-    T* row = lds + lane * L::RS;
+            for (int j = 0; j < NZ; ++j) xd[i].d[j] = (i == j) ? T(1) : T(0);
+        }
 #pragma unroll
-    for (int c = 0; c < NZ; ++c) {
-        const T sc = (c >= NX && term) ? T(0) : T(1);       // control columns of a terminal knot point are zero
+        for (int i = 0; i < NU; ++i) {
+            ud[i].v = term ? T(0) : zs[kl * NZ + NX + i];
 #pragma unroll
-        for (int i = 0; i < NY; ++i) row[c * NY + i] = yd[i].d[c] * sc;
-    }
+            for (int j = 0; j < NZ; ++j) ud[i].d[j] = (NX + i == j) ? T(1) : T(0);
+        }
+        wave_sync();
+        // the next tile's inputs are requested now and consumed at the top of the next iteration
+        const long long nxt = tile + tstep;
+        const bool more = nxt < ntiles;
+        const TileRef<T> nx = bt.at(more ? nxt : tile);
+        request(nx, more);
+        __builtin_amdgcn_sched_barrier(0);
+        fn.eval(xd, ud, t, h, yd);
+        T* row = jt + lane * JN;
 #pragma unroll
-    for (int i = 0; i < NY; ++i) row[JN + i] = yd[i].v;
-    wave_sync();
-    // copy-out: element e of the J tile is (knot e / JN, offset e % JN); consecutive lanes -> consecutive addresses
-    T* Jt = J + k0 * JN;
-    for (int e = lane; e < nk * JN; e += TILE) { const int r = e / JN; Jt[e] = lds[r * L::RS + (e - r * JN)]; }
-    if (Y) {
-        T* Yt = Y + k0 * NY;
-        for (int e = lane; e < nk * NY; e += TILE) { const int r = e / NY; Yt[e] = lds[r * L::RS + JN + (e - r * NY)]; }
+        for (int c = 0; c < NZ; ++c) {
+            const T sc = (c >= NX && term) ? T(0) : T(1);       // control columns of a terminal knot point are zero
+#pragma unroll
+            for (int i = 0; i < NY; ++i) row[c * NY + i] = yd[i].d[c] * sc;
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) yt[lane * NY + i] = yd[i].v;
+        wave_sync();
+        // copy-out: the tile slabs J[k0 ..] and Y[k0 ..] are contiguous
+        T* Jt = cur.J + k0 * JN;
+        T* Yt = cur.Y ? cur.Y + k0 * NY : nullptr;
+        const bool al16 = ((reinterpret_cast<unsigned long long>(Jt) | reinterpret_cast<unsigned long long>(Yt)) & 15) == 0;
+        if (al16) {
+            const int jbytes = nk * JN * (int)sizeof(T), ybytes = nk * NY * (int)sizeof(T);
+            const V4* jsrc = reinterpret_cast<const V4*>(jt);
+            V4* jdst = reinterpret_cast<V4*>(Jt);
+#pragma unroll
+            for (int r = 0; r < (L::JU + TILE - 1) / TILE; ++r) {
+                const int u = r * TILE + lane;
+                if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jsrc[u]);
+                else if (u * 16 < jbytes) { for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= jbytes) Jt[u * (16 / sizeof(T)) + q] = jt[u * (16 / sizeof(T)) + q]; }
+            }
+            if (Yt) {
+                const V4* ysrc = reinterpret_cast<const V4*>(yt);
+                V4* ydst = reinterpret_cast<V4*>(Yt);
+#pragma unroll
+                for (int r = 0; r < (L::YU + TILE - 1) / TILE; ++r) {
+                    const int u = r * TILE + lane;
+                    if (u * 16 + 16 <= ybytes) RD_TILE_STORE(ydst + u, ysrc[u]);
+                    else if (u * 16 < ybytes) { for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= ybytes) Yt[u * (16 / sizeof(T)) + q] = yt[u * (16 / sizeof(T)) + q]; }
+                }
+            }
+        } else {                                                // slabs that are only sizeof(T)-aligned: element by element
+            for (int e = lane; e < nk * JN; e += TILE) Jt[e] = jt[e];
+            if (Yt) for (int e = lane; e < nk * NY; e += TILE) Yt[e] = yt[e];
+        }
+        wave_sync();
+        cur = nx;
     }
 }
 template <class Fn, class T>

@@ -98,7 +98,70 @@ RD_DEV void sincos_(double x, double& sn, double& cs) {
         cs = ((n + 1) & 2) ? -b : b;
     } else { sn = sin(x); cs = cos(x); }
 }
-RD_DEV void sincos_(float x, float& sn, float& cs) { sn = sinf(x); cs = cosf(x); }   // (through the fp64 path: fewer instructions but a longer dependent chain -- the fp32 rollout ran 1.6x slower)
+// fp32: one shared three-constant Cody-Waite reduction by pi/2 (exact products inside the FMAs) and the Cephes single-precision polynomials on
+// [-pi/4, pi/4]: <= 1.6 ulp for |x| < 1e5 (checked against float64 sin / cos on 3 10^6 arguments per decade), ~22 instructions for both values.
+// The device library's sinf + cosf (each with its own reduction and large-argument branch) cost ~3x that, and a cartpole rollout step is four
+// dependent stages of them: 0.78 us per fp32 RK4 step, slower than the 13-state satellite's.  Larger arguments fall back to the library.
+RD_DEV void sincos_fast_(float x, float& sn, float& cs) {
+    const float fn = __builtin_rintf(x * 6.3661977237e-01f);
+    float r = __builtin_fmaf(-fn, 1.5707963705062866f, x);
+    r = __builtin_fmaf(-fn, -4.371138828673793e-08f, r);
+    r = __builtin_fmaf(-fn, -1.7151245100058819e-15f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float ks = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float kc = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int n = (int)fn;
+    const float a = (n & 1) ? kc : ks, b = (n & 1) ? ks : kc;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+// the same polynomials behind a reduction carried out in DOUBLE precision (two-constant Cody-Waite with exact products inside the FMAs): no range
+// limit worth a branch -- <= 1.6 ulp up to 1e7, absolute error below 1e-7 as long as the quadrant count fits a double (|x| < 9e15, where
+// consecutive floats are 10^9 apart) -- at the price of three conversions
+RD_DEV void sincos_wide_(float x, float& sn, float& cs) {
+    const double xd = (double)x;
+    const double fn = __builtin_rint(xd * 6.36619772367581382433e-01);
+    double rd = __builtin_fma(-fn, 1.5707963267948966, xd);
+    rd = __builtin_fma(-fn, 6.123233995736766e-17, rd);
+    const float r = (float)rd;
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float ks = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float kc = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int n = (int)(fn - 4.0 * __builtin_rint(fn * 0.25));      // quadrant, -2 .. 2
+    const float a = (n & 1) ? kc : ks, b = (n & 1) ? ks : kc;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+#ifndef RD_SINCOSF
+#define RD_SINCOSF 4
+#endif
+RD_DEV void sincos_(float x, float& sn, float& cs) {
+#if RD_SINCOSF == 0          // tuning: the device library
+    sn = sinf(x); cs = cosf(x);
+#elif RD_SINCOSF == 1        // tuning: per-lane branch
+    if (__builtin_fabsf(x) < 1.0e5f) sincos_fast_(x, sn, cs); else { sn = sinf(x); cs = cosf(x); }
+#elif RD_SINCOSF == 2        // tuning: no fallback at all
+    sincos_fast_(x, sn, cs);
+#elif RD_SINCOSF == 4
+    // No branch: a branch to a library fallback for large arguments -- per lane or per wavefront -- sits on the latency chain of every rollout step
+    // (four dependent stages of it) and measured 0.87 / 0.73 us per fp32 RK4 cartpole step against 0.48 without one (library: 0.77).
+    sincos_wide_(x, sn, cs);
+#else
+    // the fast path unconditionally (straight-line code on the latency chain of a rollout step); the library only if SOME lane of the wavefront
+    // holds an argument beyond the reduction's range -- one wave-uniform scalar branch, never taken for physical angles
+    sincos_fast_(x, sn, cs);
+    const bool big = !(__builtin_fabsf(x) < 1.0e5f);
+    if (__builtin_amdgcn_ballot_w64(big) != 0) { if (big) { sn = sinf(x); cs = cosf(x); } }
+#endif
+}
 RD_DEV float sin_(float a) { float s, c; sincos_(a, s, c); return s; }
 RD_DEV float cos_(float a) { float s, c; sincos_(a, s, c); return c; }
 RD_DEV float sqrt_(float a) { return sqrtf(a); }
@@ -106,7 +169,9 @@ RD_DEV double sin_(double a) { double s, c; sincos_(a, s, c); return s; }
 RD_DEV double cos_(double a) { double s, c; sincos_(a, s, c); return c; }
 RD_DEV double sqrt_(double a) { return sqrt(a); }
 // 1 / a: one division shared by several quotients with the same denominator (each quotient then differs from a true division by <= 1 ulp)
-RD_DEV float recip_(float a) { return 1.0f / a; }
+// fp32: hardware reciprocal (1 ulp) + one Newton step instead of the ten-instruction IEEE division sequence -- within an ulp of 1 / a, and a third
+// of the depth on a rollout step's latency chain (the cartpole evaluates one per stage)
+RD_DEV float recip_(float a) { const float r = __builtin_amdgcn_rcpf(a); return __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r); }
 RD_DEV double recip_(double a) { return 1.0 / a; }
 // max(0, a) with ForwardDiff's tie rule: ifelse(0 > a, 0, a)
 RD_DEV float max0_(float a) { return (0.0f > a) ? 0.0f : a; }
@@ -131,7 +196,7 @@ template <class T, int K> RD_DEV Dual<T, K> sqrt_(const Dual<T, K>& a) {
     return r;
 }
 template <class T, int K> RD_DEV Dual<T, K> recip_(const Dual<T, K>& a) {
-    Dual<T, K> r; r.v = T(1) / a.v; const T c = -(r.v * r.v);
+    Dual<T, K> r; r.v = recip_(a.v); const T c = -(r.v * r.v);
 #pragma unroll
     for (int i = 0; i < K; ++i) r.d[i] = c * a.d[i];
     return r;

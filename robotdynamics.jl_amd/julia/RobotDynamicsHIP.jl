@@ -874,6 +874,43 @@ function rollout_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.
                    _p(Zs.data), _p(Zs.t), _p(Zs.dt), _p(x0), _p(J), sp)
     end
     check(c, rc)
+    k = Ref{Cint}(0)          # kernel launches issued: 1 = rollout and Jacobians overlapped in one launch
+    check(c, ccall((:rdhip_ctx_last_rollout_jacobian_launches, librdhip), Cint, (Ptr{Cvoid}, Ref{Cint}), c.ptr, k))
+    Int(k[])
+end
+
+# rollout! + jacobian! along the rollouts for several MODELS in one call (the mixed-model Monte-Carlo batch: even trajectories one model, odd ones
+# another): every model on its own internal stream between one fork and one join, so the rollouts' latency chains run side by side
+function rollout_jacobian_multi!(::RD.FunctionSignature, diff::RD.DiffMethod, funs::Vector{<:RD.DiscretizedDynamics}, Js::Vector, Zs::Vector, Ks::Vector{<:Integer},
+                                 x0s::Union{Nothing,Vector}=nothing; time_major::Bool=false, ctx::Union{Nothing,Context}=nothing)
+    nm = length(funs)
+    length(Js) == nm && length(Zs) == nm && length(Ks) == nm && (x0s === nothing || length(x0s) == nm) || throw(DimensionMismatch("one entry per model"))
+    nm == 0 && return nothing
+    T = eltype(Zs[1].data)
+    all_arrays = Any[]
+    Ms = Clonglong[]
+    for p = 1:nm
+        _checkmodel(funs[p], Zs[p]); _checkdiff(funs[p], diff)
+        eltype(Zs[p].data) == T || throw(ArgumentError("all stacks must share one element type"))
+        N = length(Zs[p]); M = Ks[p] == 0 ? 0 : div(N, Ks[p])
+        M * Ks[p] == N || throw(DimensionMismatch("stack $p must hold whole trajectories of K knot points"))
+        push!(Ms, M)
+        push!(all_arrays, Zs[p].data, Zs[p].t, Zs[p].dt, Js[p])
+        x0s === nothing || x0s[p] === nothing || push!(all_arrays, x0s[p])
+    end
+    sp, found = _where(all_arrays...)
+    c = _ctx(ctx, found)
+    hs = Ptr{Cvoid}[handle(f) for f in funs]; rules = Cint[rulecode(f) for f in funs]; Kc = Clonglong[k for k in Ks]
+    pZ = Ptr{Cvoid}[_p(Z.data) for Z in Zs]; pt = Ptr{Cvoid}[_p(Z.t) for Z in Zs]; pdt = Ptr{Cvoid}[_p(Z.dt) for Z in Zs]
+    pX = Ptr{Cvoid}[(x0s === nothing ? C_NULL : _p(x0s[p])) for p = 1:nm]
+    pJ = Ptr{Cvoid}[_p(J) for J in Js]
+    GC.@preserve funs Js Zs x0s begin
+        rc = ccall((:rdhip_rollout_jacobian_multi, librdhip), Cint,
+                   (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cint}, Cint, Cint, Ptr{Clonglong}, Ptr{Clonglong}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}},
+                    Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint),
+                   c.ptr, nm, hs, rules, diffcode(diff), dtypecode(T), Kc, Ms, time_major ? TIME_MAJOR : TRAJECTORY_MAJOR, pZ, pt, pdt, pX, pJ, sp)
+    end
+    check(c, rc)
 end
 
 # jacobian! for several INDEPENDENT packed trajectories (different arrays) in ONE kernel launch: a trajectory of a few thousand knot points is

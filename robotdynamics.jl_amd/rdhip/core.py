@@ -1786,6 +1786,68 @@ def rollout_jacobian_(sig, diff, model, J, Z, x0=None, time_major=False):
     ctx, space = _resolve_ctx([az, at, adt, a0, aj])
     L.check(L.lib().rdhip_rollout_jacobian(ctx.handle, cm._handle, rule, diff.code, az.dtype, K, M, 1 if time_major else 0,
                                            az.ptr, at.ptr, adt.ptr, a0.ptr, aj.ptr, space), ctx.handle)
+    k = C.c_int(0)
+    L.check(L.lib().rdhip_ctx_last_rollout_jacobian_launches(ctx.handle, C.byref(k)), ctx.handle)
+    return k.value          # kernel launches issued: 1 = rollout and Jacobians overlapped in one launch, 2 (or more) = one after the other
+
+
+class PreparedRolloutJacobianMulti:
+    """rollout! + jacobian! along the rollouts for several MODELS in one call (rdhip_rollout_jacobian_multi): the mixed-model Monte-Carlo batch.
+    models / Js / Zs / x0s list one entry per model (Zs[p] = {"data", "t", "dt"} stacks as for rollout_jacobian_).  Argument checking happens once;
+    calling the object re-issues the call (array contents may change, their memory may not)."""
+
+    def __init__(self, sig, diff, models, Js, Zs, x0s=None, time_major=False):
+        if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
+            raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+        nm = len(models)
+        if not (len(Js) == len(Zs) == nm) or (x0s is not None and len(x0s) != nm):
+            raise ValueError("models, Js, Zs (and x0s) must list one entry per model")
+        if nm > 4:
+            raise ValueError("at most four models per call")
+        handles, rules = (C.c_void_p * max(nm, 1))(), (C.c_int * max(nm, 1))()
+        Ks, Ms = (C.c_longlong * max(nm, 1))(), (C.c_longlong * max(nm, 1))()
+        tabs = [(C.c_void_p * max(nm, 1))() for _ in range(5)]
+        args, dtype = [], None
+        for p, (model, J, Z) in enumerate(zip(models, Js, Zs)):
+            cm, rule = _model_rule(model)
+            if rule in (L.CONTINUOUS, L.IMPLICIT_MIDPOINT):
+                raise TypeError("rollout_jacobian_multi_ takes explicit DiscreteDynamics models")
+            data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
+            n, m = state_dim(model), control_dim(model)
+            _check_stack(data3, t2, dt2, n + m)
+            K, M = (data3.shape[0], data3.shape[1]) if time_major else (data3.shape[1], data3.shape[0])
+            x0 = None if x0s is None else x0s[p]
+            if x0 is not None and tuple(x0.shape) != (M, n):
+                raise ValueError(f"x0s[{p}] has the wrong shape")
+            _dense(J, (K * M, n, n + m), f"Js[{p}]", transposed_last2=True)
+            az, at, adt, a0 = _Arg(data3, f"Zs[{p}].data"), _Arg(t2, f"Zs[{p}].t"), _Arg(dt2, f"Zs[{p}].dt"), _Arg(x0, f"x0s[{p}]")
+            dtype = az.dtype if dtype is None else dtype
+            if az.dtype != dtype or (a0.ptr is not None and a0.dtype != dtype):
+                raise ValueError("all stacks must share one dtype")
+            aj = _Arg(J, f"Js[{p}]", dtype)
+            args += [az, at, adt, a0, aj]
+            handles[p], rules[p], Ks[p], Ms[p] = cm._handle, rule, K, M
+            for tab, a in zip(tabs, (az, at, adt, a0, aj)):
+                tab[p] = a.ptr
+        if isinstance(diff, ImplicitFunctionTheorem):
+            raise ValueError("ImplicitFunctionTheorem needs an implicit integrator")
+        ctx, space = _resolve_ctx(args) if args else (None, L.HOST)
+        self._keep = (models, Js, Zs, x0s, handles, rules, Ks, Ms, tabs)
+        self._space, self._dev, self._ctx, self._nm = space, (args[0].device if args else None), ctx, nm
+        self._args = (nm, handles, rules, diff.code, dtype if dtype is not None else L.F64, Ks, Ms, 1 if time_major else 0, *tabs, space)
+
+    def __call__(self):
+        if self._nm == 0:
+            return
+        ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
+        rc = L.lib().rdhip_rollout_jacobian_multi(ctx.handle, *self._args)
+        if rc:
+            L.check(rc, ctx.handle)
+
+
+def rollout_jacobian_multi_(sig, diff, models, Js, Zs, x0s=None, time_major=False):
+    """One call for the rollouts and the Jacobians along them of several models (see PreparedRolloutJacobianMulti)."""
+    PreparedRolloutJacobianMulti(sig, diff, models, Js, Zs, x0s, time_major)()
     return None
 
 

@@ -11,8 +11,12 @@
 #
 # What it pins that the restatement cannot (SURVEY App. A, all [3P] = third-party arithmetic not vendored in the reference checkout):
 #   * Rotations.jl: `q * r` / `q \ r` for NON-unit quaternions inside the RK stages, `kinematics`, `∇differential` (the 4x3 values of G, not
-#     just their placement), `∇²differential`, `rotation_error(q, q0, CayleyMap())`, and the MRP / RodriguesParam error maps (keys of
-#     ref_mrp_body.npz: the product serves state_diff for them and returns RDHIP_ERR_UNSUPPORTED for their dynamics until these are pinned);
+#     just their placement), `∇²differential`, `rotation_error(q, q0, CayleyMap())`, and the MRP / RodriguesParam kinematics, rotations and
+#     error maps (keys of ref_mrp_body.npz / ref_rp_body.npz: the product SERVES RigidBody{MRP} / RigidBody{RodriguesParam} dynamics, Jacobians,
+#     rollouts, errstate_jacobian! and state_diff on the formulas of SURVEY App. A, pinned so far only by their definitions -- these files are
+#     what would confirm or refute them; ∇errstate_jacobian! and the fused error-state expansion stay RDHIP_ERR_UNSUPPORTED for them);
+#   * the operators added since the first generator: ImplicitMidpoint (Newton solve + ImplicitFunctionTheorem Jacobian, ref_implicit_*.npz),
+#     rollout! (ref_rollout_*.npz) and explicitly time-dependent models (stage times t, t + h/2, t + h: ref_tv_*.npz);
 #   * ForwardDiff.jl: `max(0, x)` tie rule in the quadrotor wrench;
 #   * FiniteDiff.jl: the forward-difference step rule (key `Jfd_rk4`; the reference's own tests only hold it to 1e-6).
 #
@@ -260,6 +264,127 @@ function three_param_case(::Type{R}, tag) where {R}
     npzwrite(joinpath(HERE, "ref_$(tag)_body.npz"), out)
 end
 
+# ------------------------------------------------------------------------------------------------ ImplicitMidpoint: Newton solve + IFT Jacobian
+# src/integration.jl:422-463,517-538 (defaults: 10 iterations, tolerance 1e-12); keys xn_implicit, J_ift
+function implicit_case(name)
+    d = npzread(joinpath(HERE, "dyn_$name.npz"))
+    model = model_for(name, d)
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    N = size(Z, 1)
+    dm = RD.DiscretizedDynamics{RD.ImplicitMidpoint}(model)
+    out = Dict{String,Any}("Z" => Z, "t" => t, "dt" => dt, "xn_implicit" => zeros(N, n), "J_ift" => zeros(N, n, n + m))
+    J = zeros(n, n + m); y = zeros(n)
+    for k = 1:N
+        z = knot(Z, t, dt, k, n, m)
+        RD.evaluate!(dm, y, z); out["xn_implicit"][k, :] = y
+        RD.jacobian!(RD.InPlace(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dm, J, y, z); out["J_ift"][k, :, :] = J
+    end
+    npzwrite(joinpath(HERE, "ref_implicit_$name.npz"), out)
+end
+
+# ------------------------------------------------------------------------------------------------ rollout! (src/trajectories.jl:436-441)
+# the first 8 knot points of a dyn_* fixture as ONE trajectory: controls, t, dt as stored, x0 = the first state; key X (8 x n)
+function rollout_case(name, Q, rn)
+    d = npzread(joinpath(HERE, "dyn_$name.npz"))
+    model = model_for(name, d)
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    Z, t, dt = d["Z"], d["t"], d["dt"]
+    K = min(8, size(Z, 1))
+    dm = RD.DiscretizedDynamics{Q}(model)
+    traj = RD.SampledTrajectory([knot(Z, t, dt, k, n, m) for k = 1:K])
+    RD.rollout!(RD.StaticReturn(), dm, traj, SVector{n}(Z[1, 1:n]))
+    X = zeros(K, n)
+    for k = 1:K
+        X[k, :] = RD.state(traj[k])
+    end
+    npzwrite(joinpath(HERE, "ref_rollout_$(name)_$rn.npz"), Dict("Z" => Z[1:K, :], "t" => t[1:K], "dt" => dt[1:K], "X" => X))
+end
+
+# ------------------------------------------------------------------------------------------------ explicitly time-dependent dynamics
+# dynamics(model, x, u, t) (src/dynamics.jl:81-83): the two test models of oracle/rd_oracle.cpp (M_TV_PENDULUM, M_TV_SATELLITE)
+RD.@autodiff struct TVPendulum <: RobotDynamics.ContinuousDynamics
+    a::Float64; b::Float64; w::Float64; c::Float64
+end
+RD.state_dim(::TVPendulum) = 2
+RD.control_dim(::TVPendulum) = 1
+RD.dynamics(p::TVPendulum, x, u, t) = SA[x[2], -(p.a + p.b * cos(p.w * t)) * sin(x[1]) - p.c * x[2] + u[1] + p.b * sin(p.w * t)]
+RD.@autodiff struct TVSat{R} <: RobotDynamics.RigidBody{R}
+    mass::Float64
+    J::SMatrix{3,3,Float64,9}
+    fd::Float64; td::Float64; w::Float64
+end
+RD.control_dim(::TVSat) = 6
+RD.mass(model::TVSat) = model.mass
+RD.inertia(model::TVSat) = model.J
+RD.wrenches(model::TVSat, x, u, t) = begin          # F += fd [cos wt, 0, sin wt] (world), tau += td [sin wt, cos wt, sin 2wt]
+    q = RD.orientation(model, x); wt = model.w * t
+    F = q * SA[u[1], u[2], u[3]] + model.fd * SA[cos(wt), 0.0, sin(wt)]
+    T = SA[u[4], u[5], u[6]] + model.td * SA[sin(wt), cos(wt), sin(2wt)]
+    return [F; T]
+end
+function tv_case()
+    rngZ(N, nz) = [0.1 + 0.8 * ((7919 * (i + 31 * j)) % 1000) / 1000 for i = 1:N, j = 1:nz]
+    for (tag, model) in (("pendulum", TVPendulum(2.0, 0.7, 3.0, 0.1)), ("satellite", TVSat{QR}(2.0, S33(Diagonal(SA[2.0, 3.0, 1.0])), 0.3, 0.2, 1.7)))
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        N = 16
+        Z = rngZ(N, n + m); t = collect(0:N-1) .* 0.13 .+ 0.4; dt = fill(0.05, N)
+        if n == 13
+            for k = 1:N
+                Z[k, 4:7] = normalize(Z[k, 4:7] .- 0.5)
+            end
+        end
+        out = Dict{String,Any}("Z" => Z, "t" => t, "dt" => dt, "xdot" => zeros(N, n), "xn_rk4" => zeros(N, n), "Jd_rk4" => zeros(N, n, n + m), "xn_rk3" => zeros(N, n))
+        J = zeros(n, n + m); y = zeros(n)
+        for k = 1:N
+            z = knot(Z, t, dt, k, n, m)
+            out["xdot"][k, :] = RD.dynamics(model, z)
+            out["xn_rk3"][k, :] = RD.discrete_dynamics(RD.DiscretizedDynamics{RD.RK3}(model), z)
+            dm = RD.DiscretizedDynamics{RD.RK4}(model)
+            out["xn_rk4"][k, :] = RD.discrete_dynamics(dm, z)
+            RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), dm, J, y, z); out["Jd_rk4"][k, :, :] = J
+        end
+        npzwrite(joinpath(HERE, "ref_tv_$tag.npz"), out)
+    end
+end
+
+# ------------------------------------------------------------------------------------------------ the Julia host of this repository, once per wrapper
+# (robotdynamics.jl_amd/julia/RobotDynamicsHIP.jl needs librdhip.so and a GPU: skipped with a message otherwise).  Every batched wrapper is
+# called once on a small satellite batch and compared with the reference's per-knot loop computed above in this same session.
+function host_smoke()
+    jl = normpath(joinpath(HERE, "..", "..", "robotdynamics.jl_amd", "julia", "RobotDynamicsHIP.jl"))
+    try
+        include(jl)
+    catch err
+        println("RobotDynamicsHIP not exercised (", sprint(showerror, err), ")"); return
+    end
+    H = Main.RobotDynamicsHIP
+    if H.device_count() == 0
+        println("RobotDynamicsHIP loaded; no GPU: wrappers not called"); return
+    end
+    d = npzread(joinpath(HERE, "dyn_satellite_world.npz"))
+    Z, t, dt = d["Z"], d["t"], d["dt"]; N = size(Z, 1)
+    ref = Sat{QR}(Float64(d["mass"][]), S33(d["J"]), false)
+    hm = H.Satellite(Float64(d["mass"][]), Matrix(d["J"]))
+    dm = RD.DiscretizedDynamics{RD.RK4}(hm)
+    P = H.PackedTrajectory{13,6,Float64}(permutedims(Z), t, dt)
+    J = zeros(13, 19, N); Y = zeros(13, N)
+    RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, P)
+    Jr = zeros(13, 19); yr = zeros(13); worst = 0.0
+    for k = 1:N
+        RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), RD.DiscretizedDynamics{RD.RK4}(ref), Jr, yr, knot(Z, t, dt, k, 13, 6))
+        worst = max(worst, maximum(abs.(J[:, :, k] .- Jr)), maximum(abs.(Y[:, k] .- yr)))
+    end
+    println("RobotDynamicsHIP jacobian! vs RobotDynamics per-knot loop: max |diff| = ", worst)
+    Xd = zeros(13, N); RD.dynamics!(hm, Xd, P)
+    Xn = zeros(13, N); RD.discrete_dynamics!(dm, Xn, P)
+    G = zeros(13, 12, N); RD.errstate_jacobian!(hm, G, P)
+    dX = zeros(12, N); RD.state_diff!(hm, dX, Z[:, 1:13]', circshift(Z[:, 1:13], (1, 0))')
+    E = zeros(12, 18, N - 1); H.error_expansion!(dm, E, nothing, P)
+    H.rollout_jacobian!(RD.StaticReturn(), RD.ForwardAD(), dm, J, P, N)
+    println("RobotDynamicsHIP: dynamics!, discrete_dynamics!, errstate_jacobian!, state_diff!, error_expansion!, rollout_jacobian! ran")
+end
+
 function main()
     dyn = sort([replace(basename(f), r"^dyn_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "dyn_") && endswith(f, ".npz")])
     foreach(dyn_case, dyn)
@@ -267,6 +392,12 @@ function main()
     foreach(err_case, [replace(basename(f), r"^err_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "err_") && endswith(f, ".npz")])
     three_param_case(MRP{Float64}, "mrp")
     three_param_case(RodriguesParam{Float64}, "rp")
+    foreach(implicit_case, ["cartpole", "satellite_world", "quadrotor_world", "di2"])
+    for (Q, rn) in ((RD.RK4, "rk4"), (RD.RK3, "rk3"), (RD.ImplicitMidpoint, "implicit")), name in ("cartpole", "satellite_world", "quadrotor_body")
+        rollout_case(name, Q, rn)
+    end
+    tv_case()
+    host_smoke()
     println("wrote reference-generated fixtures ref_*.npz to ", HERE, " (RobotDynamics ", pkgversion(RD), ")")
 end
 

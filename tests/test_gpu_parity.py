@@ -476,6 +476,14 @@ def test_sincos_argument_reduction_over_the_whole_range():
     Jo, Yo = om.jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
     np.testing.assert_allclose(host(Y), Yo, rtol=1e-13, atol=1e-9)
     np.testing.assert_allclose(host(J), Jo, rtol=1e-12, atol=TOL)
+    # fp32 has its own sincos_ (three-constant reduction below 1e5, library beyond): a few float ulps of the fp64 oracle at angles float can resolve
+    th32 = np.concatenate([np.array([1e-30, 1e-4, 0.5, 3.0, 1e2, 12345.678, 9.9e4, 99999.9, 1.0e5, 100000.1, 1e6]), rng.uniform(-1e5, 1e5, 4000),
+                           rng.uniform(-50, 50, 3000), np.arange(1, 2000) * (np.pi / 2)]).astype(np.float32)
+    th32 = np.concatenate([th32, -th32])
+    Z32 = rng.random((th32.size, 5)).astype(np.float32); Z32[:, 1] = th32
+    t32, dt32 = np.zeros(th32.size), np.full(th32.size, 1e-3)
+    got = host(RD.dynamics(model, traj(model, Z32, t32, dt32, "cuda", dtype=np.float32))).astype(np.float64)
+    np.testing.assert_allclose(got, om.dynamics(Z32.astype(np.float64), t32, dt32), rtol=3e-5, atol=3e-5)
 
 
 @pytest.mark.parametrize("where", ["host", "cuda"])
@@ -1409,6 +1417,132 @@ def test_rollout_then_jacobians_in_one_call(case):
     np.testing.assert_allclose(Jg.reshape(Jref.shape), Jref, rtol=0, atol=1e-8 if implicit else TOL)
     if after is not None:
         assert abs(float(after) - float(Jref.sum())) <= 1e-6 * max(1.0, abs(float(Jref.sum())))
+
+
+@pytest.mark.parametrize("case", ["satellite_f64_rk4_512x41", "satellite_f64_rk4_130x14_ragged", "quadrotor_f64_rk3_192x6", "satellite_f32_rk4_132x30",
+                                  "satellite_f64_rk4_64x1", "satellite_f64_rk4_66x2", "satellite_body_f64_euler_128x9", "satellite_f64_rk4_129x7_unaligned",
+                                  "satellite_f32_rk4_130x5_unaligned"])
+def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
+    """rdhip_rollout_jacobian on time-major stacks of a rigid body is ONE launch (csrc/fused.hpp): rollout workgroups publish every finished chunk
+    of 4 steps in a progress word, Jacobian workgroups on the other compute units consume the chunks behind them.  It must reproduce the oracle's
+    sequential rollout and Jacobians, agree with the two-call path (states bit for bit: rdhip_rollout runs the SAME kernel with rollout workgroups
+    only; Jacobians to the last bit or two: the same column code in a separately compiled kernel), survive being called again
+    (the words of an earlier call must not satisfy a later one) and being replayed from a captured graph; stacks whose tiles do not start on
+    16-byte boundaries (odd M in fp64, M % 4 != 0 in fp32) take the two launches."""
+    parts = case.split("_")
+    body = parts[1] == "body"
+    if body:
+        parts.pop(1)
+    name, prec, rname, shape = parts[0], parts[1], parts[2], parts[3]
+    M, K = (int(v) for v in shape.split("x"))
+    rng = np.random.default_rng(900 + M + K)
+    if name == "satellite":
+        model, om, mctl = RD.Satellite(bodyframe=body), O.satellite(1.0, np.eye(3), O.FRAME_BODY if body else O.FRAME_WORLD), 6
+    else:
+        model, om, mctl = RD.Quadrotor(), O.quadrotor(), 4
+    rule, orule = {"rk4": (RD.RK4, O.RK4), "rk3": (RD.RK3, O.RK3), "euler": (RD.Euler, O.EULER)}[rname]
+    f32 = prec == "f32"
+    cast = (lambda a: a.astype(np.float32)) if f32 else (lambda a: a)
+    dm = RD.DiscretizedDynamics(model, rule)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    expect_fused = "unaligned" not in case
+    for trial in range(3):                                  # three calls on the same context: every call has its own epoch
+        data = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
+        t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy()
+        dt = np.full((M, K), 0.02); dt[:, -1] = 0.0
+        x0 = data[:, 0, :13].copy(); x0[:, 7:] *= 0.5
+        with_x0 = trial != 1
+        ref = om.rollout(orule, data, t, dt, X0=x0 if with_x0 else None)
+        Jref = om.jacobian(orule, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 13 + mctl)
+        mk = lambda: {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(1, 0, 2)))).cuda(),       # noqa: E731
+                      "t": torch.as_tensor(np.ascontiguousarray(t.T)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T)).cuda()}
+        X0 = torch.as_tensor(cast(x0)).cuda() if with_x0 else None
+        st1 = mk()
+        J1 = RD.alloc_jacobians(dm, K * M, st1["data"]).fill_(7.0)
+        launches = RD.rollout_jacobian_(sig, AD, dm, J1, st1, X0, time_major=True)
+        assert launches == (1 if expect_fused else 2), launches
+        got = host(st1["data"]).astype(np.float64).transpose(1, 0, 2)
+        Jg = host(J1).astype(np.float64).reshape(K, M, 13, 13 + mctl).transpose(1, 0, 2, 3)
+        if f32:
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(Jg, Jref, rtol=2e-3, atol=2e-3)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
+            np.testing.assert_allclose(Jg, Jref, rtol=0, atol=TOL)
+        # the two-call path: rdhip_rollout (trajectory-major stack) on a fresh copy of the inputs, then rdhip_jacobian on the simulated knots
+        st2 = {"data": torch.as_tensor(cast(data)).cuda(), "t": torch.as_tensor(t).cuda(), "dt": torch.as_tensor(dt).cuda()}
+        RD.rollout_(sig, dm, st2, X0)
+        assert torch.equal(st1["data"], st2["data"].transpose(0, 1))
+        J2 = RD.alloc_jacobians(dm, K * M, st1["data"])
+        flat = RD.PackedTrajectory(13, mctl, st1["data"].reshape(K * M, 13 + mctl), st1["t"].reshape(-1), st1["dt"].reshape(-1))
+        RD.jacobian_(sig, AD, dm, J2, None, flat)
+        # the Jacobian workgroups run the flagship's column code compiled into the fused kernel: a separate instantiation, whose FMA contraction
+        # may differ in the last bit (like the column-split kernel of small batches)
+        np.testing.assert_allclose(host(J1), host(J2), rtol=0, atol=1e-5 if f32 else 1e-13)
+    if not expect_fused or K < 3:
+        return
+    # replayed from a captured graph (the recorded epoch is reused: the capture carries a node that clears the progress words)
+    from rdhip import _lib as L
+    s1 = torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        st = mk()
+        J = RD.alloc_jacobians(dm, K * M, st["data"])
+        RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=True)          # once outside the capture (kernel attributes)
+        torch.cuda.synchronize()
+        ctx = L.context_for(0, s1.cuda_stream)
+        ctx.begin_capture()
+        RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=True)
+        g = ctx.end_capture()
+        for rep in range(2):
+            fresh = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
+            st["data"].copy_(torch.as_tensor(cast(np.ascontiguousarray(fresh.transpose(1, 0, 2)))))
+            J.zero_()
+            ctx.launch(g)
+            torch.cuda.synchronize()
+            ref = om.rollout(orule, fresh, t, dt, X0=x0 if with_x0 else None)
+            Jr = om.jacobian(orule, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 13 + mctl)
+            np.testing.assert_allclose(host(st["data"]).astype(np.float64).transpose(1, 0, 2), ref, rtol=2e-4 if f32 else 0, atol=2e-4 if f32 else TOL)
+            np.testing.assert_allclose(host(J).astype(np.float64).reshape(K, M, 13, 13 + mctl).transpose(1, 0, 2, 3), Jr, rtol=2e-3 if f32 else 0, atol=2e-3 if f32 else TOL)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_mixed_model_rollouts_and_jacobians_in_one_call(prec):
+    """rdhip_rollout_jacobian_multi (BASELINE config 5's shape: a Monte-Carlo batch whose trajectories belong to different models): Cartpole,
+    Satellite and Quadrotor stacks in ONE call, every model on its own internal stream between a fork and a join.  Each model's states and
+    Jacobians must be exactly what its own rdhip_rollout_jacobian call gives (the same kernels), match the oracle, and be complete for work
+    queued on the caller's stream right after the call; repeated calls must not see each other's progress words."""
+    rng = np.random.default_rng(77)
+    f32 = prec == "f32"
+    cast = (lambda a: a.astype(np.float32)) if f32 else (lambda a: a)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    specs = [(RD.Cartpole(), O.cartpole(), 1, 132, 30), (RD.Satellite(), O.satellite(), 6, 192, 25), (RD.Quadrotor(), O.quadrotor(), 4, 68, 11)]
+    for trial in range(2):
+        funs, stacks, Js, x0s, refs = [], [], [], [], []
+        for model, om, mctl, M, K in specs:
+            n = RD.state_dim(model)
+            data = (H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0) if n == 13 else rng.random((M * K, n + mctl))).reshape(M, K, n + mctl)
+            t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy(); dt = np.full((M, K), 0.02); dt[:, -1] = 0.0
+            x0 = data[:, 0, :n].copy() * 0.9
+            dm = RD.DiscretizedDynamics(model, RD.RK4)
+            mk = lambda: {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(1, 0, 2)))).cuda(),       # noqa: E731
+                          "t": torch.as_tensor(np.ascontiguousarray(t.T)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T)).cuda()}
+            st = mk()
+            funs.append(dm); stacks.append(st); Js.append(RD.alloc_jacobians(dm, K * M, st["data"]).fill_(3.0)); x0s.append(torch.as_tensor(cast(x0)).cuda())
+            ref = om.rollout(O.RK4, data, t, dt, X0=x0)
+            Jref = om.jacobian(O.RK4, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, n, n + mctl)
+            # the single-model call on a copy
+            st1 = mk(); J1 = RD.alloc_jacobians(dm, K * M, st1["data"])
+            RD.rollout_jacobian_(sig, AD, dm, J1, st1, x0s[-1], time_major=True)
+            refs.append((ref, Jref, st1, J1, M, K, n, mctl))
+        RD.rollout_jacobian_multi_(sig, AD, funs, Js, stacks, x0s, time_major=True)
+        sums = [float(J.double().sum()) for J in Js]          # work on the caller's stream behind the call
+        for p, (ref, Jref, st1, J1, M, K, n, mctl) in enumerate(refs):
+            assert torch.equal(stacks[p]["data"], st1["data"]) and torch.equal(Js[p], J1)
+            got = host(stacks[p]["data"]).astype(np.float64).transpose(1, 0, 2)
+            Jg = host(Js[p]).astype(np.float64).reshape(K, M, n, n + mctl).transpose(1, 0, 2, 3)
+            np.testing.assert_allclose(got, ref, rtol=3e-4 if f32 else 0, atol=3e-4 if f32 else TOL)
+            np.testing.assert_allclose(Jg, Jref, rtol=3e-3 if f32 else 0, atol=3e-3 if f32 else TOL)
+            assert abs(sums[p] - float(J1.double().sum())) <= 1e-9 * max(1.0, abs(sums[p]))
 
 
 @pytest.mark.parametrize("rtag", ["mrp", "rp"])

@@ -218,7 +218,43 @@ def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
             emit(name + ": rollout_ + jacobian_ (two calls)", M * K, "f64" if T == 8 else "f32", us, alg, {"trajectories": M, "knots": K})
         us = timed(lambda i: RD.rollout_jacobian_(sig, AD, fun, J, stack, time_major=tm), reps, warm=2)
         emit(name + (": rollout_jacobian_ time-major" if tm else ": rollout_jacobian_ trajectory-major"), M * K, "f64" if T == 8 else "f32", us, alg,
-             {"trajectories": M, "knots": K})
+             {"trajectories": M, "knots": K, "kernel_launches_per_call": RD.rollout_jacobian_(sig, AD, fun, J, stack, time_major=tm)})
+
+
+def c5_case(reps, rng):
+    """One GPU's share of BASELINE config 5: 512 Cartpole + 512 Satellite trajectories x 256 knots, fp32, rollouts + all Jacobians:
+    (a) four calls (rollout_, jacobian_ per model), (b) one rdhip_rollout_jacobian call per model, (c) ONE rdhip_rollout_jacobian_multi call."""
+    M, K, dtype = 512, 256, np.float32
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    funs, stacks_tm, stacks_tj, Js, flats, alg = [], [], [], [], [], 0
+    for model, mctl in ((RD.Cartpole(), 1), (RD.Satellite(), 6)):
+        n = RD.state_dim(model)
+        Zn = (rigid_inputs(M * K, mctl, rng) if n == 13 else rng.random((M * K, n + mctl))).astype(dtype)
+        fun = RD.DiscretizedDynamics(model, RD.RK4)
+        tk = np.arange(K) * 0.01
+        tm = {"data": torch.from_numpy(Zn.reshape(K, M, n + mctl)).to(DEV), "t": torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tk[:, None], (K, M)))).to(DEV),
+              "dt": torch.full((K, M), 0.01, dtype=torch.float64, device=DEV)}
+        tj = {"data": torch.from_numpy(Zn.reshape(M, K, n + mctl)).to(DEV), "t": torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tk[None, :], (M, K)))).to(DEV),
+              "dt": torch.full((M, K), 0.01, dtype=torch.float64, device=DEV)}
+        funs.append(fun); stacks_tm.append(tm); stacks_tj.append(tj); Js.append(RD.alloc_jacobians(fun, M * K, tm["data"]))
+        flats.append(RD.PackedTrajectory(n, mctl, tj["data"].reshape(M * K, n + mctl), tj["t"].reshape(-1), tj["dt"].reshape(-1)))
+        alg += M * K * ((n + mctl) * 4 + 16 + n * 4) + M * K * ((n + mctl) * 4 + 16 + n * (n + mctl) * 4)
+
+    def four(i):
+        for p in range(2):
+            RD.rollout_(sig, funs[p], stacks_tj[p])
+            RD.jacobian_(sig, AD, funs[p], Js[p], None, flats[p])
+    us = timed(four, reps, warm=2)
+    emit("C5 share (512 cartpole + 512 satellite x 256, fp32): rollout_ + jacobian_ per model (four calls)", 2 * M * K, "f32", us, alg)
+
+    def two(i):
+        for p in range(2):
+            RD.rollout_jacobian_(sig, AD, funs[p], Js[p], stacks_tm[p], time_major=True)
+    us = timed(two, reps, warm=2)
+    emit("C5 share: rollout_jacobian_ per model, time-major (two calls)", 2 * M * K, "f32", us, alg)
+    call = RD.PreparedRolloutJacobianMulti(sig, AD, funs, Js, stacks_tm, None, time_major=True)
+    us = timed(lambda i: call(), reps, warm=2)
+    emit("C5 share: ONE call (rdhip_rollout_jacobian_multi), time-major", 2 * M * K, "f32", us, alg)
 
 
 def multi_case(name, model, gen, nbatch, per, rule, dtype, reps, singles=True, diff=None):
@@ -299,6 +335,12 @@ def main():
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
         return
+    if a.only in ("c5", "rolljac"):
+        c5_case(10, rng)
+        rollout_case("C5 cartpole RK4 rollout fp32 512 traj x 256 knots", cart, 512, 256, RD.RK4, f32, 10, rng)
+        rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        if a.only == "c5":
+            return
     if a.only == "rolljac":
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("satellite RK4 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 5, rng)
