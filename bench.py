@@ -291,6 +291,7 @@ def main():
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
+    ap.add_argument("--no-overlap", action="store_true", help="issue every launch on the context's one stream (rounds 1-2 behaviour); default: rdhip_ctx_set_overlap(1)")
     ap.add_argument("--phase-timeout", type=float, default=240.0, help="seconds any single phase (rendezvous, timed region, RCCL exchange, extras) may take before the "
                                                                         "watchdog prints the JSON line with an error and exits")
     args = ap.parse_args()
@@ -335,8 +336,16 @@ def main():
     Ys = [torch.empty((N, NX), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     sig, diff = RD.StaticReturn(), RD.ForwardAD()
 
-    # argument checking once per output buffer (rdhip.prepare_jacobian); a step is then the bare C-ABI call, as from a Julia ccall
-    calls = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Z) for b in range(NBUF)]
+    # argument checking once per output buffer (rdhip.prepare_jacobian); a step is then the bare C-ABI call, as from a Julia ccall.
+    # ONE rdhip context that owns its stream, with launch overlap on (rdhip_ctx_set_overlap, include/rdhip.h): consecutive calls whose arrays do not
+    # intersect -- the steps of this benchmark rotate over NBUF output buffers -- alternate between the context's two streams, so a launch's
+    # prologue runs under its predecessor's tail; dependent calls keep their order through event edges.  --no-overlap: one stream.
+    from rdhip import _lib as L
+    torch.cuda.synchronize()
+    bctx = L.Context(local_rank)
+    if not args.no_overlap:
+        bctx.set_overlap(True)
+    calls = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Z, ctx=bctx) for b in range(NBUF)]
 
     def step(i):
         calls[i % NBUF]()
@@ -354,23 +363,35 @@ def main():
             torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
+    bctx.synchronize()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    # kernel time: ONE pair of HIP events around the K launches of the timed region, recorded on the stream the kernels
-    # are launched on (rdhip borrows torch's current stream): kernel_ms = event time / K = the average launch duration
-    # including the inter-launch gap, i.e. what a caller looping over batches sees per launch.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # kernel time: ONE pair of HIP events around the K launches of the timed region, recorded on the context's own stream through the library's
+    # stopwatch (rdhip_timer_start / _stop: both sit behind a join of the context's two streams): kernel_ms = event time / K = the average
+    # launch duration including the inter-launch gap, i.e. what a caller looping over batches sees per launch.
     t0 = _time.perf_counter()
-    ev0.record()
+    bctx.timer_start()
     for i in range(args.steps):
         step(i)
-    ev1.record()
+    kern_ms = bctx.timer_stop() / args.steps           # (synchronises on the stop event)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = _time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    # the same K steps on ONE stream (overlap off), as an extra: what the headline was measured as in rounds 1 and 2
+    single = None
+    if not args.no_overlap:
+        bctx.set_overlap(False)
+        for i in range(min(args.warmup, 200)):
+            step(i)
+        bctx.synchronize()
+        bctx.timer_start()
+        for i in range(args.steps):
+            step(i)
+        s_ms = bctx.timer_stop() / args.steps
+        single = {"kernel_ms": s_ms, "frac_of_hbm_peak": N * BYTES_PER_KNOT / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "launch overlap off: every launch on the context's one stream"}
+        bctx.set_overlap(True)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -399,13 +420,16 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Satellite RigidBody{QuatRotation} (n=13,m=6) RK4 discrete dynamics + ForwardAD Jacobian (BASELINE configs[2])",
                    "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
-                   "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective"},
+                   "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective",
+                   "launch_overlap": (not args.no_overlap), "context": "one rdhip context that owns its stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": tsrc,
                      "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
                      "kernel_source": "the kernel rdhip_jacobian dispatches to for this configuration (csrc/dispatch.hpp launch_jacobian); name as in profiles/r03/kernel_stats.csv",
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
     }
+    if single:
+        line["single_stream"] = single
     if rank == 0:
         wd.partial = line            # from here on a stuck extra costs the extra, not the line
     wd.arm(args.phase_timeout, "extras (multi-stream / RCCL exchange / secondary metrics)", rank)
@@ -460,6 +484,7 @@ def main():
             g1 = _time.perf_counter()
             for i in range(reps):
                 step(i)
+                bctx.synchronize()                           # (the exchange runs on torch's stream: behind the context's streams through the host)
                 exchange(i)
             torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
             gl = torch.tensor([_time.perf_counter() - g1], dtype=torch.float64, device=red_dev)

@@ -82,6 +82,17 @@ int rdhip_device_count(int* count);
 int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** out);
 int rdhip_ctx_destroy(rdhip_ctx* ctx);
 int rdhip_ctx_synchronize(rdhip_ctx* ctx);
+/* Launch overlap.  Back-to-back kernels on ONE stream cannot overlap: a launch's prologue (first inputs, first columns: ~2 us of a 27 us flagship
+ * launch) and its drain (~2.5 us) are exposed on every call.  With overlap on -- contexts that OWN their stream only -- consecutive rdhip_jacobian
+ * calls on device arrays (explicit rules, compiled-in models) alternate between the context's stream and one internal stream, so that a call's
+ * prologue runs under its predecessor's tail (the per-knot loop `for k: jacobian!(sig, diff, model, J[k], y, Z[k])`, src/functionbase.jl:242, of two
+ * batches side by side).  ORDERING RULE: results are what in-order execution gives.  A call is ordered behind every earlier call whose arrays
+ * (Z, t, dt read; J, Y written) intersect its own other than read-read -- an event edge between the two streams exactly there --, every other
+ * rdhip operation on the context (any other entry point, timers, graph capture, memcpy helpers, rdhip_ctx_stream, rdhip_ctx_synchronize) is ordered
+ * behind everything issued before it, and rdhip_ctx_fence orders the context's stream behind everything issued so far (call it before handing
+ * the stream from rdhip_ctx_stream to other code).  Off by default. */
+int rdhip_ctx_set_overlap(rdhip_ctx* ctx, int on);
+int rdhip_ctx_fence(rdhip_ctx* ctx);
 void* rdhip_ctx_stream(rdhip_ctx* ctx);
 /* message of the last failure on this context (ctx == NULL: last failure of a context-less call on this thread) */
 const char* rdhip_last_error(rdhip_ctx* ctx);

@@ -41,6 +41,18 @@ struct rdhip_ctx {
     unsigned long long* d_progress = nullptr;
     unsigned long long roll_epoch = 0;
     int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
+    // Launch overlap (rdhip_ctx_set_overlap): consecutive rdhip_jacobian calls on device arrays alternate between the context's stream and one
+    // internal stream, with an event edge only where a call touches memory a call still in flight on the OTHER stream touches; everything else
+    // joins first (side_join).  A launch's prologue then runs under its predecessor's tail, which one stream cannot do.
+    bool overlap = false;
+    hipStream_t side = nullptr;           // the internal stream
+    hipEvent_t side_done = nullptr, main_mark = nullptr, main_done = nullptr;
+    bool side_pending = false;            // work on `side` that the context's stream has not been ordered behind yet
+    bool in_overlapped_call = false;      // rdhip_jacobian's overlap path orders itself (check_common must not join)
+    unsigned flip = 0;                    // calls issued in overlap mode (parity = stream)
+    struct Range { const char* lo; const char* hi; };
+    struct Footprint { Range r[5]; int n = 0; };      // Z, t, dt (read), J, Y (written) of a call
+    std::vector<Footprint> pend[2];       // calls issued on stream 0 (the context's) / 1 (internal) that work on the OTHER stream has not been ordered behind
     // rdhip_rollout_jacobian_multi: one child context (own stream, own progress words) per additional model, created on first use
     rdhip_ctx* child[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
@@ -133,6 +145,8 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_progress) (void)hipFree(c->d_progress);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    for (hipEvent_t e : {c->side_done, c->main_mark, c->main_done}) if (e) (void)hipEventDestroy(e);
     for (auto& ch : c->child) if (ch) { (void)rdhip_ctx_destroy(ch); ch = nullptr; }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     for (auto& e : c->join_ev) if (e) (void)hipEventDestroy(e);
@@ -140,11 +154,42 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c; return RDHIP_OK;
 }
+// order the context's stream behind whatever the internal stream still runs (no-op unless overlap mode has put work there)
+static int side_join(rdhip_ctx* c) {
+    if (!c->side_pending) return RDHIP_OK;
+    HIP_TRY(c, hipEventRecord(c->side_done, c->side));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_done, 0));
+    c->side_pending = false;
+    c->pend[0].clear(); c->pend[1].clear();       // (the context's stream is ordered behind the internal one, and future internal work starts behind a fresh mark)
+    return RDHIP_OK;
+}
+int rdhip_ctx_set_overlap(rdhip_ctx* c, int on) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_ctx_set_overlap: the context is capturing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (on && !c->own_stream) return fail(c, RDHIP_ERR_UNSUPPORTED, "rdhip_ctx_set_overlap: only for contexts that own their stream (work the caller enqueues on a borrowed stream "
+                                                                     "could not be ordered behind the internal stream)");
+    if (on && !c->side) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->main_mark, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
+    }
+    if (!on) { const int rc = side_join(c); if (rc) return rc; }
+    c->overlap = on != 0;
+    return RDHIP_OK;
+}
+int rdhip_ctx_fence(rdhip_ctx* c) {
+    if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return side_join(c);
+}
 int rdhip_ctx_synchronize(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
 }
-void* rdhip_ctx_stream(rdhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* rdhip_ctx_stream(rdhip_ctx* c) { if (c) (void)side_join(c); return c ? (void*)c->stream : nullptr; }      // (overlap mode: what has been issued so far is ordered on it)
 const char* rdhip_last_error(rdhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 // ---- HIP graphs: record a sequence of device-memory calls once, replay it with one launch (small batches are launch-bound) ----
 struct rdhip_graph { hipGraph_t graph; hipGraphExec_t exec; int device; };
@@ -152,6 +197,7 @@ int rdhip_graph_begin_capture(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
     if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_begin_capture: the context is already capturing");
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
     return RDHIP_OK;
@@ -187,10 +233,12 @@ int rdhip_graph_destroy(rdhip_graph* g) {
 
 int rdhip_timer_start(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream)); return RDHIP_OK;
 }
 int rdhip_timer_stop(rdhip_ctx* c, float* ms) {
     if (!c || !ms) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1)); return RDHIP_OK;
 }
@@ -204,11 +252,13 @@ int rdhip_free(rdhip_ctx* c, void* p) {
 }
 int rdhip_memcpy_h2d(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device)); { const int rc = side_join(c); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
 }
 int rdhip_memcpy_d2h(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
-    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device)); { const int rc = side_join(c); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -383,6 +433,7 @@ static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long
     if (c->capturing && memspace == RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "host-memory calls copy and synchronise: they cannot be captured into a graph");
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    if (c->side_pending && !c->in_overlapped_call) return side_join(c);       // any other operation: ordered behind everything issued so far
     return RDHIP_OK;
 }
 // what a MRP / RodriguesParam model can do: op 0 = dynamics-type calls (the RigidBody{MRP|RodriguesParam} satellites and quadrotors, models.hpp
@@ -496,7 +547,11 @@ int rdhip_discrete_dynamics(rdhip_ctx* c, const rdhip_model* M, int rule, int dt
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";
-    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    const bool ov = c && c->overlap && memspace == RDHIP_DEVICE && !c->capturing && rule != RDHIP_IMPLICIT_MIDPOINT && M && M->d.kind != RDHIP_MODEL_CUSTOM;
+    if (c) c->in_overlapped_call = ov;
+    int rc = check_common(c, M, dtype, N, memspace);
+    if (c) c->in_overlapped_call = false;
+    if (rc) return rc;
     if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     if (N > 0 && (!Z || !t || !dt || !J)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
@@ -513,6 +568,42 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
         if (s.rc) return s.rc;
     }
     if (implicit && !a.Y && N > 0) { a.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }     // the Newton solution has to land somewhere
+    if (ov && N > 0) {
+        // overlap mode: this call goes to the stream the previous one did not use.  It is ordered behind (a) everything the context's stream held
+        // when overlap work began or was last joined -- both streams start behind `main_mark` -- and (b) the previous call, on the other stream,
+        // only if the two footprints intersect (the call before that ran on this very stream).
+        rdhip_ctx::Footprint fp;
+        auto add = [&](const void* p, size_t bytes) { if (p && bytes) { fp.r[fp.n].lo = (const char*)p; fp.r[fp.n].hi = (const char*)p + bytes; ++fp.n; } };
+        add(Z, (size_t)N * (d.n + d.m) * ts); add(t, (size_t)N * 8); add(dt, (size_t)N * 8); add(J, (size_t)N * d.n * (d.n + d.m) * ts); add(Y, (size_t)N * d.n * ts);
+        const unsigned me = c->flip & 1, other = me ^ 1;
+        const int nread = 3;                               // r[0..2] are read, the rest written
+        bool conflict = c->pend[other].size() >= 16;       // (bounded bookkeeping: a full list is cleared by an edge)
+        for (const rdhip_ctx::Footprint& q : c->pend[other])
+            for (int i = 0; i < fp.n && !conflict; ++i)
+                for (int j = 0; j < q.n && !conflict; ++j) {
+                    const bool both_read = i < nread && j < nread;
+                    if (!both_read && fp.r[i].lo < q.r[j].hi && q.r[j].lo < fp.r[i].hi) conflict = true;
+                }
+        hipStream_t mine = me == 0 ? c->stream : c->side, theirs = me == 0 ? c->side : c->stream;
+        if (me == 1 && !c->side_pending) {                 // the internal stream starts behind what the context's stream holds now
+            HIP_TRY(c, hipEventRecord(c->main_mark, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->side, c->main_mark, 0));
+            c->pend[0].clear();
+            conflict = false;
+        }
+        if (conflict) {                                    // everything issued on the other stream so far comes first
+            hipEvent_t ev = me == 0 ? c->side_done : c->main_done;
+            HIP_TRY(c, hipEventRecord(ev, theirs));
+            HIP_TRY(c, hipStreamWaitEvent(mine, ev, 0));
+            c->pend[other].clear();
+        }
+        a.stream = mine;
+        const int k = kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what);
+        c->pend[me].push_back(fp);
+        if (me == 1) c->side_pending = true;
+        ++c->flip;
+        return k;
+    }
     const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
@@ -919,6 +1010,7 @@ int rdhip_memcpy_peer(rdhip_ctx* dc, void* dst, rdhip_ctx* sc, const void* src, 
     if (!dst || !src) return fail(dc, RDHIP_ERR_INVALID_ARG, "rdhip_memcpy_peer: NULL pointer");
     // order after the producer's stream, run on the consumer's stream
     HIP_TRY(sc, hipSetDevice(sc->device));
+    { int rc = side_join(sc); if (rc) return rc; rc = side_join(dc); if (rc) return rc; }
     HIP_TRY(sc, hipEventRecord(sc->ev1, sc->stream));
     HIP_TRY(dc, hipSetDevice(dc->device));
     HIP_TRY(dc, hipStreamWaitEvent(dc->stream, sc->ev1, 0));

@@ -50,7 +50,9 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
                 using Mdl = typename std::remove_cv<decltype(Fn::m)>::type;
                 if constexpr (UnrollPolicy<Mdl, Fn::RULE_ID>::value && UnrollPolicy<Mdl, Fn::RULE_ID>::NC == 4) {
                     using Plan = typename UnrollPolicy<Mdl, Fn::RULE_ID>::Plan;
-                    if constexpr (Plan::NG == 4) {
+                    // (only where the one-launch form exists at all, i.e. while the rollout groups leave half of the chip to Jacobian workgroups: a
+                    // big batch of short rollouts is throughput-bound and keeps the leaner 256-thread kernel and its write-back stores)
+                    if constexpr (Plan::NG == 4) if (2LL * grid <= (long long)dev_info().cus) {
                         constexpr size_t ldsf = FusedLds<Fn, T, Cas, R, Plan, 4>::BYTES;
                         auto kf = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, 4>;
                         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), ldsf) != hipSuccess) return RDHIP_ERR_HIP;

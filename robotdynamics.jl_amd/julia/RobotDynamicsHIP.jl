@@ -101,6 +101,10 @@ function check(ctx::Union{Context,Nothing}, rc::Integer)
 end
 
 synchronize(ctx::Context=default_context()) = check(ctx, ccall((:rdhip_ctx_synchronize, librdhip), Cint, (Ptr{Cvoid},), ctx.ptr))
+"launch overlap: consecutive independent `jacobian!` calls on `ctx` alternate between two streams (ordering rule: include/rdhip.h)"
+set_overlap!(ctx::Context, on::Bool=true) = check(ctx, ccall((:rdhip_ctx_set_overlap, librdhip), Cint, (Ptr{Cvoid}, Cint), ctx.ptr, on ? 1 : 0))
+"order the context's stream behind everything issued so far (overlap mode keeps part of it on an internal stream)"
+fence(ctx::Context=default_context()) = check(ctx, ccall((:rdhip_ctx_fence, librdhip), Cint, (Ptr{Cvoid},), ctx.ptr))
 stream(ctx::Context) = ccall((:rdhip_ctx_stream, librdhip), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.ptr)
 
 # HIP-event stopwatch on the context's stream

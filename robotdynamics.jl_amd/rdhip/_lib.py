@@ -50,6 +50,8 @@ _SIGS = {
     "rdhip_ctx_create": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
     "rdhip_ctx_destroy": (C.c_int, [_P]),
     "rdhip_ctx_synchronize": (C.c_int, [_P]),
+    "rdhip_ctx_set_overlap": (C.c_int, [_P, C.c_int]),
+    "rdhip_ctx_fence": (C.c_int, [_P]),
     "rdhip_ctx_stream": (_P, [_P]),
     "rdhip_last_error": (C.c_char_p, [_P]),
     "rdhip_timer_start": (C.c_int, [_P]),
@@ -156,6 +158,14 @@ class Context:
 
     def synchronize(self):
         check(lib().rdhip_ctx_synchronize(self.handle), self.handle)
+
+    def set_overlap(self, on=True):
+        """Launch overlap (contexts that own their stream): consecutive independent rdhip_jacobian calls alternate between two streams."""
+        check(lib().rdhip_ctx_set_overlap(self.handle, 1 if on else 0), self.handle)
+
+    def fence(self):
+        """Order the context's stream behind everything issued so far (overlap mode keeps part of it on an internal stream)."""
+        check(lib().rdhip_ctx_fence(self.handle), self.handle)
 
     @property
     def stream(self):

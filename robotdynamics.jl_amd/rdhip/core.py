@@ -1369,11 +1369,14 @@ class PreparedJacobian:
     trajectory every iteration: the per-call host cost drops from ~15 us of Python checks to the bare C call (~5 us; a Julia
     `ccall` host pays only that anyway).  Device arrays: launched on torch's current stream at call time."""
 
-    def __init__(self, sig, diff, fun, J, y, Z):
+    def __init__(self, sig, diff, fun, J, y, Z, ctx=None):
+        """ctx: an rdhip Context that OWNS its stream (rdhip.Context(device)) to issue the call on instead of torch's current stream -- e.g. one with
+        launch overlap switched on (Context.set_overlap); the caller orders other streams against it with Context.fence() / synchronize()."""
         if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
             raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
         if not isinstance(Z, PackedTrajectory):
             raise TypeError("PreparedJacobian needs a PackedTrajectory")
+        self._own_ctx = ctx
         model, rule = _model_rule(fun)
         if rule == L.IMPLICIT_MIDPOINT:                      # src/integration.jl:517-538: implicit rules differentiate through the implicit function theorem
             if not isinstance(diff, ImplicitFunctionTheorem):
@@ -1396,14 +1399,17 @@ class PreparedJacobian:
         self._ctx = ctx
 
     def __call__(self):
-        ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
+        if self._own_ctx is not None and self._space == L.DEVICE:
+            ctx = self._own_ctx
+        else:
+            ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
         rc = self._fn(ctx.handle, *self._args)
         if rc:
             L.check(rc, ctx.handle)
 
 
-def prepare_jacobian(sig, diff, fun, J, y, Z):
-    return PreparedJacobian(sig, diff, fun, J, y, Z)
+def prepare_jacobian(sig, diff, fun, J, y, Z, ctx=None):
+    return PreparedJacobian(sig, diff, fun, J, y, Z, ctx)
 
 
 class PreparedJacobianMulti:

@@ -327,6 +327,74 @@ def test_two_streams_two_contexts_run_concurrently():
         np.testing.assert_allclose(host(Js[i]), refs[i], rtol=0, atol=TOL)
 
 
+def test_launch_overlap_keeps_dependent_calls_in_order():
+    """rdhip_ctx_set_overlap: consecutive rdhip_jacobian calls of a context alternate between two streams.  Independent calls may overlap; calls
+    whose arrays intersect (write after read, read after write, write after write) must still behave as if executed in order, other
+    operations on the context and rdhip_ctx_fence / synchronize must see everything issued before them, and a borrowed stream is refused."""
+    from rdhip import _lib as L
+    rng = np.random.default_rng(5)
+    model, om = RD.Satellite(), O.satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    N = 20000
+    ctx = L.Context(0)
+    ctx.set_overlap(True)
+    with pytest.raises(NotImplementedError):
+        L.context_for(0, torch.cuda.current_stream(0).cuda_stream).set_overlap(True)
+    Zn = [H.rand_rigid(rng, N, 6) for _ in range(3)]
+    t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+    Zs = [traj(model, z, t, dt, "cuda") for z in Zn]
+    refs = [om.jacobian(O.RK4, O.FORWARD_AD, z, t, dt) for z in Zn]
+    torch.cuda.synchronize()
+    # (1) independent calls, rotating outputs
+    Js = [RD.alloc_jacobians(dm, N, Zs[0].data) for _ in range(3)]
+    Ys = [torch.empty((N, 13), dtype=torch.float64, device="cuda") for _ in range(3)]
+    calls = [RD.prepare_jacobian(sig, AD, dm, Js[i], Ys[i], Zs[i], ctx=ctx) for i in range(3)]
+    for rep in range(4):
+        for c in calls:
+            c()
+    ctx.synchronize()
+    for i in range(3):
+        np.testing.assert_allclose(host(Js[i]), refs[i][0], rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(Ys[i]), refs[i][1], rtol=0, atol=TOL)
+    # (2) write after write on ONE output: the last call wins, every time
+    J = RD.alloc_jacobians(dm, N, Zs[0].data)
+    same = [RD.prepare_jacobian(sig, AD, dm, J, None, Zs[i], ctx=ctx) for i in range(3)]
+    for rep in range(5):
+        for c in same:
+            c()
+        ctx.synchronize()
+        np.testing.assert_allclose(host(J), refs[2][0], rtol=0, atol=TOL)
+    # (3) read after write: call B's time steps ARE memory call A writes (the head of A's f(z) output): B must see A's values
+    Ya = torch.zeros((N, 13), dtype=torch.float64, device="cuda")
+    JA, JB = RD.alloc_jacobians(dm, N, Zs[0].data), RD.alloc_jacobians(dm, N, Zs[0].data)
+    A_call = RD.prepare_jacobian(sig, AD, dm, JA, Ya, Zs[1], ctx=ctx)
+    dtB = Ya.view(-1)[:N]
+    B_call = RD.prepare_jacobian(sig, AD, dm, JB, None, RD.PackedTrajectory(13, 6, Zs[0].data, Zs[0].t, dtB), ctx=ctx)
+    dt_expected = refs[1][1].reshape(-1)[:N]
+    JBo = om.jacobian(O.RK4, O.FORWARD_AD, Zn[0], t, dt_expected)[0]
+    for rep in range(4):
+        Ya.zero_()
+        torch.cuda.synchronize()
+        A_call(); B_call()
+        ctx.synchronize()
+        np.testing.assert_allclose(host(JB), JBo, rtol=0, atol=1e-9)
+    # (4) write after read: the second call overwrites (with its Jacobians) the array the first one reads as its time steps
+    Jc = RD.alloc_jacobians(dm, N, Zs[0].data)
+    big = torch.zeros(N * 13 * 19, dtype=torch.float64, device="cuda")
+    reader = RD.prepare_jacobian(sig, AD, dm, Jc, None, RD.PackedTrajectory(13, 6, Zs[2].data, Zs[2].t, big[:N]), ctx=ctx)
+    writer = RD.prepare_jacobian(sig, AD, dm, big.view(N, 19, 13).transpose(1, 2), None, Zs[0], ctx=ctx)
+    for rep in range(4):
+        big[:N].copy_(Zs[2].dt)
+        torch.cuda.synchronize()
+        reader(); writer()                                   # the reader must have consumed its time steps before the writer overwrites them
+        ctx.synchronize()
+        np.testing.assert_allclose(host(Jc), refs[2][0], rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(big.view(N, 19, 13).transpose(1, 2)), refs[0][0], rtol=0, atol=TOL)
+    ctx.set_overlap(False)
+    ctx.close()
+
+
 def test_device_calls_can_be_captured_in_a_hip_graph():
     """A solver iteration at small N is launch-bound; with device-resident data the library only enqueues kernels on the context's
     stream, so a sequence of calls can be captured once into a HIP graph (torch.cuda.graph on ROCm) and replayed.  The replay must give
