@@ -120,7 +120,20 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     *out = nullptr;
     if (stream_mode != RDHIP_STREAM_OWN && stream_mode != RDHIP_STREAM_BORROW) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad stream_mode %d", stream_mode);
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return fail(nullptr, RDHIP_ERR_NO_DEVICE, "no HIP device available (librdhip has no CPU fallback)"); }
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        // RDHIP_DRY_RUN=1 (test hook, CPU-only hosts): a context WITHOUT a device, good for one thing -- driving the communicator bookkeeping of comm.hip
+        // against a recording stand-in for librccl (RDHIP_RCCL_LIB).  Every compute / memory entry point refuses it with RDHIP_ERR_NO_DEVICE.
+        const char* dry = getenv("RDHIP_DRY_RUN");
+        if (dry && dry[0] == '1' && device_id >= 0) {
+            rdhip_ctx* c = new (std::nothrow) rdhip_ctx();
+            if (!c) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
+            c->device = -1 - device_id; c->own_stream = false; c->stream = nullptr; c->ev0 = c->ev1 = nullptr;
+            for (int i = 0; i < 8; ++i) { c->ws[i] = nullptr; c->ws_bytes[i] = 0; }
+            *out = c; return RDHIP_OK;
+        }
+        return fail(nullptr, RDHIP_ERR_NO_DEVICE, "no HIP device available (librdhip has no CPU fallback)");
+    }
     if (device_id < 0 || device_id >= n) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, n);
     rdhip_ctx* c = new (std::nothrow) rdhip_ctx();
     if (!c) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
@@ -139,6 +152,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
 }
 int rdhip_ctx_destroy(rdhip_ctx* c) {
     if (!c) return RDHIP_OK;
+    if (c->device < 0) { delete c; return RDHIP_OK; }      // dry context: nothing on any device
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
@@ -165,6 +179,7 @@ static int side_join(rdhip_ctx* c) {
 }
 int rdhip_ctx_set_overlap(rdhip_ctx* c, int on) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_ctx_set_overlap: the context is capturing");
     HIP_TRY(c, hipSetDevice(c->device));
     if (on && !c->own_stream) return fail(c, RDHIP_ERR_UNSUPPORTED, "rdhip_ctx_set_overlap: only for contexts that own their stream (work the caller enqueues on a borrowed stream "
@@ -181,20 +196,23 @@ int rdhip_ctx_set_overlap(rdhip_ctx* c, int on) {
 }
 int rdhip_ctx_fence(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     HIP_TRY(c, hipSetDevice(c->device));
     return side_join(c);
 }
 int rdhip_ctx_synchronize(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
 }
-void* rdhip_ctx_stream(rdhip_ctx* c) { if (c) (void)side_join(c); return c ? (void*)c->stream : nullptr; }      // (overlap mode: what has been issued so far is ordered on it)
+void* rdhip_ctx_stream(rdhip_ctx* c) { if (c && c->device >= 0) (void)side_join(c); return c ? (void*)c->stream : nullptr; }      // (overlap mode: what has been issued so far is ordered on it)
 const char* rdhip_last_error(rdhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 // ---- HIP graphs: record a sequence of device-memory calls once, replay it with one launch (small batches are launch-bound) ----
 struct rdhip_graph { hipGraph_t graph; hipGraphExec_t exec; int device; };
 int rdhip_graph_begin_capture(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_begin_capture: the context is already capturing");
     HIP_TRY(c, hipSetDevice(c->device));
     { const int rc = side_join(c); if (rc) return rc; }
@@ -233,30 +251,36 @@ int rdhip_graph_destroy(rdhip_graph* g) {
 
 int rdhip_timer_start(rdhip_ctx* c) {
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream)); return RDHIP_OK;
 }
 int rdhip_timer_stop(rdhip_ctx* c, float* ms) {
     if (!c || !ms) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1)); return RDHIP_OK;
 }
 int rdhip_malloc(rdhip_ctx* c, void** p, unsigned long long bytes) {
     if (!c || !p) return fail(c, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return RDHIP_OK;
 }
 int rdhip_free(rdhip_ctx* c, void* p) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipFree(p)); return RDHIP_OK;
 }
 int rdhip_memcpy_h2d(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     HIP_TRY(c, hipSetDevice(c->device)); { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RDHIP_OK;
 }
 int rdhip_memcpy_d2h(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     HIP_TRY(c, hipSetDevice(c->device)); { const int rc = side_join(c); if (rc) return rc; }
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); return RDHIP_OK;
 }
@@ -430,6 +454,7 @@ static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long
     if (dtype != RDHIP_F64 && dtype != RDHIP_F32) return fail(c, RDHIP_ERR_INVALID_ARG, "bad dtype %d", dtype);
     if (N < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "negative N");
     if (memspace != RDHIP_DEVICE && memspace != RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "bad memspace %d", memspace);
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN): no compute entry point works on it");
     if (c->capturing && memspace == RDHIP_HOST) return fail(c, RDHIP_ERR_INVALID_ARG, "host-memory calls copy and synchronise: they cannot be captured into a graph");
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(c, RDHIP_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
@@ -935,6 +960,7 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
                                  int layout, void* const* Z, const double* const* t, const double* const* dt, const void* const* X0, void* const* J, int memspace) {
     const char* what = "rdhip_rollout_jacobian_multi";
     if (!c) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     if (nmodels < 0 || nmodels > 4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: 0 .. 4 models per call (got %d)", what, nmodels);
     if (nmodels == 0) return RDHIP_OK;
     if (!models || !rule || !K || !Mt || !Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL table", what);
@@ -1008,6 +1034,7 @@ int rdhip_memcpy_peer(rdhip_ctx* dc, void* dst, rdhip_ctx* sc, const void* src, 
     if (!dc || !sc) return fail(dc ? dc : sc, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
     if (bytes == 0) return RDHIP_OK;
     if (!dst || !src) return fail(dc, RDHIP_ERR_INVALID_ARG, "rdhip_memcpy_peer: NULL pointer");
+    if (dc->device < 0 || sc->device < 0) return fail(dc, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
     // order after the producer's stream, run on the consumer's stream
     HIP_TRY(sc, hipSetDevice(sc->device));
     { int rc = side_join(sc); if (rc) return rc; rc = side_join(dc); if (rc) return rc; }

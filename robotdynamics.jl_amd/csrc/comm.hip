@@ -71,6 +71,9 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // optional symbol of a recording stand-in (tests/rccl_stub.c): the local copy of a rank's own shard, reported instead of executed when the
+    // context has no device (RDHIP_DRY_RUN)
+    void (*StubLocalCopy)(void* dst, const void* src, unsigned long long bytes) = nullptr;
     std::string err;
 };
 
@@ -93,6 +96,7 @@ Rccl* rccl() {
         RD_SYM(CommDestroy, "ncclCommDestroy") RD_SYM(GroupStart, "ncclGroupStart") RD_SYM(GroupEnd, "ncclGroupEnd") RD_SYM(Send, "ncclSend")
         RD_SYM(Recv, "ncclRecv") RD_SYM(AllGather, "ncclAllGather") RD_SYM(GetErrorString, "ncclGetErrorString")
 #undef RD_SYM
+        R.StubLocalCopy = reinterpret_cast<decltype(R.StubLocalCopy)>(dlsym(R.so, "rdhipStubLocalCopy"));
     }
     return &R;
 }
@@ -172,7 +176,7 @@ int rdhip_comm_create_rank(rdhip_ctx* ctx, int nranks, int rank, const char id[R
     if (with_rccl) {
         Rccl* R = rccl();
         if (!R->so) { delete C; return cfail(ctx, RDHIP_ERR_UNSUPPORTED, "rdhip_comm_create_rank: %s", R->err.c_str()); }
-        if (hipSetDevice(rdhip_ctx_device_(ctx)) != hipSuccess) { delete C; return cfail(ctx, RDHIP_ERR_HIP, "hipSetDevice failed"); }
+        if (rdhip_ctx_device_(ctx) >= 0 && hipSetDevice(rdhip_ctx_device_(ctx)) != hipSuccess) { delete C; return cfail(ctx, RDHIP_ERR_HIP, "hipSetDevice failed"); }
         ncclUniqueId u; std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
         C->nccl.resize(1);
         const ncclResult_t r = R->CommInitRank(&C->nccl[0], nranks, u, rank);
@@ -231,6 +235,12 @@ int rdhip_gather(rdhip_comm* C, int mode, int root, const void* const* shard, co
         if (use_rccl && P == 1) continue;                                               // (forced 1-rank RCCL: sent to itself below)
         char* dst = static_cast<char*>(out[l]) + off[r];
         if (dst == shard[l]) continue;                                                  // computed in place inside the stack
+        if (rdhip_ctx_device_(C->ctx[l]) < 0) {                                         // dry context: the stand-in library records the copy
+            Rccl* Rs = rccl();
+            if (!Rs->so || !Rs->StubLocalCopy) return cfail(C->ctx[l], RDHIP_ERR_NO_DEVICE, "rdhip_gather: this context has no device (RDHIP_DRY_RUN) and RDHIP_RCCL_LIB is not the recording stand-in");
+            Rs->StubLocalCopy(dst, shard[l], bytes[r]);
+            continue;
+        }
         if (hipSetDevice(rdhip_ctx_device_(C->ctx[l])) != hipSuccess ||
             hipMemcpyAsync(dst, shard[l], bytes[r], hipMemcpyDeviceToDevice, (hipStream_t)rdhip_ctx_stream(C->ctx[l])) != hipSuccess)
             return cfail(C->ctx[l], RDHIP_ERR_HIP, "rdhip_gather: local copy failed: %s", hipGetErrorString(hipGetLastError()));

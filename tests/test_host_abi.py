@@ -216,6 +216,108 @@ def test_world_size_2_sharding_and_gather_gloo(N):
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _stub_comm_worker(rank, world, port, stub, logdir, sizes, q):
+    """one rank of a 2-process communicator on a CPU-only host: torch.distributed (gloo) carries the RCCL id, the library's exchange runs
+    against the recording stand-in, on contexts without a device (RDHIP_DRY_RUN)"""
+    import ctypes as C
+    import os as _os
+    _os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                        "RDHIP_RCCL_LIB": stub, "RDHIP_DRY_RUN": "1", "RDHIP_STUB_LOG": _os.path.join(logdir, f"rank{rank}.log")})
+    import torch.distributed as dist
+    from rdhip import parallel as P
+    from rdhip import _lib as L
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = P.Comm.from_torch_distributed(rank)           # rank 0 draws the id (stub), broadcast over gloo, rdhip_comm_create_rank on every rank
+        nr, nl = C.c_int(), C.c_int()
+        L.check(L.lib().rdhip_comm_size(comm.handle, C.byref(nr), C.byref(nl)))
+        shard = np.full(max(sizes[rank], 1), rank + 1, dtype=np.uint8)
+        stack = np.zeros(sum(sizes) + 1, dtype=np.uint8)
+
+        class Buf:                                           # what Comm.gather needs of a device tensor
+            def __init__(self, a): self.a = a
+            def data_ptr(self): return self.a.ctypes.data
+        out = {"size": (nr.value, nl.value), "shard": shard.ctypes.data, "stack": stack.ctypes.data}
+        for mode in ("root", "all"):
+            stack[:] = 0
+            open(_os.environ["RDHIP_STUB_LOG"], "a").write(f"mode {mode}\n")
+            comm.gather(mode, [Buf(shard)], sizes, [Buf(stack)], root=1)
+            out[mode + "_own"] = bytes(stack).count(bytes([rank + 1]))
+        comm.close()
+        # a compute entry point on the device-less context must refuse, not crash
+        ctx = L.Context(rank)
+        rc = L.lib().rdhip_ctx_synchronize(ctx.handle)
+        out["sync_rc"] = rc
+        q.put((rank, out))
+    except Exception as e:                                   # noqa: BLE001
+        q.put((rank, {"error": f"{type(e).__name__}: {e}"}))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [[4096, 4096], [1000, 3000], [0, 77]])
+def test_native_exchange_bookkeeping_world_size_2_against_a_recording_rccl(sizes, tmp_path):
+    """The RCCL exchange of the C ABI (csrc/comm.hip: rdhip_comm_unique_id / rdhip_comm_create_rank / rdhip_gather) with TWO ranks, on a host without
+    a GPU: a recording stand-in for librccl (tests/stubs/rccl_stub.c) is loaded through RDHIP_RCCL_LIB and every rank's calls are compared with
+    the tables the exchange must produce -- ROOT: every non-root rank sends its shard to the root, the root receives each at its offset in the
+    stack inside one group; ALL: ncclAllGather for equal shards, the grouped send / recv pattern for ragged ones; a rank's own shard is a local
+    copy at its offset; empty shards produce no traffic."""
+    import subprocess
+    import torch.multiprocessing as mp
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", stub, os.path.join(ROOT, "tests", "stubs", "rccl_stub.c")])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + sum(sizes)) % 2000
+    procs = [ctx.Process(target=_stub_comm_worker, args=(r, 2, port, stub, str(tmp_path), sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all("error" not in v for v in res.values()), res
+    off = [0, sizes[0]]
+    for rank in range(2):
+        info = res[rank]
+        assert info["size"] == (2, 1) and info["sync_rc"] == -5          # RDHIP_ERR_NO_DEVICE
+        lines = open(tmp_path / f"rank{rank}.log").read().split("\n")
+        assert any(ln.startswith(f"init rank={rank} nranks=2 idok=1") for ln in lines)
+        calls = {"root": [], "all": []}
+        mode = None
+        for ln in lines:
+            if ln.startswith("mode "):
+                mode = ln.split()[1]
+            elif mode and ln.split(" ")[0] in ("send", "recv", "allgather", "localcopy", "groupstart", "groupend"):
+                calls[mode].append(ln)
+        other = 1 - rank
+
+        def parse(ln):
+            f = dict(tok.split("=") for tok in ln.split()[1:] if "=" in tok)
+            return ln.split()[0], {k: int(v) for k, v in f.items()}
+        # ---- ROOT (root = rank 1)
+        ops = [parse(ln) for ln in calls["root"]]
+        sends = [o for o in ops if o[0] == "send"]; recvs = [o for o in ops if o[0] == "recv"]; copies = [o for o in ops if o[0] == "localcopy"]
+        if rank == 1:
+            assert not sends
+            assert [(r["peer"], r["bytes"], r["buf"] - info["stack"]) for _, r in recvs] == ([(0, sizes[0], 0)] if sizes[0] else [])
+            assert [(c["bytes"], c["dst"] - info["stack"], c["src"] - info["shard"]) for _, c in copies] == ([(sizes[1], off[1], 0)] if sizes[1] else [])
+            assert info["root_own"] >= sizes[1]
+        else:
+            assert [(s_["peer"], s_["bytes"], s_["buf"] - info["shard"]) for _, s_ in sends] == ([(1, sizes[0], 0)] if sizes[0] else [])
+            assert not recvs and not copies
+        assert [o[0] for o in ops].count("groupstart") == 1 and [o[0] for o in ops].count("groupend") == 1
+        # ---- ALL
+        ops = [parse(ln) for ln in calls["all"]]
+        if sizes[0] == sizes[1]:
+            ag = [o for o in ops if o[0] == "allgather"]
+            assert [(a["bytes"], a["send"] - info["shard"], a["recv"] - info["stack"]) for _, a in ag] == [(sizes[0], 0, 0)]
+            assert not [o for o in ops if o[0] in ("send", "recv", "localcopy")]
+        else:
+            sends = [o for o in ops if o[0] == "send"]; recvs = [o for o in ops if o[0] == "recv"]; copies = [o for o in ops if o[0] == "localcopy"]
+            assert [(s_["peer"], s_["bytes"]) for _, s_ in sends] == ([(other, sizes[rank])] if sizes[rank] else [])
+            assert [(r["peer"], r["bytes"], r["buf"] - info["stack"]) for _, r in recvs] == ([(other, sizes[other], off[other])] if sizes[other] else [])
+            assert [(c["bytes"], c["dst"] - info["stack"]) for _, c in copies] == ([(sizes[rank], off[rank])] if sizes[rank] else [])
+
+
 def test_shard_ranges_cover_everything():
     from rdhip import parallel as P
     for N in (0, 1, 7, 64, 65536, 262144 + 3):

@@ -52,6 +52,26 @@ def timed(fn, reps, warm=5):
     return e0.elapsed_time(e1) * 1e3 / reps    # us
 
 
+OVCTX = None       # --overlap: an rdhip context that owns its stream, launch overlap on (rdhip_ctx_set_overlap); jac_case issues its calls on it
+
+
+def timed_ctx(fn, reps, ctx, warm=5):
+    """timed() for calls issued on an rdhip context's own stream(s): the library's stopwatch (events on the context's stream behind a join)."""
+    import time
+    for i in range(warm):
+        fn(i)
+    ctx.synchronize()
+    t0, i = time.perf_counter(), 0
+    while time.perf_counter() - t0 < PREWARM_S:
+        for _ in range(20):
+            fn(i); i += 1
+        ctx.synchronize()
+    ctx.timer_start()
+    for i in range(reps):
+        fn(i)
+    return ctx.timer_stop() * 1e3 / reps
+
+
 def bare(thunks):
     """Run each checked Python call once while recording the C-ABI calls it makes, and return replays of just those C calls: the timed
     loops then measure the library (what a `ccall` host pays per call), not the ~13 us of Python argument checking per call, which is longer
@@ -95,7 +115,10 @@ def emit(name, N, dtype, us, alg_bytes, extra=None):
 
 
 def nbuf_for(bytes_per_buf):
-    return max(2, min(8, int(600e6 // max(bytes_per_buf, 1)) + 1))
+    nb = max(2, min(8, int(600e6 // max(bytes_per_buf, 1)) + 1))
+    # launch overlap alternates two streams: with an odd rotation a buffer changes streams every time round, and the write-after-write edge that
+    # (correctly) follows serialises every launch -- an artefact of the rotation, not of a caller's loop
+    return nb + (nb & 1) if OVCTX is not None else nb
 
 
 def jac_case(name, model, Zn, rule, diff, dtype, reps, with_y=True):
@@ -108,10 +131,11 @@ def jac_case(name, model, Zn, rule, diff, dtype, reps, with_y=True):
     Js = [RD.alloc_jacobians(fun, N, Z.data) for _ in range(nb)]
     Ys = [torch.empty((N, n), dtype=Z.data.dtype, device=DEV) for _ in range(nb)]
     sig = RD.StaticReturn()
-    calls = [RD.prepare_jacobian(sig, diff, fun, Js[b], Ys[b] if with_y else None, Z) for b in range(nb)]
-    us = timed(lambda i: calls[i % nb](), reps)
+    calls = [RD.prepare_jacobian(sig, diff, fun, Js[b], Ys[b] if with_y else None, Z, ctx=OVCTX) for b in range(nb)]
+    torch.cuda.synchronize()
+    us = timed_ctx(lambda i: calls[i % nb](), reps, OVCTX) if OVCTX is not None else timed(lambda i: calls[i % nb](), reps)
     alg = N * ((n + m) * T + 16 + n * (n + m) * T + (n * T if with_y else 0))
-    emit(name, N, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb})
+    emit(name, N, "f64" if T == 8 else "f32", us, alg, {"output_buffers": nb, "launch_overlap": OVCTX is not None})
 
 
 def errexp_case(name, model, Zn, rule, dtype, reps):
@@ -283,12 +307,28 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="also run the N sweep 2^12 .. 2^22 for C2/C3")
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default="", help="run only the rollout+Jacobian cases (value: rolljac)")
+    ap.add_argument("--overlap", action="store_true", help="Jacobian cases on one rdhip context with launch overlap on (rdhip_ctx_set_overlap)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
+    if a.overlap:
+        global OVCTX
+        from rdhip import _lib as L
+        OVCTX = L.Context(0)
+        OVCTX.set_overlap(True)
     rng = np.random.default_rng(7)
     f64, f32 = np.float64, np.float32
     sat, cart, quad = RD.Satellite(), RD.Cartpole(), RD.Quadrotor()
     AD, FD, UD = RD.ForwardAD(), RD.FiniteDifference(), RD.UserDefined()
+    if a.only == "sweep":
+        for p in range(12, 23):
+            N = 1 << p
+            jac_case("sweep satellite RK4 jacobian ForwardAD", sat, rigid_inputs(N, 6, rng), RD.RK4, AD, f64, max(5, min(a.reps, (1 << 24) // N)))
+        for p in range(12, 23, 2):
+            N = 1 << p
+            jac_case("sweep cartpole RK4 jacobian ForwardAD", cart, rng.random((N, 5)), RD.RK4, AD, f64, max(5, min(a.reps, (1 << 25) // N)))
+        jac_case("C5 cartpole RK4 jacobian fp32 (512 traj x 256 knots)", cart, rng.random((131072, 5)), RD.RK4, AD, f32, a.reps)
+        eval_case("large-N cartpole RK4 discrete_dynamics", cart, rng.random((1 << 22, 5)), RD.RK4, f64, 20)
+        return
     if a.only == "pair":
         pair = RD.SatellitePair()
         qa, qb = rng.standard_normal((65536, 4)), rng.standard_normal((65536, 4))
