@@ -418,16 +418,21 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         using IFn = IftFun<Mdl>;
         using IPlan = typename IftPlanOf<Mdl>::Plan;
         if constexpr (!reg_is_exact && NZ > 10 && SplitLds<IFn, T, IPlan, 4>::BYTES <= 160 * 1024) {
-            static const char* ift_mode = getenv("RDHIP_IFT");             // tuning switch: "reg" keeps the one-kernel register path
+            static const char* ift_mode = getenv("RDHIP_IFT");             // tuning switches: "reg" = the one-kernel register path, "3" = Newton kernel + tile kernel + gated exact kernel (round 2)
             if (a.flag && aligned16(a.J) && !(ift_mode && ift_mode[0] == 'r')) {
+                // ONE launch: the tile kernel's compute waves run the Newton solve themselves, x_next leaves through the tile loop's f(z) slab, and the
+                // tiles that need the exact solve are redone by their own workgroup behind the loop (implicit.hpp IftBody)
+                if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && !(ift_mode && ift_mode[0] == '3'))
+                    return launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, a.flag, a.newton_iters, 1, nullptr}, a);
                 hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
                 LaunchArgs b = a;
                 b.Y = nullptr;
-                const int rc = launch_split_kernel_j<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, (const T*)a.Y, a.flag, tile_flags}, b);
+                // (the tile kernel reads x_next from a.Y; its flag words are per tile, which the gated kernel behind it scans when word 0 carries this call's epoch)
+                const int rc = launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, (tile_flags & 1) ? a.flag : nullptr, a.newton_iters, 0, (const T*)a.Y}, b);
                 if (rc) return rc;
                 auto kern = implicit_midpoint_kernel<Mdl, T, true>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-                hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
+                hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags & 1);
                 return hip_status(hipGetLastError());
             }
         }

@@ -176,46 +176,19 @@ template <class Mdl, class T> struct ImplicitOps {
     }
 };
 
-// gate == NULL: every block of KP knot points is solved.  gate != NULL (second pass behind the register kernel): tile_flags = 0 -> the whole
-// batch iff gate[0] is set; tile_flags = 1 -> only the blocks that overlap a 64-knot tile whose word gate[1 + tile] the register kernel raised
-// (a row exchange somewhere no longer sends the whole batch through this 12x slower kernel).  Persistent grid: with nothing raised the pass
-// costs a launch of <= one workgroup per CU, not a sweep of N / KP workgroups with 93 KB of LDS each.
+// The exact solve of knot points first .. first + count - 1 (count <= KPL <= 64 lanes of one wavefront; lane-private matrices at lds, pivots behind
+// KPL of them): Newton's method with real row exchanges, and with WANT_J the implicit-function-theorem Jacobian at the last TESTED iterate.
 template <class Mdl, class T, bool WANT_J>
-__global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
-                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate, int tile_flags) {
+RD_DEV void implicit_exact_knots(const Mdl& m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt, T* __restrict__ Xn,
+                                 T* __restrict__ J, int newton_iters, double tol, long long first, int count, unsigned char* lds, int KPL) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
     using Ops = ImplicitOps<Mdl, T>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // tile_flags: bit 0 = one flag word per 64-knot tile (gate[1 + tile]) instead of the single word gate[0]; bits 8.. = the call's epoch (0: none):
-    // with tile words, gate[0] holds the epoch of the last call in which ANY tile was raised, so a pass with nothing to do ends after one load
-    // instead of scanning its tile words (the register kernels store the epoch next to the tile word they raise; no clearing, no memset)
-    const int epoch = tile_flags >> 8;
-    tile_flags &= 1;
-    if (gate && !tile_flags && *gate == 0) return;                       // second pass behind the register kernel: only if a row exchange was needed
-    if (gate && tile_flags && epoch && *gate != epoch) return;
-    const int lane = threadIdx.x;
-    T* A = reinterpret_cast<T*>(smem) + lane * L::RSA;
-    int* piv = reinterpret_cast<int*>(smem + (size_t)L::KP * L::RSA * sizeof(T)) + lane * 16;
-    const long long nblk = (N + L::KP - 1) / L::KP;
-    for (long long base = blockIdx.x; base < nblk; base += (long long)TILE * gridDim.x) {
-    // the workgroup's next 64 blocks are base + l * gridDim.x: lane l looks at the tile words of block l, ONE memory round trip decides all of them
-    unsigned long long todo = ~0ull;
-    if (gate && tile_flags) {
-        const long long b = base + (long long)lane * gridDim.x;
-        int raised = 0;
-        if (b < nblk) {
-            const long long first = b * L::KP, lastk = (first + L::KP < N ? first + L::KP : N) - 1;
-            raised = gate[1 + first / TILE] | gate[1 + lastk / TILE];
-        }
-        todo = __ballot(raised != 0);
-    }
-    for (int l = 0; l < TILE; ++l) {
-    const long long blk = base + (long long)l * gridDim.x;
-    if (blk >= nblk) break;
-    if (!((todo >> l) & 1)) continue;
-    if (threadIdx.x >= L::KP) continue;                                  // lanes without a matrix slot stay idle
-    const long long k = blk * L::KP + lane;
+    const int lane = threadIdx.x & 63;
+    if (lane >= count) return;                                           // lanes without a matrix slot stay idle
+    T* A = reinterpret_cast<T*>(lds) + lane * L::RSA;
+    int* piv = reinterpret_cast<int*>(lds + (size_t)KPL * L::RSA * sizeof(T)) + lane * 16;
+    const long long k = first + lane;
     const bool active = k < N;
     const long long kc = active ? k : N - 1;
     const double hd = dtt[kc];
@@ -260,6 +233,44 @@ __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long lon
         Ops::lu(A, piv);
         Ops::template ift_cols<0>(m, xm, u, tj, h, term, A, piv, J + kc * NX * NZ, active);
     }
+}
+
+// gate == NULL: every block of KP knot points is solved.  gate != NULL (second pass behind the register kernel): tile_flags = 0 -> the whole
+// batch iff gate[0] is set; tile_flags = 1 -> only the blocks that overlap a 64-knot tile whose word gate[1 + tile] the register kernel raised
+// (a row exchange somewhere no longer sends the whole batch through this 12x slower kernel).  Persistent grid: with nothing raised the pass
+// costs a launch of <= one workgroup per CU, not a sweep of N / KP workgroups with 93 KB of LDS each.
+template <class Mdl, class T, bool WANT_J>
+__global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
+                                                                 T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate, int tile_flags) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
+    using L = ImplicitLds<Mdl, T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // tile_flags: bit 0 = one flag word per 64-knot tile (gate[1 + tile]) instead of the single word gate[0]; bits 8.. = the call's epoch (0: none):
+    // with tile words, gate[0] holds the epoch of the last call in which ANY tile was raised, so a pass with nothing to do ends after one load
+    // instead of scanning its tile words (the register kernels store the epoch next to the tile word they raise; no clearing, no memset)
+    const int epoch = tile_flags >> 8;
+    tile_flags &= 1;
+    if (gate && !tile_flags && *gate == 0) return;                       // second pass behind the register kernel: only if a row exchange was needed
+    if (gate && tile_flags && epoch && *gate != epoch) return;
+    const int lane = threadIdx.x;
+    const long long nblk = (N + L::KP - 1) / L::KP;
+    for (long long base = blockIdx.x; base < nblk; base += (long long)TILE * gridDim.x) {
+    // the workgroup's next 64 blocks are base + l * gridDim.x: lane l looks at the tile words of block l, ONE memory round trip decides all of them
+    unsigned long long todo = ~0ull;
+    if (gate && tile_flags) {
+        const long long b = base + (long long)lane * gridDim.x;
+        int raised = 0;
+        if (b < nblk) {
+            const long long first = b * L::KP, lastk = (first + L::KP < N ? first + L::KP : N) - 1;
+            raised = gate[1 + first / TILE] | gate[1 + lastk / TILE];
+        }
+        todo = __ballot(raised != 0);
+    }
+    for (int l = 0; l < TILE; ++l) {
+    const long long blk = base + (long long)l * gridDim.x;
+    if (blk >= nblk) break;
+    if (!((todo >> l) & 1)) continue;
+    implicit_exact_knots<Mdl, T, WANT_J>(m, N, Z, tt, dtt, Xn, J, newton_iters, tol, blk * L::KP, L::KP, smem, L::KP);
     }
     }
 }
@@ -686,12 +697,13 @@ __global__ void __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(2))) 
 // register kernel does and the LDS kernel behind recomputes that tile.
 template <class Mdl> struct IftFun {
     using T = typename Mdl::T;
-    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, NCOLS = Mdl::NX + Mdl::NU, NVAL = Mdl::NX, NEXT = 0, NAUX = Mdl::NX;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NY = Mdl::NX, NCOLS = Mdl::NX + Mdl::NU, NVAL = Mdl::NX, NEXT = 0;
     Mdl m;
-    const T* xn;         // the Newton solutions (n x N)
-    int* flag;           // word 0, or word 1 + tile with tile_flags
-    int tile_flags;      // bit 0: tile words; bits 8..: the call's epoch (implicit_midpoint_kernel)
-    RD_DEV const T* aux_ptr() const { return xn; }
+    double tol;          // Newton: stop when ||residual||_2 < tol ...
+    int* flag;           // word 1 + tile: some lane of the tile needs the exact solve (row exchange / iteration limit); nullptr: never recomputed
+    int iters;           // ... or after this many iterations
+    int solve;           // 1: the compute waves run the Newton solve themselves (one launch for x_next + Jacobian); 0: x_next is read from xn
+    const T* xn;         // solve == 0: the Newton solutions (n x N) of an earlier kernel
 };
 template <class Fn, class T, class Plan, int G, int C> struct IftCols {
     using Mdl = decltype(Fn::m);
@@ -740,23 +752,52 @@ template <class Fn, class T, class Plan> struct IftBody {
     template <int CH> static RD_DEV void run(const Fn& fn, JacFrame<Fn, T>& fr) {
         T xm[NX], f[NX], a[NX][NX];
         int piv[NX];
+        // x_next: every compute wave solves its 64 knot points itself (block by block along the cascade where the model has one: ~1 000 dependent
+        // fp64 instructions, 3 us -- under the copy waves' store stream of the previous tile from the second tile on).  A separate Newton kernel in
+        // front cost its launch, 7 us with nothing to overlap, and a round trip of x_next through memory.
+        T xn[NX], xl[NX];
+        bool bad = false;
+        if (fn.solve) {
+            bool unconv = false;
+            bad = R::newton(fn.m, fr.x, fr.u, fr.t, fr.h, fn.iters, fn.tol, xn, xl, &unconv);
+            bad = bad || unconv;                                     // stopped at the iteration limit: the Jacobian belongs at the last tested iterate (exact solve)
+        } else {
+            const long long k = fr.tile * TILE + fr.kl;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xm[i] = (fr.x[i] + fr.aux[i]) * T(0.5);
+            for (int i = 0; i < NX; ++i) xn[i] = fn.xn[k * NX + i];
+        }
+        if (fr.g == Plan::value_wave && fr.want_y) fr.put_value(NX + NU, xn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xm[i] = (fr.x[i] + xn[i]) * T(0.5);
         R::template fill<0>(fn.m, xm, fr.u, fr.t, fr.t + fr.h * T(0.5), fr.h, a, f);
-        const bool need = R::lu(a, piv);
-        if (fr.g == 0 && fn.flag) {                                  // every compute wave factorises the same matrices: one of them reports
-            if (__any(need) && (threadIdx.x & 63) == 0) {
-                fn.flag[(fn.tile_flags & 1) ? 1 + fr.tile : 0] = 1;
-                if ((fn.tile_flags & 1) && (fn.tile_flags >> 8)) fn.flag[0] = fn.tile_flags >> 8;
-            }
+        const bool need = R::lu(a, piv) || bad;
+        if (fr.g == 0 && fn.flag) {                                  // every compute wave sees the same knot points: one of them reports (unconditionally: nothing is ever cleared)
+            const bool any = __any(need);
+            if ((threadIdx.x & 63) == 0 && (fn.solve || any)) fn.flag[1 + fr.tile] = any ? 1 : 0;      // (solve == 0: the Newton kernel wrote the word, this one only raises it)
         }
         waves<0>(fn, fr, xm, a, piv);
+    }
+    // behind the tile loop: the tiles of THIS workgroup that asked for the exact solve (real row exchanges; Jacobian at the last tested iterate) are
+    // redone in place by its first wavefront, with the tile's LDS as the lanes' matrices -- no second launch, and nothing to do in the usual case
+    static constexpr bool EPILOGUE = true;
+    template <class BT> static RD_DEV void epilogue(const Fn& fn, const BT& bt, long long tile, long long tend, long long tstep, unsigned char* smem, size_t smem_bytes) {
+        if (!fn.flag || !fn.solve || threadIdx.x >= TILE) return;
+        using L = ImplicitLds<Mdl, T>;
+        int kpl = (int)(smem_bytes / L::LANE_BYTES);
+        if (kpl > TILE) kpl = TILE;
+        for (; tile < tend; tile += tstep) {
+            if (__builtin_amdgcn_readfirstlane(fn.flag[1 + tile]) == 0) continue;
+            const TileRef<T> r = bt.at(tile);
+            const int nk = (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE);
+            for (int c0 = 0; c0 < nk; c0 += kpl)
+                implicit_exact_knots<Mdl, T, true>(fn.m, r.N, r.Z, r.t, r.dt, r.Y, r.J, fn.iters, fn.tol, r.k0 + c0, (nk - c0) < kpl ? (nk - c0) : kpl, smem, kpl);
+        }
     }
 };
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) implicit_ift_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                                     const double* __restrict__ dtt, T* __restrict__ J) {
-    jac_split_loop<Fn, T, Plan, NC, IftBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, nullptr});
+                                                                                     const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Xn) {
+    jac_split_loop<Fn, T, Plan, NC, IftBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Xn});
 }
 
 template <class Mdl, class T>

@@ -595,20 +595,35 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
         const size_t lds_ift = a16((size_t)64 * M.n * nz * ts) + a16((size_t)64 * M.n * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8;
         if (mode == 1 && a.flag && M.n > 6 && M.n <= 14 && nz > 10 && lds_ift <= 160 * 1024 && (reinterpret_cast<uintptr_t>(a.J) & 15) == 0) {
             JitKernel *kr, *ki;
-            rc = jit_get(M, JOP_IMPLICIT_X_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
             rc = jit_get(M, JOP_IMPLICIT_IFT, RDHIP_IMPLICIT_MIDPOINT, dtype, &ki); if (rc) return rc;
             int* flag = a.flag;
+            static const char* ift_mode = getenv("RDHIP_IFT");
+            if (tile_flags && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && !(ift_mode && ift_mode[0] == '3')) {
+                // ONE launch (dispatch.hpp launch_implicit, implicit.hpp IftBody): Newton inside the tile kernel, x_next through its f(z) slab, flagged tiles
+                // redone by their own workgroup behind the loop.  IftFun<UserModel<T>> = { UserModel m; double tol; int* flag; int iters; int solve; const T* xn; }
+                std::vector<unsigned char> one(fn);
+                one.resize((one.size() + 7) / 8 * 8);
+                const size_t o = one.size();
+                one.resize(o + 32, 0);
+                const int solve1 = 1;
+                std::memcpy(one.data() + o, &tol, 8); std::memcpy(one.data() + o + 8, &flag, 8); std::memcpy(one.data() + o + 16, &iters, 4); std::memcpy(one.data() + o + 20, &solve1, 4);
+                void* ar[] = {one.data(), &N, &Z, &t, &dt, &J, &Y};
+                return launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar);
+            }
+            rc = jit_get(M, JOP_IMPLICIT_X_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
             if (!tile_flags && hipMemsetAsync(flag, 0, sizeof(int), a.stream) != hipSuccess) { M.err = "hipMemsetAsync failed"; return RDHIP_ERR_HIP; }
             int tf2 = tile_flags | 2;
             { void* ar[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&nul, &iters, &tol, &flag, &tf2}; rc = launch(M, kr, gr, a.stream, ar); if (rc) return rc; }
-            // IftFun<UserModel<T>> = { UserModel m; const T* xn; int* flag; int tile_flags; } with the natural alignment of its members
+            // IftFun<UserModel<T>> = { UserModel m; double tol; int* flag; int iters; int solve; const T* xn; } with the natural alignment of its members
             std::vector<unsigned char> ifn(fn);
             ifn.resize((ifn.size() + 7) / 8 * 8);
             const size_t off = ifn.size();
-            ifn.resize(off + 24, 0);
-            const void* xn = Y;
-            std::memcpy(ifn.data() + off, &xn, 8); std::memcpy(ifn.data() + off + 8, &flag, 8); std::memcpy(ifn.data() + off + 16, &tile_flags, 4);
-            { void* ar[] = {ifn.data(), &N, &Z, &t, &dt, &J}; rc = launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar); if (rc) return rc; }
+            ifn.resize(off + 32, 0);
+            const void* xn = Y; const int solve0 = 0;
+            int* iflag = tile_flags ? flag : nullptr;        // (per-tile words only)
+            std::memcpy(ifn.data() + off, &tol, 8); std::memcpy(ifn.data() + off + 8, &iflag, 8); std::memcpy(ifn.data() + off + 16, &iters, 4);
+            std::memcpy(ifn.data() + off + 20, &solve0, 4); std::memcpy(ifn.data() + off + 24, &xn, 8);
+            { void* ar[] = {ifn.data(), &N, &Z, &t, &dt, &J, (void*)&nul}; rc = launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar); if (rc) return rc; }
             const int* gate2 = flag;
             void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&J, &iters, &tol, &gate2, &tile_flags};
             return launch(M, k, tile_grid(k->lds, 64, nblk), a.stream, args);

@@ -293,6 +293,8 @@ template <int NZ, int NG_, int VW, int SPLIT, int... W> struct TablePlanS : Tabl
 };
 template <class Plan, class = void> struct FirstSplitOf { static constexpr int N = 0; };
 template <class Plan> struct FirstSplitOf<Plan, decltype((void)Plan::FIRST_SPLIT)> { static constexpr int N = Plan::FIRST_SPLIT; };
+template <class Body, class = void> struct EpilogueOf { static constexpr bool value = false; };
+template <class Body> struct EpilogueOf<Body, decltype((void)Body::EPILOGUE)> { static constexpr bool value = Body::EPILOGUE; };
 template <class Body, class = void> struct EarlyOf { static constexpr bool value = false; };
 template <class Body> struct EarlyOf<Body, decltype((void)Body::EARLY)> { static constexpr bool value = Body::EARLY; };
 
@@ -624,6 +626,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
     } else { tile = wg; tend = ntiles; tstep = nwg; }
     if (tile >= tend) return;
+    const long long tile0 = tile;
 
     if (wave < NG) {
         // =========================== compute waves ===========================
@@ -796,6 +799,13 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             }
             cur = nxt;
         }
+    }
+    // a body may have work behind the tile loop (the implicit-function-theorem kernel redoes the tiles that asked for the exact solve): every wave of
+    // the workgroup has passed the same barriers, the copy waves' stores are acknowledged, and the whole dynamic LDS is free again
+    if constexpr (EpilogueOf<Body>::value) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        __syncthreads();
+        Body::epilogue(fn, bt, tile0, tend, tstep, smem, (size_t)L::BYTES);
     }
 }
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
