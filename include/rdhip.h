@@ -84,7 +84,7 @@ int rdhip_ctx_destroy(rdhip_ctx* ctx);
 int rdhip_ctx_synchronize(rdhip_ctx* ctx);
 /* Launch overlap.  Back-to-back kernels on ONE stream cannot overlap: a launch's prologue (first inputs, first columns: ~2 us of a 27 us flagship
  * launch) and its drain (~2.5 us) are exposed on every call.  With overlap on -- contexts that OWN their stream only -- consecutive rdhip_jacobian
- * calls on device arrays (explicit rules, compiled-in models) alternate between the context's stream and one internal stream, so that a call's
+ * calls on device arrays (compiled-in models; RDHIP_IMPLICIT_MIDPOINT when Y is given) alternate between the context's stream and one internal stream, so that a call's
  * prologue runs under its predecessor's tail (the per-knot loop `for k: jacobian!(sig, diff, model, J[k], y, Z[k])`, src/functionbase.jl:242, of two
  * batches side by side).  ORDERING RULE: results are what in-order execution gives.  A call is ordered behind every earlier call whose arrays
  * (Z, t, dt read; J, Y written) intersect its own other than read-read -- an event edge between the two streams exactly there --, every other

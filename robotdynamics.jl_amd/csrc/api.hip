@@ -143,7 +143,8 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) { if (c->own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); else c->stream = (hipStream_t)stream; }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc(&c->d_flag, (size_t)(1 + IMPLICIT_FLAG_WORDS) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_flag, (size_t)2 * (1 + IMPLICIT_FLAG_WORDS) * sizeof(int));     // (two sets: one per stream of the launch-overlap mode)
+    if (e == hipSuccess) e = hipMemset(c->d_flag + (1 + IMPLICIT_FLAG_WORDS), 0, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));          // word 0 = epoch of the last call that raised a tile word (0: none yet)
     if (e == hipSuccess) e = hipMalloc(&c->d_progress, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_progress, 0, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
@@ -526,11 +527,11 @@ static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, con
     }
 }
 
-static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype, LaunchArgs a) {
+static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype, LaunchArgs a, int flag_set = 0) {
     g_jit_model = nullptr;
     a.newton_iters = d.newton_iters; a.newton_tol = d.newton_tol;
     if (mode != 2) {     // Newton kernels: register pass + gated LDS pass communicate through a device word
-        a.flag = c->d_flag;
+        a.flag = c->d_flag + (size_t)flag_set * (1 + IMPLICIT_FLAG_WORDS);
         c->epoch = c->epoch >= (1 << 22) ? 1 : c->epoch + 1;
         a.epoch = c->epoch;
     }
@@ -572,7 +573,7 @@ int rdhip_discrete_dynamics(rdhip_ctx* c, const rdhip_model* M, int rule, int dt
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";
-    const bool ov = c && c->overlap && memspace == RDHIP_DEVICE && !c->capturing && rule != RDHIP_IMPLICIT_MIDPOINT && M && M->d.kind != RDHIP_MODEL_CUSTOM;
+    const bool ov = c && c->overlap && memspace == RDHIP_DEVICE && !c->capturing && M && M->d.kind != RDHIP_MODEL_CUSTOM && (rule != RDHIP_IMPLICIT_MIDPOINT || Y != nullptr);
     if (c) c->in_overlapped_call = ov;
     int rc = check_common(c, M, dtype, N, memspace);
     if (c) c->in_overlapped_call = false;
@@ -623,7 +624,8 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
             c->pend[other].clear();
         }
         a.stream = mine;
-        const int k = kernel_status(c, family_jacobian(d, rule, diff, dtype, a), what);
+        // (implicit rule: each stream has its own set of flag words, so the two launches in flight do not share any)
+        const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a, (int)me) : family_jacobian(d, rule, diff, dtype, a), what);
         c->pend[me].push_back(fp);
         if (me == 1) c->side_pending = true;
         ++c->flip;

@@ -423,7 +423,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 // ONE launch: the tile kernel's compute waves run the Newton solve themselves, x_next leaves through the tile loop's f(z) slab, and the
                 // tiles that need the exact solve are redone by their own workgroup behind the loop (implicit.hpp IftBody)
                 if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && !(ift_mode && ift_mode[0] == '3'))
-                    return launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, a.flag, a.newton_iters, 1, nullptr}, a);
+                    return launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, a.flag, a.newton_iters, IftBody<IFn, T, IPlan>::HELPER ? 2 : 1, nullptr}, a);
                 hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
                 LaunchArgs b = a;
                 b.Y = nullptr;

@@ -242,7 +242,6 @@ RD_DEV void implicit_exact_knots(const Mdl& m, long long N, const T* __restrict_
 template <class Mdl, class T, bool WANT_J>
 __global__ void __launch_bounds__(TILE) implicit_midpoint_kernel(Mdl m, long long N, const T* __restrict__ Z, const double* __restrict__ tt, const double* __restrict__ dtt,
                                                                  T* __restrict__ Xn, T* __restrict__ J, int newton_iters, double tol, const int* __restrict__ gate, int tile_flags) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, NZ = NX + NU;
     using L = ImplicitLds<Mdl, T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // tile_flags: bit 0 = one flag word per 64-knot tile (gate[1 + tile]) instead of the single word gate[0]; bits 8.. = the call's epoch (0: none):
@@ -702,7 +701,7 @@ template <class Mdl> struct IftFun {
     double tol;          // Newton: stop when ||residual||_2 < tol ...
     int* flag;           // word 1 + tile: some lane of the tile needs the exact solve (row exchange / iteration limit); nullptr: never recomputed
     int iters;           // ... or after this many iterations
-    int solve;           // 1: the compute waves run the Newton solve themselves (one launch for x_next + Jacobian); 0: x_next is read from xn
+    int solve;           // 2: the helper wave runs the Newton solve one tile ahead (one launch for x_next + Jacobian); 1: the compute waves do; 0: x_next is read from xn
     const T* xn;         // solve == 0: the Newton solutions (n x N) of an earlier kernel
 };
 template <class Fn, class T, class Plan, int G, int C> struct IftCols {
@@ -757,7 +756,12 @@ template <class Fn, class T, class Plan> struct IftBody {
         // front cost its launch, 7 us with nothing to overlap, and a round trip of x_next through memory.
         T xn[NX], xl[NX];
         bool bad = false;
-        if (fn.solve) {
+        if (fn.solve == 2) {                                         // the helper wave solved this tile while the previous one was being computed
+            const T* hx = reinterpret_cast<const T*>(fr.helper);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xn[i] = hx[fr.kl * NX + i];
+            bad = *reinterpret_cast<const int*>(fr.helper + (size_t)TILE * NX * sizeof(T)) != 0;
+        } else if (fn.solve) {
             bool unconv = false;
             bad = R::newton(fn.m, fr.x, fr.u, fr.t, fr.h, fn.iters, fn.tol, xn, xl, &unconv);
             bad = bad || unconv;                                     // stopped at the iteration limit: the Jacobian belongs at the last tested iterate (exact solve)
@@ -776,6 +780,35 @@ template <class Fn, class T, class Plan> struct IftBody {
             if ((threadIdx.x & 63) == 0 && (fn.solve || any)) fn.flag[1 + fr.tile] = any ? 1 : 0;      // (solve == 0: the Newton kernel wrote the word, this one only raises it)
         }
         waves<0>(fn, fr, xm, a, piv);
+    }
+    // The Newton solve is ~1 000 dependent fp64 instructions (3 us at the single-wave issue rate): in front of every tile's columns it made the compute
+    // waves the bottleneck (6.5 us per tile against 4.3 us of store issue: 33.7 us per launch, no faster than three launches).  One of the four
+    // copy waves takes it over, one tile AHEAD of the compute waves, and leaves x_next in an LDS double buffer; three waves issue the stores
+    // just as fast (the store stream is bound by the memory system, not by the waves that feed it).
+    static constexpr size_t HELPER_BYTES = ((size_t)TILE * NX * sizeof(T) + 16 + 15) / 16 * 16;
+    static constexpr bool HELPER = SplitLds<Fn, T, Plan, 4>::BYTES + 2 * HELPER_BYTES <= 160 * 1024;
+    template <class TR> static RD_DEV void helper_tile(const Fn& fn, const TR& r, unsigned char* dst) {
+        if (fn.solve != 2) return;
+        constexpr int NZ = NX + NU;
+        const int lane = threadIdx.x & 63;
+        const int nk = (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE);
+        const long long k = r.k0 + (lane < nk ? lane : nk - 1);
+        const double hd = r.dt[k];
+        const T h = (T)hd, tj = (T)r.t[k];
+        const bool term = is_terminal_dt(hd);
+        T x1[NX], u[NU], xn[NX], xl[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x1[i] = r.Z[k * NZ + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : r.Z[k * NZ + NX + i];
+        bool unconv = false;
+        bool bad = R::newton(fn.m, x1, u, tj, h, fn.iters, fn.tol, xn, xl, &unconv);
+        bad = bad || unconv;
+        T* hx = reinterpret_cast<T*>(dst);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hx[lane * NX + i] = xn[i];
+        const bool any = __any(bad);
+        if (lane == 0) *reinterpret_cast<int*>(dst + (size_t)TILE * NX * sizeof(T)) = any ? 1 : 0;
     }
     // behind the tile loop: the tiles of THIS workgroup that asked for the exact solve (real row exchanges; Jacobian at the last tested iterate) are
     // redone in place by its first wavefront, with the tile's LDS as the lanes' matrices -- no second launch, and nothing to do in the usual case

@@ -605,7 +605,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
                 one.resize((one.size() + 7) / 8 * 8);
                 const size_t o = one.size();
                 one.resize(o + 32, 0);
-                const int solve1 = 1;
+                const int solve1 = (lds_ift + 2 * (((size_t)64 * M.n * ts + 16 + 15) / 16 * 16) <= 160 * 1024) ? 2 : 1;       // IftBody::HELPER: the helper wave's double buffer fits next to the tile
                 std::memcpy(one.data() + o, &tol, 8); std::memcpy(one.data() + o + 8, &flag, 8); std::memcpy(one.data() + o + 16, &iters, 4); std::memcpy(one.data() + o + 20, &solve1, 4);
                 void* ar[] = {one.data(), &N, &Z, &t, &dt, &J, &Y};
                 return launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar);

@@ -293,6 +293,11 @@ template <int NZ, int NG_, int VW, int SPLIT, int... W> struct TablePlanS : Tabl
 };
 template <class Plan, class = void> struct FirstSplitOf { static constexpr int N = 0; };
 template <class Plan> struct FirstSplitOf<Plan, decltype((void)Plan::FIRST_SPLIT)> { static constexpr int N = Plan::FIRST_SPLIT; };
+// Body::HELPER: the LAST copy wave does not copy; it runs Body::helper_tile one tile ahead of the compute waves (results through an LDS double
+// buffer of Body::HELPER_BYTES each, handed to the body as fr.helper): a latency chain that must precede a tile's columns (the Newton solve of
+// the implicit-function-theorem kernel) then runs beside the previous tile's arithmetic instead of in front of this tile's
+template <class Body, class = void> struct HelperOf { static constexpr bool value = false; static constexpr size_t BYTES = 0; };
+template <class Body> struct HelperOf<Body, decltype((void)Body::HELPER)> { static constexpr bool value = Body::HELPER; static constexpr size_t BYTES = Body::HELPER_BYTES; };
 template <class Body, class = void> struct EpilogueOf { static constexpr bool value = false; };
 template <class Body> struct EpilogueOf<Body, decltype((void)Body::EPILOGUE)> { static constexpr bool value = Body::EPILOGUE; };
 template <class Body, class = void> struct EarlyOf { static constexpr bool value = false; };
@@ -318,6 +323,7 @@ template <class Fn, class T> struct JacFrame {
     int kl;          // this lane's knot point inside the tile
     long long tile;  // global tile index (split-role loop)
     bool first;      // split-role loop: this is the workgroup's first tile (bodies with EARLY pass a workgroup barrier at column Plan::FIRST_SPLIT)
+    const unsigned char* helper;   // split-role loop, bodies with HELPER: what the helper wave left for this tile (LDS)
     T aux[NA > 0 ? NA : 1];
     T x[NX], u[NU];
     T t, h;
@@ -605,6 +611,10 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     constexpr int RING_FREE = (int)((160 * 1024 - L::BYTES) / 64);
     constexpr int RING_N = !BT::RING ? 0 : RING_FREE >= 64 ? 64 : RING_FREE >= 32 ? 32 : RING_FREE >= 16 ? 16 : RING_FREE >= 8 ? 8 : 0;
     __shared__ long long ring[RING_N > 0 ? RING_N : 1][8];
+    constexpr bool HELPER = HelperOf<Body>::value;
+    constexpr int NCC = HELPER ? NC - 1 : NC;                // copy waves that copy
+    constexpr int JPLc = (L::JU + NCC * TILE - 1) / (NCC * TILE), YPLc = (L::YU + NCC * TILE - 1) / (NCC * TILE);
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = bt.ntiles();
     // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  For long
@@ -700,6 +710,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
             fr.kl = kl;
             fr.tile = tile;
+            fr.helper = hbuf + (size_t)(it & 1) * HelperOf<Body>::BYTES;
             Body::template run<0>(fn, fr);
             fr.first = false;
             if constexpr (NA > 0) {
@@ -713,9 +724,23 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
             cur = nx;
         }
+    } else if (HELPER && wave == NG + NC - 1) {
+        // =========================== helper wave =============================
+        if constexpr (HELPER) {
+            Body::helper_tile(fn, bt.at(tile), hbuf);
+            __syncthreads();                                   // barrier 0
+            bool first = ES > 0;
+            for (int it = 0; tile < tend; tile += tstep, ++it) {
+                if (first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
+                const long long nxt = tile + tstep;
+                if (nxt < tend) Body::helper_tile(fn, bt.at(nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
+                __syncthreads();                               // barrier A
+                __syncthreads();                               // barrier B
+            }
+        }
     } else {
         // =========================== copy waves ==============================
-        const int ct = threadIdx.x - NG * TILE;            // 0 .. NC*64-1
+        const int ct = threadIdx.x - NG * TILE;            // 0 .. NCC*64-1
         const V4* jsrc = reinterpret_cast<const V4*>(jt);
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
         __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
@@ -736,7 +761,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
-            V4 jv[L::JPL], yv[L::YPL];
+            V4 jv[JPLc], yv[YPLc];
             bool skip_early = false;
             if constexpr (ES > 0) {
                 if (first) {
@@ -747,8 +772,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     if (nk == TILE) {
                         V4* jd = reinterpret_cast<V4*>(cur.J + k0 * OW);
 #pragma unroll
-                        for (int r = 0; r < L::JPL; ++r) {
-                            const int u = r * (NC * TILE) + ct;
+                        for (int r = 0; r < JPLc; ++r) {
+                            const int u = r * (NCC * TILE) + ct;
                             if (u < L::JU && early_line(u)) RD_TILE_STORE(jd + u, jsrc[u]);
                         }
                         skip_early = true;
@@ -758,9 +783,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             }
             __syncthreads();                               // barrier A
 #pragma unroll
-            for (int r = 0; r < L::JPL; ++r) { const int u = r * (NC * TILE) + ct; jv[r] = jsrc[u < L::JU ? u : 0]; }
+            for (int r = 0; r < JPLc; ++r) { const int u = r * (NCC * TILE) + ct; jv[r] = jsrc[u < L::JU ? u : 0]; }
 #pragma unroll
-            for (int r = 0; r < L::YPL; ++r) { const int u = r * (NC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
+            for (int r = 0; r < YPLc; ++r) { const int u = r * (NCC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the tile is in registers
             __syncthreads();                               // barrier B
             // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
@@ -774,8 +799,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
             V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
 #pragma unroll
-            for (int r = 0; r < L::JPL; ++r) {
-                const int u = r * (NC * TILE) + ct;
+            for (int r = 0; r < JPLc; ++r) {
+                const int u = r * (NCC * TILE) + ct;
                 if (ES > 0 && skip_early && early_line(u)) continue;
                 if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
                 else if (u * 16 < jbytes) {                // partial last unit of a ragged tile: element-wise
@@ -787,8 +812,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             if (Y) {
                 V4* ydst = reinterpret_cast<V4*>(Y + k0 * NVAL);
 #pragma unroll
-                for (int r = 0; r < L::YPL; ++r) {
-                    const int u = r * (NC * TILE) + ct;
+                for (int r = 0; r < YPLc; ++r) {
+                    const int u = r * (NCC * TILE) + ct;
                     if (u * 16 + 16 <= ybytes) RD_TILE_STORE(ydst + u, yv[r]);
                     else if (u * 16 < ybytes) {
                         const T* pv = reinterpret_cast<const T*>(&yv[r]);
