@@ -166,6 +166,24 @@ def secondary_metrics(dev, reps):
     us = _timed_us(lambda i: RD.rollout_(RD.StaticReturn(), dm, stack), 20, warm=2)
     out["rollout_rk4_satellite_fp32"] = {"trajectories": Mr, "knot_points_per_trajectory": Kr, "value": Mr * (Kr - 1) / (us * 1e-6), "unit": "simulated steps/s",
                                          "us_per_launch": us, "us_per_step": us / (Kr - 1)}
+    # C5's share of one GPU in ONE call: 512 Cartpole + 512 Satellite trajectories x 256 knots, fp32, rollouts + all Jacobians (rdhip_rollout_jacobian_multi)
+    try:
+        funs, stacks, Jc = [], [], []
+        for mdl, mctl in ((RD.Cartpole(), 1), (sat, NU)):
+            n = RD.state_dim(mdl)
+            zz = synthetic_inputs(Mr * Kr, 13)[0] if n == 13 else np.random.default_rng(14).random((Mr * Kr, n + mctl))
+            fun = RD.DiscretizedDynamics(mdl, RD.RK4)
+            st = {"data": torch.as_tensor(zz.astype(np.float32).reshape(Kr, Mr, n + mctl)).to(dev),
+                  "t": torch.as_tensor(np.ascontiguousarray(np.broadcast_to((np.arange(Kr) * 0.01)[:, None], (Kr, Mr)))).to(dev),
+                  "dt": torch.full((Kr, Mr), 0.01, dtype=torch.float64, device=dev)}
+            funs.append(fun); stacks.append(st); Jc.append(RD.alloc_jacobians(fun, Mr * Kr, st["data"]))
+        c5 = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stacks, None, time_major=True)
+        us = _timed_us(lambda i: c5(), 20, warm=2)
+        out["c5_share_one_call_fp32"] = {"trajectories": 2 * Mr, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mr * Kr / (us * 1e-6),
+                                         "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi"}
+        del funs, stacks, Jc, c5
+    except Exception as e:
+        out["c5_share_one_call_fp32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # 16 x 4096: separate launches vs one fused launch
     nbt, per = 16, 4096
     Zs = []
@@ -185,6 +203,17 @@ def secondary_metrics(dev, reps):
              "frac_of_hbm_peak": tot * BYTES_PER_KNOT / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBS,
              "separate_launches_us": us_sep, "separate_frac_of_hbm_peak": tot * BYTES_PER_KNOT / (us_sep * 1e-6) / 1e9 / HBM_PEAK_GBS,
              "entry_point": "rdhip_jacobian_multi"}
+    del Js, Ys, singles, fused
+    # the reference's real unit at scale: 1 024 independent trajectories of 101 knot points (examples/cartpole.jl:46), separate arrays, ONE call
+    nbt, per = 1024, 101
+    zn, tt, dd = synthetic_inputs(nbt * per, 300)
+    Zs = [RD.PackedTrajectory(NX, NU, zn[b * per:(b + 1) * per], tt[:per], dd[:per]).to(dev) for b in range(nbt)]
+    Js = [[RD.alloc_jacobians(dm, per, Zs[0].data) for _ in range(nbt)] for _ in range(2)]
+    Ys = [[torch.empty((per, NX), dtype=torch.float64, device=dev) for _ in range(nbt)] for _ in range(2)]
+    fused = [RD.prepare_jacobian_multi(sig, AD, dm, Js[k], Ys[k], Zs) for k in range(2)]
+    us_k = _timed_us(lambda i: fused[i % 2](), max(20, reps // 4), warm=3)
+    small["trajectories_1024_x_101"] = {"one_call_us": us_k, "kernel_launches_per_call": fused[0].launches, "value": nbt * per / (us_k * 1e-6),
+                                        "frac_of_hbm_peak": nbt * per * BYTES_PER_KNOT / (us_k * 1e-6) / 1e9 / HBM_PEAK_GBS}
     return out, small
 
 

@@ -269,8 +269,10 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             static const char* mode = getenv("RDHIP_ROLLJAC");              // tuning switch: "split" keeps the two launches
             if (mode && mode[0] == 's') return RDHIP_ERR_UNSUPPORTED;
             const long long K = a.K, M = a.N;
-            if (diff != RDHIP_FORWARD_AD || !a.time_major || !a.progress || K < 1 || M < 1 || K >= (1LL << 26) || M >= (1LL << 26)) return RDHIP_ERR_UNSUPPORTED;
-            if (!aligned16(a.J) || (M * Fn::NY * (Fn::NX + Fn::NU) * (long long)sizeof(T)) % 16 != 0) return RDHIP_ERR_UNSUPPORTED;   // every knot's row of tiles starts aligned
+            if (diff != RDHIP_FORWARD_AD || !a.progress || K < 1 || M < 1 || K >= (1LL << 26) || M >= (1LL << 26)) return RDHIP_ERR_UNSUPPORTED;
+            // time-major tiles are copied as aligned 16-byte units of one slab: every knot's row of tiles must start aligned (trajectory-major
+            // tiles are gathered run by run and take any alignment)
+            if (a.time_major && (!aligned16(a.J) || (M * Fn::NY * (Fn::NX + Fn::NU) * (long long)sizeof(T)) % 16 != 0)) return RDHIP_ERR_UNSUPPORTED;
             const long long G = (M + TILE - 1) / TILE;
             using FL = FusedLds<Fn, T, Cas, R, Plan, NC>;
             constexpr size_t lds = FL::BYTES;
@@ -278,12 +280,21 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             const long long cus = dev_info().cus;
             // the rollout workgroups must leave most of the chip to the Jacobians (and all of them must be resident together with consumers)
             if (G > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
-            auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC>;
-            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-            const long long ntiles = K * G;
-            long long nj = cus - G; if (nj > ntiles) nj = ntiles;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
-                               a.progress, a.pbase);
+            if (a.time_major) {
+                auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC, true>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                const long long ntiles = K * G;
+                long long nj = cus - G; if (nj > ntiles) nj = ntiles;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                   a.progress, a.pbase);
+            } else {
+                auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC, false>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                const long long ntiles = ((K + GATHER_RUN - 1) / GATHER_RUN) * ((M + GATHER_NRUN - 1) / GATHER_NRUN);
+                long long nj = cus - G; if (nj > ntiles) nj = ntiles;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, K, 1LL, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                   a.progress, a.pbase);
+            }
             return hip_status(hipGetLastError());
         }
     }

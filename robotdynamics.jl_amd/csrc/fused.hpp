@@ -43,16 +43,42 @@ template <class T> struct RolloutTilesTM {
     }
 };
 
+// the same for a TRAJECTORY-MAJOR stack (knot k of trajectory j at flat index j K + k -- how the reference holds a batch of trajectories): a tile
+// is 16 trajectories x 4 consecutive knots (GATHER tiles of the split-role loop: 16 runs of 4 slabs), item i = (chunk i / Q of 4 knots, quarter
+// group i % Q of 16 trajectories, Q = ceil(M / 16)), again in the order of production: group g's chunk c is complete when its progress word
+// reaches knot 4 c + 3
+template <class T> struct RolloutTilesTJ {
+    static constexpr bool RING = false, WAITS = true, GATHER = true;
+    long long K, M; int Q;
+    const T* Z; const double* t; const double* dt; T* J;
+    const unsigned long long* progress; unsigned long long pbase;
+    RD_DEV long long ntiles() const { return ((K + GATHER_RUN - 1) / GATHER_RUN) * Q; }
+    RD_DEV TileRef<T> at(long long item) const {
+        const long long c = item / Q, q4 = item - c * Q, j0 = q4 * GATHER_NRUN, k = c * GATHER_RUN;
+        TileRef<T> r{Z, t, dt, J, nullptr, 0, j0 * K + k};
+        r.run_stride = K;
+        r.run_knots = (int)((K - k) < GATHER_RUN ? (K - k) : GATHER_RUN);
+        r.nruns = (int)((M - j0) < GATHER_NRUN ? (M - j0) : GATHER_NRUN);
+        return r;
+    }
+    RD_DEV void wait(long long item) const {
+        const long long c = item / Q, q4 = item - c * Q, g = q4 / (TILE / GATHER_NRUN);
+        const long long last = (c + 1) * GATHER_RUN < K ? (c + 1) * GATHER_RUN : K;            // knots 0 .. last - 1 are needed
+        const unsigned long long need = pbase | (unsigned long long)last;
+        while (__hip_atomic_load(progress + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+    }
+};
+
 constexpr int FUSED_THREADS = 8 * TILE;
 template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedLds {
-    static constexpr size_t ROLL = CascadeLds<Fn, Cas, R>::BYTES, JAC = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static constexpr size_t ROLL = CascadeLds<Fn, Cas, R>::BYTES, JAC = SplitLds<Fn, T, Plan, NC>::BYTES + SPLIT_GATHER_EXTRA;
     static constexpr size_t BYTES = ROLL > JAC ? ROLL : JAC;
     static_assert((Cas::NB + 1) * TILE <= FUSED_THREADS && (Plan::NG + NC) * TILE == FUSED_THREADS, "both roles live in one 512-thread workgroup");
 };
 // (sj, sk): strides of the rollout's data, (K, 1) = the knots of a trajectory contiguous, (1, M) = time-major.  The SAME kernel serves rdhip_rollout
 // for these models (grid = G, no Jacobian workgroups, any strides): "rollout, then Jacobians" in two calls and in one are the same machine code
-// and give the same bits.  Jacobian workgroups (grid > G) need time-major data.
-template <class Fn, class T, class Cas, int R, class Plan, int NC>
+// and give the same bits.  TM: the Jacobian workgroups' tiles are time-major slabs (RolloutTilesTM) or gathered from a trajectory-major stack (RolloutTilesTJ).
+template <class Fn, class T, class Cas, int R, class Plan, int NC, bool TM = true>
 __global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
                                                                             const double* __restrict__ tt, const double* __restrict__ dtt, const T* __restrict__ X0,
                                                                             T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase) {
@@ -71,8 +97,13 @@ __global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn 
         if (threadIdx.x == 0) pub_progress(pword, pbase, K);
         return;
     }
-    const RolloutTilesTM<T> rt{K, M, G, Z, tt, dtt, J, progress, pbase};
-    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
+    if constexpr (TM) {
+        const RolloutTilesTM<T> rt{K, M, G, Z, tt, dtt, J, progress, pbase};
+        jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
+    } else {
+        const RolloutTilesTJ<T> rt{K, M, (int)((M + GATHER_NRUN - 1) / GATHER_NRUN), Z, tt, dtt, J, progress, pbase};
+        jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
+    }
 }
 
 }  // namespace rd

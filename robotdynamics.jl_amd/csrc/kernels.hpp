@@ -193,7 +193,14 @@ template <class T> struct TileRef {
     const T* Z; const double* t; const double* dt; T* J; T* Y;
     long long N;      // knot points of the batch the tile belongs to
     long long k0;     // first knot point of the tile inside that batch
+    // descriptors with GATHER: the tile's 64 slots are GATHER_NRUN runs of GATHER_RUN consecutive knot points, run r starting at knot k0 + r run_stride
+    // (16 trajectories x 4 knots of a trajectory-major stack); the first nruns runs and the first run_knots knots of every run exist
+    long long run_stride; int run_knots; int nruns;
 };
+constexpr int GATHER_RUN = 4, GATHER_NRUN = TILE / GATHER_RUN;
+constexpr size_t SPLIT_GATHER_EXTRA = (size_t)GATHER_NRUN * 16;
+template <class BT, class = void> struct GatherOf { static constexpr bool value = false; };
+template <class BT> struct GatherOf<BT, decltype((void)BT::GATHER)> { static constexpr bool value = BT::GATHER; };
 template <class T> struct SingleBatch {
     static constexpr bool RING = false;    // at() is arithmetic
     long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
@@ -597,16 +604,24 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
 #if defined(RD_NO_EARLY)
     constexpr int ES = 0;
 #else
-    constexpr int ES = EarlyOf<Body>::value ? FirstSplitOf<Plan>::N : 0;
+    constexpr int ES = (EarlyOf<Body>::value && !GatherOf<BT>::value) ? FirstSplitOf<Plan>::N : 0;
 #endif
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
+    // GATHER tiles (runs of GATHER_RUN knot points from GATHER_NRUN places): every run of the LDS output tile is followed by 16 bytes of slack, so
+    // that a run can sit at the same offset modulo 16 as its slab in global memory (slabs of n (n+m) values are only sizeof(T)-aligned) and the
+    // copy waves still move whole aligned 16-byte units; the dynamic LDS is SPLIT_GATHER_EXTRA bytes larger
+    constexpr bool GATHER = GatherOf<BT>::value;
+    constexpr int RB = OW * (int)sizeof(T);                                        // bytes of one knot point's slab
+    constexpr int GRUN_BYTES = GATHER_RUN * RB + 16;
+    constexpr size_t JB = L::J_BYTES + (GATHER ? SPLIT_GATHER_EXTRA : 0);
+    static_assert(!GATHER || (Fn::NEXT == 0 && NC == 4 && (GATHER_RUN * RB) % 16 == 0), "gather tiles: four copy waves of four runs each");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* jt = reinterpret_cast<T*>(smem);
-    T* yt = reinterpret_cast<T*>(smem + L::J_BYTES);
-    T* zs = reinterpret_cast<T*>(smem + L::J_BYTES + L::Y_BYTES);
-    double* ts = reinterpret_cast<double*>(smem + L::J_BYTES + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
+    T* yt = reinterpret_cast<T*>(smem + JB);
+    T* zs = reinterpret_cast<T*>(smem + JB + L::Y_BYTES);
+    double* ts = reinterpret_cast<double*>(smem + JB + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     // resolved tiles of this workgroup's iterations 0 .. RING_N - 1 (static LDS next to the dynamic tile, as many entries as fit the CU's 160 KiB)
     constexpr int RING_FREE = (int)((160 * 1024 - L::BYTES) / 64);
     constexpr int RING_N = !BT::RING ? 0 : RING_FREE >= 64 ? 64 : RING_FREE >= 32 ? 32 : RING_FREE >= 16 ? 16 : RING_FREE >= 8 ? 8 : 0;
@@ -641,6 +656,14 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     if (wave < NG) {
         // =========================== compute waves ===========================
         constexpr int ZPT = (TIN * NZ + NTC - 1) / NTC;
+        // gather tiles: slot s of the tile = knot (s % GATHER_RUN) of run (s / GATHER_RUN); slots that do not exist repeat the last one that does
+        auto gather_knot = [](const TileRef<T>& r, int slot) -> long long {
+            int run = slot / GATHER_RUN, kk = slot - run * GATHER_RUN;
+            run = run < r.nruns ? run : r.nruns - 1; kk = kk < r.run_knots ? kk : r.run_knots - 1;
+            return r.k0 + run * r.run_stride + kk;
+        };
+        auto gather_z = [&](const TileRef<T>& r, int e) -> long long { const int slot = e / NZ; return gather_knot(r, slot) * NZ + (e - slot * NZ); };
+        (void)gather_knot; (void)gather_z;
         JacFrame<Fn, T> fr;
         fr.g = wave;
         fr.first = ES > 0;
@@ -656,12 +679,19 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const int nk = (int)((N - k0) < TILE ? (N - k0) : TILE);
             const int nin = (int)((NIN - k0) < TIN ? (NIN - k0) : TIN);
             T z0[ZPT]; double t0;
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[gather_z(cur, e < TILE * NZ ? e : 0)]; }
+                const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
+                t0 = tp[gather_knot(cur, threadIdx.x & (TILE - 1))];
+            } else {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[(e < nin * NZ) ? k0 * NZ + e : 0]; }
             {
                 const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 const int idx = threadIdx.x & (TILE - 1);
                 t0 = tp[(threadIdx.x < 2 * TILE && idx < nk) ? k0 + idx : 0];
+            }
             }
             if constexpr (NA > 0) {                        // lane-private extra inputs of the first tile (requested behind the tile's own loads)
                 const T* __restrict__ A = fn.aux_ptr();
@@ -689,12 +719,19 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
             const int nin1 = more ? (int)((nx.N + Fn::NEXT - k1) < TIN ? (nx.N + Fn::NEXT - k1) : TIN) : 0;
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[gather_z(nx, e < TILE * NZ ? e : 0)]; }
+                const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
+                tpre = tp[gather_knot(nx, threadIdx.x & (TILE - 1))];
+            } else {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nin1 * NZ) ? k1 * NZ + e : 0]; }
             {
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 const int idx = threadIdx.x & (TILE - 1);
                 tpre = tp[(threadIdx.x < 2 * TILE && idx < nk1) ? k1 + idx : 0];
+            }
             }
             T apre[NA > 0 ? NA : 1];
             if constexpr (NA > 0) {
@@ -704,7 +741,13 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 for (int i = 0; i < NA; ++i) apre[i] = A[ka * NA + i];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int kl = lane < nk ? lane : nk - 1;
+            const int kl = GATHER ? lane : (lane < nk ? lane : nk - 1);
+            if constexpr (GATHER) {                          // this lane's row: run (lane / 4) of the tile, shifted like the run's slab in global memory
+                const int run = lane / GATHER_RUN, kk = lane - run * GATHER_RUN;
+                const unsigned padb = (unsigned)(reinterpret_cast<unsigned long long>(cur.J + (cur.k0 + run * cur.run_stride) * OW) & 15);
+                fr.row = reinterpret_cast<T*>(smem + (size_t)run * GRUN_BYTES + padb) + kk * OW;
+                fr.want_y = false;
+            }
             const double hd = ts[TILE + kl];
             fr.t = (T)ts[kl]; fr.h = (T)hd; fr.term = is_terminal_dt(hd);
             read_knot<Fn, T>(zs, kl, fr.term, fr.x, fr.u);
@@ -757,6 +800,48 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             return l0 + 128 <= k * RB + EB;
         };
         TileRef<T> cur = bt.at(tile);
+        if constexpr (GATHER) {
+            // gather tiles: copy wave w moves runs 4 w .. 4 w + 3.  A run is GATHER_RUN consecutive slabs = one contiguous piece of global memory that
+            // starts at byte A (only sizeof(T)-aligned); in LDS it sits at the same offset modulo 16 (padb = A & 15), so the wave moves the ALIGNED
+            // 16-byte units that cover it -- whole 128-byte lines except at the two ends of the run (3 % of its lines) -- and handles the at most two
+            // partly covered units element by element.
+            constexpr int UPR = (GRUN_BYTES + 15) / 16, PASSES = (UPR + TILE - 1) / TILE, RPW = GATHER_NRUN / 4;      // units per run, sweeps per run, runs per wave
+            const int cw = ct >> 6, cl = ct & 63;
+            for (; tile < tend; tile += tstep) {
+                V4 gv[RPW * PASSES];
+                __syncthreads();                           // barrier A
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const unsigned char* lrun = smem + (size_t)(cw * RPW + q) * GRUN_BYTES;
+#pragma unroll
+                    for (int p2 = 0; p2 < PASSES; ++p2) { const int u = p2 * TILE + cl; gv[q * PASSES + p2] = *reinterpret_cast<const V4*>(lrun + 16 * (u < UPR ? u : 0)); }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the tile is in registers
+                __syncthreads();                           // barrier B
+                const long long nxt_tile = tile + tstep;
+                const TileRef<T> nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) {
+                    const int run = cw * RPW + q;
+                    unsigned char* A = reinterpret_cast<unsigned char*>(cur.J + (cur.k0 + run * cur.run_stride) * OW);
+                    const int padb = (int)(reinterpret_cast<unsigned long long>(A) & 15);
+                    const int lo = padb, hi = padb + (run < cur.nruns ? cur.run_knots * RB : 0);       // valid bytes of the unit grid that starts at A - padb
+                    unsigned char* G0 = A - padb;
+#pragma unroll
+                    for (int p2 = 0; p2 < PASSES; ++p2) {
+                        const int u = p2 * TILE + cl, b0 = 16 * u;
+                        if (b0 >= lo && b0 + 16 <= hi) RD_TILE_STORE(reinterpret_cast<V4*>(G0 + b0), gv[q * PASSES + p2]);
+                        else if (b0 + 16 > lo && b0 < hi) {       // a unit at an end of the run: the elements inside [lo, hi)
+                            const T* pv = reinterpret_cast<const T*>(&gv[q * PASSES + p2]);
+                            T* pd = reinterpret_cast<T*>(G0 + b0);
+                            for (int e = 0; e < (int)(16 / sizeof(T)); ++e) { const int be = b0 + e * (int)sizeof(T); if (be >= lo && be + (int)sizeof(T) <= hi) pd[e] = pv[e]; }
+                        }
+                    }
+                }
+                cur = nxt;
+            }
+        } else
         for (int it = 0; tile < tend; tile += tstep, ++it) {
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);

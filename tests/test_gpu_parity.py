@@ -1489,14 +1489,15 @@ def test_rollout_then_jacobians_in_one_call(case):
 
 @pytest.mark.parametrize("case", ["satellite_f64_rk4_512x41", "satellite_f64_rk4_130x14_ragged", "quadrotor_f64_rk3_192x6", "satellite_f32_rk4_132x30",
                                   "satellite_f64_rk4_64x1", "satellite_f64_rk4_66x2", "satellite_body_f64_euler_128x9", "satellite_f64_rk4_129x7_unaligned",
-                                  "satellite_f32_rk4_130x5_unaligned"])
+                                  "satellite_f32_rk4_130x5_unaligned", "quadrotor_f32_rk4_77x9_unaligned", "satellite_f64_rk3_1040x11"])
 def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
-    """rdhip_rollout_jacobian on time-major stacks of a rigid body is ONE launch (csrc/fused.hpp): rollout workgroups publish every finished chunk
-    of 4 steps in a progress word, Jacobian workgroups on the other compute units consume the chunks behind them.  It must reproduce the oracle's
-    sequential rollout and Jacobians, agree with the two-call path (states bit for bit: rdhip_rollout runs the SAME kernel with rollout workgroups
-    only; Jacobians to the last bit or two: the same column code in a separately compiled kernel), survive being called again
-    (the words of an earlier call must not satisfy a later one) and being replayed from a captured graph; stacks whose tiles do not start on
-    16-byte boundaries (odd M in fp64, M % 4 != 0 in fp32) take the two launches."""
+    """rdhip_rollout_jacobian on stacks of a rigid body is ONE launch (csrc/fused.hpp): rollout workgroups publish every finished chunk of 4 steps
+    in a progress word, Jacobian workgroups on the other compute units consume the chunks behind them -- time-major stacks as 64-trajectory
+    slabs per knot, trajectory-major stacks (the reference's layout) as gathered tiles of 16 trajectories x 4 knots.  It must reproduce the
+    oracle's sequential rollout and Jacobians, agree with the two-call path (states bit for bit: rdhip_rollout runs the SAME kernel with rollout
+    workgroups only; Jacobians to the last bit or two: the same column code in a separately compiled kernel), survive being called again
+    (the words of an earlier call must not satisfy a later one) and being replayed from a captured graph; time-major stacks whose tiles do not
+    start on 16-byte boundaries (odd M in fp64, M % 4 != 0 in fp32) take the two launches, trajectory-major stacks take any shape."""
     parts = case.split("_")
     body = parts[1] == "body"
     if body:
@@ -1513,8 +1514,9 @@ def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
     cast = (lambda a: a.astype(np.float32)) if f32 else (lambda a: a)
     dm = RD.DiscretizedDynamics(model, rule)
     sig, AD = RD.StaticReturn(), RD.ForwardAD()
-    expect_fused = "unaligned" not in case
-    for trial in range(3):                                  # three calls on the same context: every call has its own epoch
+    for trial in range(4):                                  # calls on the same context: every call has its own epoch; both layouts
+        tm = trial % 2 == 0
+        expect_fused = not (tm and "unaligned" in case)
         data = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
         t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy()
         dt = np.full((M, K), 0.02); dt[:, -1] = 0.0
@@ -1522,15 +1524,17 @@ def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
         with_x0 = trial != 1
         ref = om.rollout(orule, data, t, dt, X0=x0 if with_x0 else None)
         Jref = om.jacobian(orule, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 13 + mctl)
-        mk = lambda: {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(1, 0, 2)))).cuda(),       # noqa: E731
-                      "t": torch.as_tensor(np.ascontiguousarray(t.T)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T)).cuda()}
+        order = (1, 0, 2) if tm else (0, 1, 2)
+        mk = lambda: {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(order)))).cuda(),       # noqa: E731
+                      "t": torch.as_tensor(np.ascontiguousarray(t.T if tm else t)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T if tm else dt)).cuda()}
         X0 = torch.as_tensor(cast(x0)).cuda() if with_x0 else None
         st1 = mk()
         J1 = RD.alloc_jacobians(dm, K * M, st1["data"]).fill_(7.0)
-        launches = RD.rollout_jacobian_(sig, AD, dm, J1, st1, X0, time_major=True)
-        assert launches == (1 if expect_fused else 2), launches
-        got = host(st1["data"]).astype(np.float64).transpose(1, 0, 2)
-        Jg = host(J1).astype(np.float64).reshape(K, M, 13, 13 + mctl).transpose(1, 0, 2, 3)
+        launches = RD.rollout_jacobian_(sig, AD, dm, J1, st1, X0, time_major=tm)
+        assert launches == (1 if expect_fused else 2), (launches, tm)
+        got = host(st1["data"]).astype(np.float64).transpose(order)
+        Jg = host(J1).astype(np.float64).reshape((K, M, 13, 13 + mctl) if tm else (M, K, 13, 13 + mctl))
+        Jg = Jg.transpose(1, 0, 2, 3) if tm else Jg
         if f32:
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
             np.testing.assert_allclose(Jg, Jref, rtol=2e-3, atol=2e-3)
@@ -1540,37 +1544,41 @@ def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
         # the two-call path: rdhip_rollout (trajectory-major stack) on a fresh copy of the inputs, then rdhip_jacobian on the simulated knots
         st2 = {"data": torch.as_tensor(cast(data)).cuda(), "t": torch.as_tensor(t).cuda(), "dt": torch.as_tensor(dt).cuda()}
         RD.rollout_(sig, dm, st2, X0)
-        assert torch.equal(st1["data"], st2["data"].transpose(0, 1))
+        assert torch.equal(st1["data"], st2["data"].transpose(0, 1) if tm else st2["data"])
         J2 = RD.alloc_jacobians(dm, K * M, st1["data"])
         flat = RD.PackedTrajectory(13, mctl, st1["data"].reshape(K * M, 13 + mctl), st1["t"].reshape(-1), st1["dt"].reshape(-1))
         RD.jacobian_(sig, AD, dm, J2, None, flat)
         # the Jacobian workgroups run the flagship's column code compiled into the fused kernel: a separate instantiation, whose FMA contraction
         # may differ in the last bit (like the column-split kernel of small batches)
         np.testing.assert_allclose(host(J1), host(J2), rtol=0, atol=1e-5 if f32 else 1e-13)
-    if not expect_fused or K < 3:
+    if "unaligned" in case or K < 3:
         return
     # replayed from a captured graph (the recorded epoch is reused: the capture carries a node that clears the progress words)
     from rdhip import _lib as L
-    s1 = torch.cuda.Stream()
-    with torch.cuda.stream(s1):
-        st = mk()
-        J = RD.alloc_jacobians(dm, K * M, st["data"])
-        RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=True)          # once outside the capture (kernel attributes)
-        torch.cuda.synchronize()
-        ctx = L.context_for(0, s1.cuda_stream)
-        ctx.begin_capture()
-        RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=True)
-        g = ctx.end_capture()
-        for rep in range(2):
-            fresh = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
-            st["data"].copy_(torch.as_tensor(cast(np.ascontiguousarray(fresh.transpose(1, 0, 2)))))
-            J.zero_()
-            ctx.launch(g)
+    for tm in (True, False):
+        order = (1, 0, 2) if tm else (0, 1, 2)
+        s1 = torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            st = {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(order)))).cuda(),
+                  "t": torch.as_tensor(np.ascontiguousarray(t.T if tm else t)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T if tm else dt)).cuda()}
+            J = RD.alloc_jacobians(dm, K * M, st["data"])
+            RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=tm)          # once outside the capture (kernel attributes)
             torch.cuda.synchronize()
-            ref = om.rollout(orule, fresh, t, dt, X0=x0 if with_x0 else None)
-            Jr = om.jacobian(orule, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 13 + mctl)
-            np.testing.assert_allclose(host(st["data"]).astype(np.float64).transpose(1, 0, 2), ref, rtol=2e-4 if f32 else 0, atol=2e-4 if f32 else TOL)
-            np.testing.assert_allclose(host(J).astype(np.float64).reshape(K, M, 13, 13 + mctl).transpose(1, 0, 2, 3), Jr, rtol=2e-3 if f32 else 0, atol=2e-3 if f32 else TOL)
+            ctx = L.context_for(0, s1.cuda_stream)
+            ctx.begin_capture()
+            RD.rollout_jacobian_(sig, AD, dm, J, st, X0, time_major=tm)
+            g = ctx.end_capture()
+            for rep in range(2):
+                fresh = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
+                st["data"].copy_(torch.as_tensor(cast(np.ascontiguousarray(fresh.transpose(order)))))
+                J.zero_()
+                ctx.launch(g)
+                torch.cuda.synchronize()
+                ref = om.rollout(orule, fresh, t, dt, X0=x0 if with_x0 else None)
+                Jr = om.jacobian(orule, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 13 + mctl)
+                np.testing.assert_allclose(host(st["data"]).astype(np.float64).transpose(order), ref, rtol=2e-4 if f32 else 0, atol=2e-4 if f32 else TOL)
+                Jg = host(J).astype(np.float64).reshape((K, M, 13, 13 + mctl) if tm else (M, K, 13, 13 + mctl))
+                np.testing.assert_allclose(Jg.transpose(1, 0, 2, 3) if tm else Jg, Jr, rtol=2e-3 if f32 else 0, atol=2e-3 if f32 else TOL)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])

@@ -77,6 +77,29 @@ if kern and os.path.exists(trace):
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if int(r["Grid_Size_X"]) == gmax]
     summary["dominant_kernel"]["full_grid"] = {"grid_threads": gmax, "calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d),
                                                "note": "launches with the full persistent grid = the timed N = 65 536 batches; kernel_stats.csv averages over every launch of the name"}
+# launch overlap: in the trace of the driver's command consecutive full-grid launches of the dominant kernel run on two streams and overlap in time.
+# What the bench line's roofline.kernel_ms measures there is the time per launch of the JOB: the interval between consecutive launch starts.
+if kern and os.path.exists(trace):
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == kern and int(r["Grid_Size_X"]) == gmax))
+    ov_iv, ov_dur, sg_iv, sg_dur = [], [], [], []
+    for (s0, e0), (s1, e1) in zip(rows, rows[1:]):
+        if s1 - s0 > 200000:                       # a pause between phases of the command
+            continue
+        (ov_iv if s1 < e0 else sg_iv).append(s1 - s0)
+        (ov_dur if s1 < e0 else sg_dur).append(e1 - s1)
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    summary["dominant_kernel"]["overlap_trace"] = {
+        "launches_overlapping_their_predecessor": len(ov_iv), "median_start_to_start_ns": med(ov_iv), "mean_start_to_start_ns": (sum(ov_iv) / len(ov_iv)) if ov_iv else None,
+        "median_duration_ns": med(ov_dur),
+        "launches_not_overlapping": len(sg_iv), "median_start_to_start_ns_not_overlapping": med(sg_iv), "median_duration_ns_not_overlapping": med(sg_dur),
+        "note": "overlap mode (bench default): the job's time per launch is the start-to-start interval; a launch's own duration is longer because two launches share the chip"}
+single = os.path.join(src, "trace_single", f"{tag}_kernel_stats.csv")
+if os.path.exists(single):
+    shutil.copy(single, os.path.join(out, "kernel_stats_single_stream.csv"))
+    for r in csv.DictReader(open(single)):
+        if kern and r["Name"] == kern:
+            summary["dominant_kernel"]["single_stream"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                                          "note": "bench.py --no-overlap: one stream, the per-kernel average duration IS the time per launch (agrees with the bench line's single_stream.kernel_ms)"}
 for f in ("bench.json", "pytest_gpu.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(out, f))

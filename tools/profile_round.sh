@@ -1,7 +1,10 @@
-tag=r02p
+tag=${1:-r03p}
 bash tools/gpu_profile.sh $tag > gpurun_out/$tag.log 2>&1
 out=gpurun_out/$tag
 python tools/bench_configs.py --sweep > $out/configs.jsonl 2> $out/configs.err
+python tools/bench_configs.py --only sweep --overlap --reps 100 > $out/sweep_overlap.jsonl 2>> $out/configs.err
+python tools/bench_configs.py --only c5 > $out/c5.jsonl 2>> $out/configs.err
+python tools/bench_configs.py --only implicit --overlap > $out/implicit_overlap.jsonl 2>> $out/configs.err
 python tools/host_overhead.py > $out/host_overhead.txt 2>&1
 python tools/two_stream_bench.py 65536 1000 > $out/multi_stream.jsonl 2>/dev/null
 tools/abi_bench robotdynamics.jl_amd/lib/librdhip.so > $out/abi_bench.txt 2>&1
