@@ -277,6 +277,15 @@ int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype,
 #define RDHIP_TRAJECTORY_MAJOR 0   /* knot k of trajectory j at index j*K + k: M consecutive trajectories, what rdhip_rollout takes */
 #define RDHIP_TIME_MAJOR 1         /* knot k of trajectory j at index k*M + j: knot k of all trajectories contiguous */
 
+/* rdhip_rollout for either layout of the stack (rdhip_rollout = RDHIP_TRAJECTORY_MAJOR, the reference's "vector of trajectories").  Big batches
+ * -- from two 64-trajectory groups per compute unit on, 32 768 trajectories on an MI355X -- are streamed through LDS in chunks of knot points as
+ * whole 16-byte units (csrc/rollout_stream.hpp; every run of the stack must start on a 16-byte boundary: Z 16-byte aligned and K (n+m) sizeof(T)
+ * [trajectory-major] or M (n+m) sizeof(T) [time-major] a multiple of 16; other shapes take the one-lane-per-trajectory kernel).  That path
+ * rewrites the CONTROLS of Z with the values it read (whole-line stores): Z must not be written concurrently by other work, which an in-place
+ * rollout! forbids anyway.  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only (RDHIP_ERR_UNSUPPORTED otherwise).  src/trajectories.jl:436-441. */
+int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M, int layout,
+                         void* Z, const double* t, const double* dt, const void* X0, int memspace);
+
 /* rollout!(sig, dmodel, Z, x0) followed by jacobian!(sig, diff, dmodel, J[k], y, Z[k]) at every knot point of the simulated trajectories
  * (the forward pass + linearisation of a shooting method; rollout!: src/trajectories.jl:436-441, jacobian!: src/functionbase.jl:242-257).
  * Same result as rdhip_rollout + rdhip_jacobian on the K*M knot points (the states bit for bit: rdhip_rollout runs the same kernel; the Jacobians to the

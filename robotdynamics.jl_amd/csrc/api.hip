@@ -888,17 +888,19 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype,
     return s.finish(kernel_status(c, launch_nabla_errstate(M->lie, dtype, c->stream, N, a, ldx, b, ldxb, clear, o), what));
 }
 
-int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, void* Z, const double* t, const double* dt,
-                  const void* X0, int memspace) {
+int rdhip_rollout_layout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, int layout, void* Z, const double* t, const double* dt,
+                         const void* X0, int memspace) {
     const char* what = "rdhip_rollout";
     int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
     if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
     if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    if (layout != RDHIP_TRAJECTORY_MAJOR && layout != RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad layout %d", what, layout);
     if (K * Mt > 0 && (!Z || !t || !dt)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
-    LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K;
+    LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K; a.time_major = layout == RDHIP_TIME_MAJOR;
     const bool implicit = rule == RDHIP_IMPLICIT_MIDPOINT;
+    if (implicit && a.time_major) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: implicit rules take trajectory-major stacks", what);
     if (memspace == RDHIP_DEVICE) { a.Z = Z; a.t = t; a.dt = dt; a.X0 = X0; return kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what); }
     Stage s(c);
     a.Z = s.out(Z, (size_t)K * Mt * (d.n + d.m) * ts, /*preload=*/true);
@@ -906,6 +908,10 @@ int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long 
     a.X0 = s.in(X0, (size_t)Mt * d.n * ts);
     if (s.rc) return s.rc;
     return s.finish(kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
+}
+int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, void* Z, const double* t, const double* dt,
+                  const void* X0, int memspace) {
+    return rdhip_rollout_layout(c, M, rule, dtype, K, Mt, RDHIP_TRAJECTORY_MAJOR, Z, t, dt, X0, memspace);
 }
 
 // rollout!, then the Jacobians along the rollout: what a shooting / iLQR forward pass + linearisation needs, in one call.

@@ -9,6 +9,7 @@
 #include "cascade.hpp"
 #include "implicit.hpp"
 #include "fused.hpp"
+#include "rollout_stream.hpp"
 
 namespace rd {
 
@@ -25,6 +26,8 @@ template <class Mdl> struct IftPlanOf<Mdl, typename std::enable_if<UnrollPolicy<
 // cost-balanced column plan of the cascade FiniteDifference kernel (defined next to the model's other plans)
 template <class Mdl> struct FdPlanOf { static constexpr bool value = false; using Plan = void; };
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
     if (a.N == 0) return RDHIP_OK;
@@ -38,10 +41,42 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     const unsigned grid = (unsigned)((a.N + 63) / 64);
     const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
     using Cas = Cascade<decltype(Fn::m)>;
+    static const char* roll_env = getenv("RDHIP_ROLLOUT");                 // tuning switch: "plain" / "cascade" / "stream" force a kernel where it applies
+    if constexpr (Fn::RULE_ID != RULE_IMPLICIT_MIDPOINT) {
+        // the throughput regime (rollout_stream.hpp): at least two 64-trajectory groups per CU.  Chunks move as whole 16-byte units, so every run of
+        // the stack must start on a 16-byte boundary; other shapes take the one-lane-per-trajectory kernel there (the cascade kernel buys latency, not
+        // traffic: 0.30-0.36 of the roofline at 65 536 x 32 / 262 144 x 16 where the plain kernel reaches 0.37-0.44 and the streaming one 0.41-0.49)
+        const bool forced = roll_env && roll_env[0] == 's';
+        if ((forced || (!roll_env && (long long)grid >= 2LL * dev_info().cus)) && a.K >= 1) {
+            typedef unsigned int V4 __attribute__((ext_vector_type(4)));
+            constexpr int ZB = (Fn::NX + Fn::NU) * (int)sizeof(T);
+            const bool al = aligned16(a.Z) && ((a.time_major ? a.N : a.K) * ZB) % 16 == 0;
+            if (al && a.time_major) {
+                using L = StreamCfg<Fn, T, true>;
+                if constexpr (L::UNITS) {
+                    auto ks = rollout_stream_kernel<Fn, T, true, V4>;
+                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+                    hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                    return hip_status(hipGetLastError());
+                }
+            } else if (al) {
+                using L = StreamCfg<Fn, T, false>;
+                if constexpr (L::UNITS) {
+                    auto ks = rollout_stream_kernel<Fn, T, false, V4>;
+                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+                    hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                    return hip_status(hipGetLastError());
+                }
+            }
+            if (!forced) {
+                hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                return hip_status(hipGetLastError());
+            }
+        }
+    }
     if constexpr (Cas::NB > 1) {
         // one wavefront per cascade block + an IO wavefront (cascade.hpp): the latency chain of a step shrinks to the longest block's
-        static const char* mode = getenv("RDHIP_ROLLOUT");             // tuning switch: "plain" forces the one-lane-per-trajectory kernel
-        const bool plain = mode && mode[0] == 'p';
+        const bool plain = roll_env && roll_env[0] == 'p';
         if (!plain && a.K < (1LL << 26) && a.N < (1LL << 26)) {            // (the IO wave's per-lane offsets are 32-bit)
             constexpr int R = 4;
             // models whose rollout + Jacobians can run as one launch (fused.hpp) roll out through THAT kernel (rollout workgroups only): the two-call
@@ -107,7 +142,6 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     return hip_status(hipGetLastError());
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // host MultiDesc -> the kernel argument (same bytes: MultiPod is the image of MultiBatch<T>)
 template <class T> MultiBatch<T> to_multi_batch(const MultiDesc& md) {

@@ -847,8 +847,9 @@ end
 
 # rollout!(sig, dmodel, Z, x0) (src/trajectories.jl:436-441): one packed trajectory, or M stacked trajectories of K knot points
 # (Zs holds them back to back; `K` knot points each), sequential in k, parallel over trajectories.
+# time_major = true: knot k of all M trajectories contiguous (index k M + j) instead of trajectory after trajectory (j K + k); explicit rules only.
 function RobotDynamics.rollout!(::RD.FunctionSignature, fun::RD.DiscretizedDynamics, Zs::AbstractPackedTrajectory{n,m,T}, x0::Union{Nothing,Dense{T}}=nothing;
-                                K::Integer=length(Zs), ctx::Union{Nothing,Context}=nothing) where {n,m,T}
+                                K::Integer=length(Zs), time_major::Bool=false, ctx::Union{Nothing,Context}=nothing) where {n,m,T}
     _checkmodel(fun, Zs)
     N = length(Zs); M = K == 0 ? 0 : div(N, K)
     M * K == N || throw(DimensionMismatch("the stack must hold whole trajectories of K knot points"))
@@ -856,7 +857,10 @@ function RobotDynamics.rollout!(::RD.FunctionSignature, fun::RD.DiscretizedDynam
     sp, found = _where(Zs.data, Zs.t, Zs.dt, x0)
     c = _ctx(ctx, found)
     GC.@preserve Zs x0 begin
-        rc = ccall((:rdhip_rollout, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Clonglong, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+        rc = time_major ?
+             ccall((:rdhip_rollout_layout, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Clonglong, Clonglong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   c.ptr, handle(fun), rulecode(fun), dtypecode(T), K, M, Cint(1), _p(Zs.data), _p(Zs.t), _p(Zs.dt), _p(x0), sp) :
+             ccall((:rdhip_rollout, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Clonglong, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
                    c.ptr, handle(fun), rulecode(fun), dtypecode(T), K, M, _p(Zs.data), _p(Zs.t), _p(Zs.dt), _p(x0), sp)
     end
     check(c, rc)

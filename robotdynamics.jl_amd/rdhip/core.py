@@ -1732,9 +1732,10 @@ def _check_stack(data3, t2, dt2, nz):
         _dense(a, lead, name)
 
 
-def rollout_(sig, model, Z, x0=None):
-    """rollout!(sig, model, Z, x0): src/trajectories.jl:436-441.  Z is ONE PackedTrajectory (K knots) or a list /
-    (M, K, n+m) stack of trajectories that share the kernel launch (sequential in k, parallel over trajectories)."""
+def rollout_(sig, model, Z, x0=None, time_major=False):
+    """rollout!(sig, model, Z, x0): src/trajectories.jl:436-441.  Z is ONE PackedTrajectory (K knots) or a
+    (M, K, n+m) stack of trajectories that share the kernel launch (sequential in k, parallel over trajectories); with
+    time_major=True the stack is (K, M, n+m) / (K, M): knot k of all trajectories contiguous (explicit rules)."""
     cm, rule = _model_rule(model)
     if rule == L.CONTINUOUS:
         raise TypeError("rollout! needs a DiscreteDynamics model")
@@ -1745,7 +1746,7 @@ def rollout_(sig, model, Z, x0=None):
     else:                       # {"data": (M, K, n+m), "t": (M, K), "dt": (M, K)}
         data3, t2, dt2 = Z["data"], Z["t"], Z["dt"]
         _check_stack(data3, t2, dt2, state_dim(model) + control_dim(model))
-        M, K = data3.shape[0], data3.shape[1]
+        M, K = (data3.shape[1], data3.shape[0]) if time_major else (data3.shape[0], data3.shape[1])
     x0a = x0
     if x0a is not None and not _is_torch(x0a):
         x0a = np.ascontiguousarray(np.asarray(x0a, dtype=data3.dtype if isinstance(data3, np.ndarray) else np.float64).reshape(M, -1))
@@ -1755,7 +1756,7 @@ def rollout_(sig, model, Z, x0=None):
     if a0.ptr is not None and a0.dtype != az.dtype:
         raise ValueError("x0 dtype does not match the trajectory")
     ctx, space = _resolve_ctx([az, at, adt, a0])
-    L.check(L.lib().rdhip_rollout(ctx.handle, cm._handle, rule, az.dtype, K, M, az.ptr, at.ptr, adt.ptr, a0.ptr, space), ctx.handle)
+    L.check(L.lib().rdhip_rollout_layout(ctx.handle, cm._handle, rule, az.dtype, K, M, 1 if time_major and M > 1 else 0, az.ptr, at.ptr, adt.ptr, a0.ptr, space), ctx.handle)
     return None
 
 

@@ -1435,6 +1435,53 @@ def test_cascade_rollout_shapes_layouts_and_rules(variant, shape):
                 np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("case", ["satellite_f64_rk4_32806x10", "satellite_f32_rk4_32772x12", "cartpole_f64_rk4_32770x18", "quadrotor_f64_rk3_32768x9",
+                                  "satellite_f64_euler_33000x1"])
+def test_streaming_rollout_of_big_batches(case):
+    """From two 64-trajectory groups per CU on (32 768 trajectories on an MI355X) rollout_ streams the stack through LDS in chunks of 4 / 8 knot points
+    (csrc/rollout_stream.hpp: whole 16-byte units in, the states advanced in place, whole lines out -- the controls are written back unchanged).
+    Against the oracle's sequential rollout of EVERY trajectory: both layouts, a ragged last group, step counts that are not multiples of the
+    chunk, a single knot, a dt = 0 knot inside some trajectories, with and without a separate x0, fp32; shapes whose runs do not start on
+    16-byte boundaries (odd K in the reference's layout) take the one-lane-per-trajectory kernel and must give the same answer.  The controls,
+    the times and the knot points behind a trajectory's end must come back untouched."""
+    parts = case.split("_")
+    M, K = (int(v) for v in parts[3].split("x"))
+    rng = np.random.default_rng(4242 + K)
+    f32 = parts[1] == "f32"
+    rule, orule = {"rk4": (RD.RK4, O.RK4), "rk3": (RD.RK3, O.RK3), "euler": (RD.Euler, O.EULER)}[parts[2]]
+    if parts[0] == "cartpole":
+        model, om, n, mctl = RD.Cartpole(), O.cartpole(), 4, 1
+        data = rng.random((M, K, 5))
+    else:
+        mctl = 4 if parts[0] == "quadrotor" else 6
+        model, om, n = (RD.Quadrotor(), O.quadrotor(), 13) if mctl == 4 else (RD.Satellite(), O.satellite(), 13)
+        data = H.rand_rigid(rng, M * K, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0).reshape(M, K, 13 + mctl)
+    dm = RD.DiscretizedDynamics(model, rule)
+    t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy()
+    dt = np.full((M, K), 0.02)
+    if K > 4:
+        dt[::5, K // 2] = 0.0
+    x0 = data[:, 0, :n].copy(); x0[:, n // 2:] *= 0.5
+    cast = (lambda a: a.astype(np.float32)) if f32 else (lambda a: a)
+    for tm in (False, True):
+        for with_x0 in (False, True):
+            ref = om.rollout(orule, data, t, dt, X0=x0 if with_x0 else None)
+            order = (1, 0, 2) if tm else (0, 1, 2)
+            stack = {"data": torch.as_tensor(cast(np.ascontiguousarray(data.transpose(order)))).cuda(),
+                     "t": torch.as_tensor(np.ascontiguousarray(t.T if tm else t)).cuda(), "dt": torch.as_tensor(np.ascontiguousarray(dt.T if tm else dt)).cuda()}
+            t_before, dt_before = stack["t"].clone(), stack["dt"].clone()
+            RD.rollout_(RD.StaticReturn(), dm, stack, torch.as_tensor(cast(x0)).cuda() if with_x0 else None, time_major=tm)
+            got = host(stack["data"]).astype(np.float64)
+            got = got.transpose(order) if tm else got
+            if f32:
+                np.testing.assert_allclose(got[:, :, :n], ref[:, :, :n], rtol=2e-4, atol=2e-4)
+                np.testing.assert_array_equal(got[:, :, n:], cast(data[:, :, n:]).astype(np.float64))
+            else:
+                np.testing.assert_allclose(got[:, :, :n], ref[:, :, :n], rtol=0, atol=TOL)
+                np.testing.assert_array_equal(got[:, :, n:], data[:, :, n:])           # the controls: bit for bit
+            assert torch.equal(stack["t"], t_before) and torch.equal(stack["dt"], dt_before)
+
+
 @pytest.mark.parametrize("case", ["satellite_tm_large", "satellite_traj_major", "cartpole_tm_large", "quadrotor_tm_host", "custom_tm_large",
                                   "satellite_implicit_traj_major"])
 def test_rollout_then_jacobians_in_one_call(case):

@@ -204,16 +204,18 @@ def statediff_case(name, model, Zn, reps, rng):
     emit(name.replace("state_diff", "nabla_errstate_jacobian clear=True"), N, "f64", us, N * (2 * n * 8 + e * e * 8))
 
 
-def rollout_case(name, model, M, K, rule, dtype, reps, rng):
+def rollout_case(name, model, M, K, rule, dtype, reps, rng, tm=False):
     n, m = RD.state_dim(model), RD.control_dim(model)
     T = 8 if dtype == np.float64 else 4
     Zn = (rigid_inputs(M * K, m, rng) if n == 13 else rng.random((M * K, n + m))).astype(dtype)
-    data = torch.from_numpy(Zn.reshape(M, K, n + m)).to(DEV)
-    t = torch.from_numpy(np.tile(np.arange(K) * 0.01, (M, 1))).to(DEV)
-    dt = torch.full((M, K), 0.01, dtype=torch.float64, device=DEV)
+    shape = (K, M) if tm else (M, K)
+    data = torch.from_numpy(Zn.reshape(*shape, n + m)).to(DEV)
+    tk = np.arange(K) * 0.01
+    t = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tk[:, None] if tm else tk[None, :], shape))).to(DEV)
+    dt = torch.full(shape, 0.01, dtype=torch.float64, device=DEV)
     fun = RD.DiscretizedDynamics(model, rule)
-    us = timed(lambda i: RD.rollout_(RD.StaticReturn(), fun, {"data": data, "t": t, "dt": dt}), reps, warm=2)
-    emit(name, M * K, "f64" if T == 8 else "f32", us, M * K * ((n + m) * T + 16 + n * T), {"trajectories": M, "knots": K})
+    us = timed(lambda i: RD.rollout_(RD.StaticReturn(), fun, {"data": data, "t": t, "dt": dt}, time_major=tm), reps, warm=2)
+    emit(name + (" (time-major)" if tm else ""), M * K, "f64" if T == 8 else "f32", us, M * K * ((n + m) * T + 16 + n * T), {"trajectories": M, "knots": K})
 
 
 def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
@@ -372,6 +374,10 @@ def main():
         rollout_case("satellite RK4 rollout fp64 16384 traj x 64 knots", sat, 16384, 64, RD.RK4, f64, 10, rng)
         rollout_case("satellite RK4 rollout fp64 65536 traj x 32 knots", sat, 65536, 32, RD.RK4, f64, 10, rng)
         rollout_case("satellite RK4 rollout fp64 262144 traj x 16 knots", sat, 262144, 16, RD.RK4, f64, 5, rng)
+        rollout_case("satellite RK4 rollout fp64 65536 traj x 32 knots", sat, 65536, 32, RD.RK4, f64, 10, rng, tm=True)
+        rollout_case("satellite RK4 rollout fp64 262144 traj x 16 knots", sat, 262144, 16, RD.RK4, f64, 5, rng, tm=True)
+        rollout_case("cartpole RK4 rollout fp64 262144 traj x 32 knots", cart, 262144, 32, RD.RK4, f64, 5, rng)
+        rollout_case("cartpole RK4 rollout fp64 262144 traj x 32 knots", cart, 262144, 32, RD.RK4, f64, 5, rng, tm=True)
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
         return
