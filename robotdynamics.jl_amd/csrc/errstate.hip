@@ -330,10 +330,12 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
 int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G) {
     return dtype == RDHIP_F64 ? errstate_T<double>(d, s, N, X, ldx, clear, G) : errstate_T<float>(d, s, N, X, ldx, clear, G);
 }
-// Tiled state_diff: 128 knot points per workgroup; the x and x0 tiles (contiguous spans of the inputs, any leading dimension <= 32) are
-// staged into LDS with lane-contiguous loads issued in batches of four, ONE lane then computes all e error coordinates of its knot point
-// (each relative rotation once, not once per component), and the e x 128 output tile leaves as a lane-contiguous sweep.
-template <class T>
+// Tiled state_diff: 128 knot points per workgroup; the x and x0 tiles (contiguous spans of the inputs, any leading dimension <= MAXLD) are
+// staged into LDS with lane-contiguous loads, ALL of a thread's loads of both tiles requested before the first is waited for (the loop used to
+// run in batches of four: eight dependent memory round trips per workgroup, 20 us for 262 144 quadrotor states = 0.49 of the roofline), ONE
+// lane then computes all e error coordinates of its knot point (each relative rotation once, not once per component), and the e x 128 output
+// tile leaves as a lane-contiguous sweep.
+template <class T, int MAXLD>
 __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, T* __restrict__ dX) {
     constexpr int NB = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sd[];
@@ -344,19 +346,20 @@ __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long lo
     const long long k0 = (long long)blockIdx.x * NB;
     const int nk = (int)((N - k0) < NB ? (N - k0) : NB);
     const int tid = threadIdx.x;
-    for (int pass = 0; pass < 2; ++pass) {
-        const T* src = pass == 0 ? X + k0 * ldx : X0 + k0 * ldx0;
-        T* dst = pass == 0 ? xa : xb;
+    {
         // the header only promises ld >= n: the last state of the array may be followed by fewer than ld - n valid elements, so the
         // staged span ends with the last knot point's n-th entry, not with its full ld-wide column
-        const int total = (nk - 1) * (pass == 0 ? ldx : ldx0) + d.n;
-        for (int base = 0; base < total; base += 4 * NB) {
-            T r[4];
+        const T* sa = X + k0 * ldx; const T* sb = X0 + k0 * ldx0;
+        const int ta = (nk - 1) * ldx + d.n, tb = (nk - 1) * ldx0 + d.n;
+        T ra[MAXLD], rb[MAXLD];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int e = base + q * NB + tid; r[q] = src[e < total ? e : 0]; }
+        for (int q = 0; q < MAXLD; ++q) { const int e = q * NB + tid; ra[q] = sa[e < ta ? e : 0]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int e = base + q * NB + tid; if (e < total) dst[e] = r[q]; }
-        }
+        for (int q = 0; q < MAXLD; ++q) { const int e = q * NB + tid; rb[q] = sb[e < tb ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < MAXLD; ++q) { const int e = q * NB + tid; if (e < ta) xa[e] = ra[q]; }
+#pragma unroll
+        for (int q = 0; q < MAXLD; ++q) { const int e = q * NB + tid; if (e < tb) xb[e] = rb[q]; }
     }
     __syncthreads();
     if (tid < nk) {
@@ -404,8 +407,12 @@ __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long lo
 template <class T> static int sdiff_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX) {
     if (N == 0) return RDHIP_OK;
     const size_t lds = (size_t)128 * (ldx + ldx0 + (d.e | 1)) * sizeof(T);
+    if (ldx <= 16 && ldx0 <= 16 && lds <= 64 * 1024) {
+        hipLaunchKernelGGL((state_diff_tile_kernel<T, 16>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        return st(hipGetLastError());
+    }
     if (ldx <= 32 && ldx0 <= 32 && lds <= 64 * 1024) {
-        hipLaunchKernelGGL((state_diff_tile_kernel<T>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        hipLaunchKernelGGL((state_diff_tile_kernel<T, 32>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
         return st(hipGetLastError());
     }
     hipLaunchKernelGGL((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);

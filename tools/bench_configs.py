@@ -366,6 +366,10 @@ def main():
         jac_case("C3 satellite RK4 jacobian FiniteDifference", sat, Zs, RD.RK4, FD, f64, a.reps)
         jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship]", sat, Zs, RD.RK4, AD, f64, a.reps)
         return
+    if a.only == "lie":
+        statediff_case("quadrotor state_diff N=262144", quad, rigid_inputs(262144, 4, rng), a.reps, rng)
+        statediff_case("quadrotor state_diff N=1048576", quad, rigid_inputs(1 << 20, 4, rng), max(10, a.reps // 4), rng)
+        return
     if a.only == "rollout":
         rollout_case("satellite RK4 rollout fp64 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_case("C5 satellite RK4 rollout fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
