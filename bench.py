@@ -316,7 +316,9 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="sustained load (the same launches, untimed) before the W warm-up steps: clocks and TLBs settle over ~100 ms, "
                          "a short W alone measures the ramp (0.62 instead of 0.65-0.68 of the roofline)")
-    ap.add_argument("--streams", type=int, default=4, help="N=1 only: also report independent batches issued round-robin on this many streams (extra object, never `value`; 1 = skip)")
+    # (off by default since the launch-overlap mode of one context became the headline: HIP maps streams onto four hardware queues, and the extra's four
+    # streams + the library's internal ones then alias -- the two models of the C5 extra ended up on ONE queue and ran one after the other, 281 instead of 160 us)
+    ap.add_argument("--streams", type=int, default=1, help="N=1 only: also report independent batches issued round-robin on this many streams (extra object, never `value`; 1 = skip)")
     ap.add_argument("--knots", type=int, default=N_PER_GPU, help="knot points per GPU (default = BASELINE config)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for N>1 (gloo: control-path dry run, no gather)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (exercises the N>1 control path on a 1-GPU box)")
