@@ -273,6 +273,16 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
 int rdhip_rollout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M,
                   void* Z, const double* t, const double* dt, const void* X0, int memspace);
 
+/* wrenches(model, x, u, t) = [forces; moments] (src/rigidbody.jl:244-248; the first thing a RigidBody's dynamics evaluate, :217) for every knot
+ * point: W 6 x N; and its Jacobian with respect to z = [x; u], F 6 x (n+m) x N -- what the default wrench_jacobian!(F, model, z) of
+ * src/rigidbody.jl:315-320 (ForwardDiff.jacobian of `wrenches`) is written to return; test/rigidbody_test.jl:33-46 holds the closed form for the
+ * satellite wrench (dF/dq = grad-rotate(q, u[1:3]), dF/du = RotMatrix(q), dM/du = I).  The compiled-in RigidBody models (satellite, quadrotor;
+ * QuatRotation, MRP and RodriguesParam attitudes); `t` may be NULL (their wrenches do not depend on time).  rdhip_model_wrench_sparsity:
+ * wrench_sparsity(model) (src/rigidbody.jl:322-347), js[i + 2 j] for i = F, M and j = r, q, v, w, u (column-major 2 x 5 like the SMatrix). */
+int rdhip_wrenches(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N, const void* Z, const double* t, void* W, int memspace);
+int rdhip_wrench_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N, const void* Z, const double* t, void* F, int memspace);
+int rdhip_model_wrench_sparsity(const rdhip_model* model, int js[10]);
+
 /* layouts of a batch of M trajectories x K knot points (Z, t, dt and the Jacobians share the knot indexing) */
 #define RDHIP_TRAJECTORY_MAJOR 0   /* knot k of trajectory j at index j*K + k: M consecutive trajectories, what rdhip_rollout takes */
 #define RDHIP_TIME_MAJOR 1         /* knot k of trajectory j at index k*M + j: knot k of all trajectories contiguous */

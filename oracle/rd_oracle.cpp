@@ -496,6 +496,38 @@ static int user_jacobian(const OModel& M, const double* x, const double* u, doub
 }
 #undef JJ
 
+// wrenches(model, x, u, t) = [forces; moments] (src/rigidbody.jl:244-248) of the RigidBody models, and its ForwardDiff Jacobian with respect to
+// z = [x; u] -- what the default wrench_jacobian!(F, model, z) of src/rigidbody.jl:315-320 is written to return (in v0.4.8 it cannot run: the
+// knot-point method of `wrenches` it calls is commented out at :243); test/rigidbody_test.jl:33-46 holds the closed form for the satellite wrench.
+template <class S> static int wrench_any(const OModel& M, const S* x, const S* u, S t, S* W) {
+    if (M.kind != M_SATELLITE && M.kind != M_QUADROTOR && M.kind != M_TV_SATELLITE) return -1;
+    S F[3], T[3];
+    if (M.rot == ROT_QUAT) {
+        if (M.kind == M_SATELLITE) wrench_satellite(M, x, u, F, T);
+        else if (M.kind == M_TV_SATELLITE) wrench_tv_satellite(M, x, u, t, F, T);
+        else wrench_quadrotor(M, x, u, F, T);
+    } else {
+        // three-parameter attitudes act through their unit quaternion (dyn_rigidbody3): the quaternion wrench on [r, q(p), ...]
+        if (M.kind == M_TV_SATELLITE) return -1;
+        S xx[7]; for (int i = 0; i < 3; ++i) xx[i] = x[i];
+        rot3_quat(M.rot, x + 3, xx + 3);
+        if (M.kind == M_SATELLITE) wrench_satellite(M, xx, u, F, T); else wrench_quadrotor(M, xx, u, F, T);
+    }
+    for (int i = 0; i < 3; ++i) { W[i] = F[i]; W[3 + i] = T[i]; }
+    return 0;
+}
+template <int NP> static int wrench_jac_ad(const OModel& M, const double* z, double t, double* F, double* w) {
+    Dual<NP> zd[MAXZ], wd[6];
+    for (int i = 0; i < NP; ++i) { zd[i] = Dual<NP>(z[i]); zd[i].d[i] = 1.0; }
+    int rc = wrench_any(M, zd, zd + M.n, Dual<NP>(t), wd);
+    if (rc) return rc;
+    for (int i = 0; i < 6; ++i) { if (w) w[i] = wd[i].v; for (int j = 0; j < NP; ++j) F[i + j * 6] = wd[i].d[j]; }
+    return 0;
+}
+typedef int (*wrench_jac_fn)(const OModel&, const double*, double, double*, double*);
+template <int NP> struct WrenchTable { static void fill(wrench_jac_fn* tab) { tab[NP] = &wrench_jac_ad<NP>; WrenchTable<NP - 1>::fill(tab); } };
+template <> struct WrenchTable<1> { static void fill(wrench_jac_fn* tab) { tab[1] = &wrench_jac_ad<1>; } };
+
 // ------------------------------------------------------------------------------------------
 // Jacobians of `evaluate`
 // ------------------------------------------------------------------------------------------
@@ -690,6 +722,20 @@ int oracle_jacobian(const OModel* M, int rule, int diff, int sig, int N, const d
         else if (diff == DIFF_FINITE_DIFF) jac_finite_diff(*M, rule, sig, z, t[k], dt[k], Jk, yk);
         else { int rc = jac_chain_rule(*M, rule, z, t[k], dt[k], Jk, yk); if (rc) rc_all = rc; }
     }
+    return rc_all;
+}
+
+// wrenches(model, x, u, t) per knot point (W: 6 x N) and its Jacobian with respect to z (F: 6 x (n+m) x N), RigidBody models only
+int oracle_wrenches(const OModel* M, int N, const double* Z, const double* t, double* W) {
+    int nz = M->n + M->m; int rc_all = 0;
+    for (int k = 0; k < N; ++k) { const double* z = Z + (size_t)k * nz; int rc = wrench_any(*M, z, z + M->n, t[k], W + (size_t)k * 6); if (rc) rc_all = rc; }
+    return rc_all;
+}
+int oracle_wrench_jacobian(const OModel* M, int N, const double* Z, const double* t, double* F) {
+    static wrench_jac_fn tab[MAXZ + 1]; static bool init = false;
+    if (!init) { WrenchTable<MAXZ>::fill(tab); init = true; }
+    int nz = M->n + M->m; int rc_all = 0;
+    for (int k = 0; k < N; ++k) { int rc = tab[nz](*M, Z + (size_t)k * nz, t[k], F + (size_t)k * 6 * nz, nullptr); if (rc) rc_all = rc; }
     return rc_all;
 }
 

@@ -242,6 +242,24 @@ class Model:
             raise NotImplementedError(f"rc={rc}")
         return out.transpose(0, 2, 1)
 
+    def wrenches(self, Z, t):
+        """wrenches(model, x, u, t) = [forces; moments] per knot point (src/rigidbody.jl:244-248): (N, 6)."""
+        Z, t, _, N = self._prep(Z, t, 0.0)
+        out = np.empty((N, 6))
+        rc = lib().oracle_wrenches(self._buf, N, _dp(Z), _dp(t), _dp(out))
+        if rc:
+            raise NotImplementedError(f"rc={rc}")
+        return out
+
+    def wrench_jacobian(self, Z, t):
+        """d wrenches / d z by forward duals (what src/rigidbody.jl:315-320 is written to return): (N, 6, n+m)."""
+        Z, t, _, N = self._prep(Z, t, 0.0)
+        out = np.empty((N, self.n + self.m, 6))
+        rc = lib().oracle_wrench_jacobian(self._buf, N, _dp(Z), _dp(t), _dp(out))
+        if rc:
+            raise NotImplementedError(f"rc={rc}")
+        return out.transpose(0, 2, 1)
+
     def rollout(self, rule, Z, t, dt, X0=None, sig=STATIC_RETURN):
         """Z: (M, K, n+m) trajectories; returns a copy with states k>=1 overwritten by the simulation."""
         Z = np.array(Z, dtype=np.float64, order="C")

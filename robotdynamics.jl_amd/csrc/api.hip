@@ -570,6 +570,44 @@ int rdhip_discrete_dynamics(rdhip_ctx* c, const rdhip_model* M, int rule, int dt
     return eval_common(c, M, rule, dtype, N, Z, t, dt, Xn, memspace, "rdhip_discrete_dynamics");
 }
 
+// wrenches(model, x, u, t) and wrench_jacobian!(F, model, z) for every knot point (src/rigidbody.jl:244-248, :315-320)
+static int wrench_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, void* Out, int jac, int memspace, const char* what) {
+    int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
+    if (N > 0 && (!Z || !Out)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    const ModelDesc& d = M->d;
+    if (d.kind != RDHIP_MODEL_SATELLITE && d.kind != RDHIP_MODEL_QUADROTOR)
+        return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: defined for the compiled-in RigidBody models (a custom model's forces / moments are part of its dynamics source)", what);
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4, per = jac ? (size_t)6 * (d.n + d.m) : 6;
+    LaunchArgs a{}; a.stream = c->stream; a.N = N;
+    if (memspace == RDHIP_DEVICE) { a.Z = Z; (jac ? a.J : a.Y) = Out; return kernel_status(c, fam_wrench(d, dtype, a, jac), what); }
+    Stage s(c);
+    a.Z = s.in(Z, (size_t)N * (d.n + d.m) * ts);
+    (jac ? a.J : a.Y) = s.out(Out, (size_t)N * per * ts);
+    if (s.rc) return s.rc;
+    return s.finish(kernel_status(c, fam_wrench(d, dtype, a, jac), what));
+}
+int rdhip_wrenches(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, const double* t, void* W, int memspace) {
+    (void)t;                                                      // the compiled-in wrenches do not depend on time
+    return wrench_common(c, M, dtype, N, Z, W, 0, memspace, "rdhip_wrenches");
+}
+int rdhip_wrench_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* Z, const double* t, void* F, int memspace) {
+    (void)t;
+    return wrench_common(c, M, dtype, N, Z, F, 1, memspace, "rdhip_wrench_jacobian");
+}
+// wrench_sparsity(model) (src/rigidbody.jl:322-347): js[i + 2 j], i = 0 (F) / 1 (M), j = r, q, v, w, u -- 0 where the block is identically zero
+int rdhip_model_wrench_sparsity(const rdhip_model* M, int js[10]) {
+    if (!M || !js) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    const int k = M->d.kind;
+    if (k != RDHIP_MODEL_SATELLITE && k != RDHIP_MODEL_QUADROTOR && !(k == RDHIP_MODEL_CUSTOM && M->d.lie_nP == 2 && M->d.lie_P[0] == 3 && M->d.lie_P[1] == 6))
+        return fail(nullptr, RDHIP_ERR_UNSUPPORTED, "wrench_sparsity is defined for RigidBody models only");
+    for (int i = 0; i < 10; ++i) js[i] = 1;                       // the reference's default: every block may be non-zero
+    if (k != RDHIP_MODEL_CUSTOM) {
+        // satellite: F = q * u[1:3], M = u[4:6]; quadrotor: F = m g + q * [0, 0, sum kf u], M = M(u): forces see q and u, moments u only
+        js[0] = 0; js[1] = 0;  /* d/dr */   js[2] = 1; js[3] = 0;  /* d/dq */   js[4] = 0; js[5] = 0;  /* d/dv */   js[6] = 0; js[7] = 0;  /* d/dw */
+    }
+    return RDHIP_OK;
+}
+
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";

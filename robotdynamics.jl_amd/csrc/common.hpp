@@ -137,6 +137,8 @@ RD_DECLARE_FAMILY(fam_satellite)
 RD_DECLARE_FAMILY(fam_quadrotor)
 RD_DECLARE_FAMILY(fam_lie)
 RD_DECLARE_FAMILY(fam_rigid3)   // RigidBody{MRP}, RigidBody{RodriguesParam}
+// wrenches(model, x, u, t) (jac = 0: a.Y = W, 6 x N) and d wrenches / d z (jac = 1: a.J = F, 6 x (n+m) x N) of the RigidBody models (fam_wrench.hip)
+int fam_wrench(const ModelDesc& d, int dtype, const LaunchArgs& a, int jac);
 int fam_satellite_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
 int fam_quadrotor_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);
 int fam_lie_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);               // satellite pair, lie satellite

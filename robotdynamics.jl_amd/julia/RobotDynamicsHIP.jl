@@ -603,6 +603,13 @@ function native_gen_inds(model)
     check(nothing, ccall((:rdhip_model_gen_inds, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}), handle(model), first5, len5))
     return NamedTuple{(:r, :q, :v, :ω, :u)}(ntuple(i -> first5[i]:(first5[i]+len5[i]-1), 5))
 end
+"wrench_sparsity(model) (src/rigidbody.jl:322-347) of a native RigidBody model: the 2 x 5 Bool pattern [∂F/∂r ∂F/∂q ∂F/∂v ∂F/∂ω ∂F/∂u; ∂M/∂…]"
+function native_wrench_sparsity(model)
+    js = zeros(Cint, 10)
+    check(nothing, ccall((:rdhip_model_wrench_sparsity, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cint}), handle(model), js))
+    return SMatrix{2,5,Bool,10}(js .!= 0)
+end
+RobotDynamics.wrench_sparsity(model::Union{Satellite,Quadrotor}) = native_wrench_sparsity(model)
 "length, errstate_dim, first(rot_inds(R,P,i)), first(vec_inds(R,P,i)) of a LieState{R,P} (src/liestate.jl:121-131), from the library"
 function liestate_query(::Type{R}, P::Tuple{Vararg{Int}}) where {R}
     nP = length(P)
@@ -687,6 +694,33 @@ function RobotDynamics.jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fu
         rc = ccall((:rdhip_jacobian, librdhip), Cint,
                    (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
                    c.ptr, handle(fun), rulecode(fun), diffcode(diff), dtypecode(T), N, _p(Z.data), _p(Z.t), _p(Z.dt), _p(J), _p(Y), sp)
+    end
+    check(c, rc)
+end
+
+# wrenches(model, x, u, t) = [forces; moments] for all k (src/rigidbody.jl:244-248): W is 6 x N; and d wrenches / d z for all k -- what the default
+# wrench_jacobian!(F, model, z) of src/rigidbody.jl:315-320 is written to return --: F is 6 x (n+m) x N.  Native RigidBody models only.
+function wrenches!(W::Dense{T,2}, model::RD.AbstractModel, Z::AbstractPackedTrajectory{n,m,T}; ctx::Union{Nothing,Context}=nothing) where {n,m,T}
+    _checkmodel(model, Z)
+    N = length(Z)
+    size(W) == (6, N) || throw(DimensionMismatch("W must be 6 x N"))
+    sp, found = _where(Z.data, Z.t, W)
+    c = _ctx(ctx, found)
+    GC.@preserve W Z begin
+        rc = ccall((:rdhip_wrenches, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   c.ptr, handle(model), dtypecode(T), N, _p(Z.data), _p(Z.t), _p(W), sp)
+    end
+    check(c, rc)
+end
+function RobotDynamics.wrench_jacobian!(F::Dense{T,3}, model::RD.AbstractModel, Z::AbstractPackedTrajectory{n,m,T}; ctx::Union{Nothing,Context}=nothing) where {n,m,T}
+    _checkmodel(model, Z)
+    N = length(Z)
+    size(F) == (6, n + m, N) || throw(DimensionMismatch("F must be 6 x (n+m) x N"))
+    sp, found = _where(Z.data, Z.t, F)
+    c = _ctx(ctx, found)
+    GC.@preserve F Z begin
+        rc = ccall((:rdhip_wrench_jacobian, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   c.ptr, handle(model), dtypecode(T), N, _p(Z.data), _p(Z.t), _p(F), sp)
     end
     check(c, rc)
 end

@@ -99,6 +99,9 @@ _SIGS = {
     "rdhip_gather": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_ulonglong), C.POINTER(_P)]),
     "rdhip_jacobian_sharded_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P)]),
     "rdhip_errstate_jacobian_sharded_gather": (C.c_int, [_P, _P, C.c_int, _LL, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P)]),
+    "rdhip_wrenches": (C.c_int, [_P, _P, C.c_int, _LL, _P, _P, _P, C.c_int]),
+    "rdhip_wrench_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, _P, _P, C.c_int]),
+    "rdhip_model_wrench_sparsity": (C.c_int, [_P, _IP]),
     "rdhip_rollout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, _P, _P, _P, _P, C.c_int]),
     "rdhip_rollout_layout": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, C.c_int]),
     "rdhip_ctx_last_rollout_jacobian_launches": (C.c_int, [_P, _IP]),

@@ -932,6 +932,41 @@ def gen_inds(model):
     return {k: range(first[i], first[i] + ln[i]) for i, k in enumerate(("r", "q", "v", "w", "u"))}
 
 
+def wrench_sparsity(model):
+    """wrench_sparsity(model) (src/rigidbody.jl:322-347): the 2 x 5 boolean block pattern [dF/dr dF/dq dF/dv dF/dw dF/du; dM/d...]."""
+    js = (C.c_int * 10)()
+    L.check(L.lib().rdhip_model_wrench_sparsity(_cm(model)._handle, js))
+    return np.array(list(js), dtype=bool).reshape(5, 2).T
+
+
+def _wrench_call(model, Z, out_shape, jac):
+    Z, single = _as_traj(model, _split_args(Z))
+    n, m = _check_traj(model, Z)
+    N = len(Z)
+    out = _empty_like_data(Z.data, (N,) + out_shape(n, m))
+    az, at = _Arg(Z.data, "Z.data"), _Arg(Z.t, "Z.t")
+    ao = _Arg(out, "output", az.dtype)
+    ctx, space = _resolve_ctx([az, at, ao])
+    fn = L.lib().rdhip_wrench_jacobian if jac else L.lib().rdhip_wrenches
+    L.check(fn(ctx.handle, _cm(model)._handle, az.dtype, N, az.ptr, at.ptr, ao.ptr, space), ctx.handle)
+    return out, single
+
+
+def wrenches(model, *args):
+    """wrenches(model, x, u, t) = [forces; moments] (src/rigidbody.jl:244-248): one knot point (x, u[, t]) / KnotPoint, or every knot point of a
+    PackedTrajectory -> (N, 6)."""
+    W, single = _wrench_call(model, args, lambda n, m: (6,), False)
+    return W[0] if single else W
+
+
+def wrench_jacobian(model, *args):
+    """d wrenches / d z (what wrench_jacobian!(F, model, z) of src/rigidbody.jl:315-320 is written to return): (6, n+m) for one knot point,
+    (N, 6, n+m) views for a PackedTrajectory (stored (N, n+m, 6): each slab column-major 6 x (n+m) like the reference's F)."""
+    F, single = _wrench_call(model, args, lambda n, m: (n + m, 6), True)
+    F = F.transpose(1, 2) if _is_torch(F) else F.transpose(0, 2, 1)
+    return F[0] if single else F
+
+
 def _ix(r):     # 1-based Julia range -> numpy slice
     return slice(r.start - 1, r.stop - 1)
 

@@ -1668,6 +1668,48 @@ def test_mixed_model_rollouts_and_jacobians_in_one_call(prec):
             assert abs(sums[p] - float(J1.double().sum())) <= 1e-9 * max(1.0, abs(sums[p]))
 
 
+@pytest.mark.parametrize("variant", ["satellite_quat", "quadrotor_quat", "satellite_mrp", "quadrotor_rp", "satellite_quat_f32"])
+def test_wrenches_and_wrench_jacobian(variant):
+    """wrenches(model, x, u, t) = [forces; moments] and d wrenches / d z (src/rigidbody.jl:244-248; wrench_jacobian!, :315-320) for every knot point
+    of a batch against the oracle's forward duals (which tests/test_oracle_kat.py holds to test/rigidbody_test.jl:26-46's closed form): ragged
+    batches, one knot point, host arrays through the staging path, fp32, MRP / RodriguesParam attitudes; wrench_sparsity as in the reference's
+    docstring example; models without a wrench refuse."""
+    kind, rtag = variant.split("_")[:2]
+    f32 = variant.endswith("_f32")
+    R, rot = {"quat": (RD.QuatRotation, O.ROT_QUAT), "mrp": (RD.MRP, O.ROT_MRP), "rp": (RD.RodriguesParam, O.ROT_RP)}[rtag]
+    rng = np.random.default_rng(71)
+    if kind == "satellite":
+        model, om, mctl = (RD.Body(R, False), O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), O.FRAME_WORLD, rot), 6)
+    else:
+        model, om, mctl = (RD.Quadrotor(R), O.quadrotor(O.FRAME_WORLD, rot), 4)
+    n = RD.state_dim(model)
+    for N in (130, 1, 64):
+        if rot == O.ROT_QUAT:
+            Zn = H.rand_rigid(rng, N, mctl, 0.5 if mctl == 4 else 0.0, 1.5 if mctl == 4 else 1.0)
+        else:
+            Zn = np.concatenate([rng.random((N, 3)), 0.6 * rng.random((N, 3)) - 0.3, rng.random((N, 6)), 0.5 + rng.random((N, mctl))], axis=1)
+        t, dt = np.arange(N) * 0.1, np.full(N, 0.1)
+        Wo, Fo = om.wrenches(Zn, t), om.wrench_jacobian(Zn, t)
+        for where in ("cuda", None):
+            Z = traj(model, Zn, t, dt, where, dtype=np.float32 if f32 else np.float64)
+            W, F = RD.wrenches(model, Z), RD.wrench_jacobian(model, Z)
+            assert tuple(W.shape) == (N, 6) and tuple(F.shape) == (N, 6, n + mctl)
+            if f32:
+                np.testing.assert_allclose(host(W).astype(np.float64), Wo, rtol=2e-5, atol=2e-5)
+                np.testing.assert_allclose(host(F).astype(np.float64), Fo, rtol=2e-5, atol=2e-5)
+            else:
+                np.testing.assert_allclose(host(W), Wo, rtol=0, atol=TOL)
+                np.testing.assert_allclose(host(F), Fo, rtol=0, atol=TOL)
+    # one knot point, (x, u, t) form
+    w1 = RD.wrenches(model, Zn[0, :n], Zn[0, n:], 0.3)
+    np.testing.assert_allclose(np.asarray(w1), Wo[0], rtol=0, atol=1e-12)
+    js = RD.wrench_sparsity(model)
+    np.testing.assert_array_equal(js, np.array([[False, True, False, False, True], [False, False, False, False, True]]))     # src/rigidbody.jl:339-345
+    assert np.all((np.abs(Fo).max(axis=0).reshape(6, -1)[:3, :3] == 0))                                                        # dF/dr = 0, as the pattern says
+    with pytest.raises(Exception):
+        RD.wrenches(RD.Cartpole(), traj(RD.Cartpole(), rng.random((4, 5)), np.zeros(4), np.full(4, 0.1), "cuda"))
+
+
 @pytest.mark.parametrize("rtag", ["mrp", "rp"])
 def test_three_parameter_rigid_bodies_rollout_implicit_midpoint_and_finite_difference(rtag):
     """RigidBody{MRP} / RigidBody{RodriguesParam} (src/rigidbody.jl:80-107, :213-236; test/rigidbody_test.jl:79-98) beyond the golden fixtures: both

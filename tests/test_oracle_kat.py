@@ -245,3 +245,54 @@ def test_implicit_midpoint_linear_closed_form_and_properties():
         E, J2, J1 = om.implicit_midpoint_error(np.concatenate([Zn[:1], np.concatenate([Xn[:1], Zn[:1, n:]], axis=1)]), 0.0, h)
         assert np.abs(E).max() < 1e-13                       # dynamics_error(z2 = [x_next; u], z1) = 0
         np.testing.assert_allclose(-np.linalg.solve(J2[0][:, :n], J1[0]), J[0], rtol=0, atol=1e-12)    # J = -J2[:,1:n] \\ J1
+
+
+def test_wrenches_and_their_jacobian_closed_forms():
+    """wrenches(model, x, u, t) and wrench_jacobian! (src/rigidbody.jl:244-248, :315-320).  Known answers:
+    * test/rigidbody_test.jl:26-46 (`Body`): F = q * u[1:3], M = u[4:6]; dF/dq = grad-rotate(q, f) (here: central differences of the rotation of
+      the NON-normalised quaternion, as `QuatRotation(q, false) * v` in test/rigidbody_test.jl:21), dF/du[1:3] = RotMatrix(q), dM/du[4:6] = I, zero elsewhere;
+    * test/rigidbody_test.jl:143-148: linear_velocity(xdot) = F / mass and angular_velocity(xdot) = inv(J) (T - w x J w) for every RigidBody;
+    * the quadrotor's wrench (test/quadrotor.jl:56-96): gravity + thrust along the body z axis, moments from the arm length / torque constant."""
+    rng = np.random.default_rng(23)
+    N = 7
+    Z = H.rand_rigid(rng, N, 6)
+
+    def rotm(q):
+        w, x, y, z = q
+        return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])      # q v q* without normalising q
+    om = O.body()
+    W, F = om.wrenches(Z, 0.0), om.wrench_jacobian(Z, 0.0)
+    assert W.shape == (N, 6) and F.shape == (N, 6, 19)
+    for k in range(N):
+        q, f = Z[k, 3:7], Z[k, 13:16]
+        np.testing.assert_allclose(W[k, :3], rotm(q) @ f, rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(W[k, 3:], Z[k, 16:19])
+        np.testing.assert_allclose(F[k, :3, 13:16], rotm(q), rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(F[k, 3:, 16:19], np.eye(3))
+        for j in range(4):
+            e = np.zeros(4); e[j] = 1e-6
+            np.testing.assert_allclose(F[k, :3, 3 + j], (rotm(q + e) @ f - rotm(q - e) @ f) / 2e-6, rtol=0, atol=1e-8)
+        mask = np.ones((6, 19), bool); mask[:3, 3:7] = False; mask[:3, 13:16] = False; mask[3:, 16:19] = False
+        assert np.all(F[k][mask] == 0.0)
+    # Newton-Euler identities for every rigid body (both frames enter only through the dynamics, not the wrench)
+    for om, Zr, mass, J in ((O.body(), Z, 2.0, np.diag([2.0, 3.0, 1.0])), (O.quadrotor(), H.rand_rigid(rng, N, 4, 0.5, 1.5), 0.5, np.diag([0.0023, 0.0023, 0.004]))):
+        W = om.wrenches(Zr, 0.0)
+        xd = om.dynamics(Zr, 0.0, 0.1)
+        w = Zr[:, 10:13]
+        np.testing.assert_allclose(xd[:, 7:10], W[:, :3] / mass, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(xd[:, 10:13], np.linalg.solve(J, (W[:, 3:] - np.cross(w, w @ J.T)).T).T, rtol=0, atol=1e-10)
+        Fj = om.wrench_jacobian(Zr, 0.0)
+        for j in range(Zr.shape[1]):                          # central differences of the wrench itself
+            Zp, Zm = Zr.copy(), Zr.copy(); Zp[:, j] += 1e-6; Zm[:, j] -= 1e-6
+            np.testing.assert_allclose(Fj[:, :, j], (om.wrenches(Zp, 0.0) - om.wrenches(Zm, 0.0)) / 2e-6, rtol=0, atol=1e-7)
+    # three-parameter attitudes act through their unit quaternion
+    for rot in (O.ROT_MRP, O.ROT_RP):
+        om3 = O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), O.FRAME_WORLD, rot)
+        Z3 = np.concatenate([rng.random((N, 3)), 0.6 * rng.random((N, 3)) - 0.3, rng.random((N, 6)), rng.random((N, 6))], axis=1)
+        W3 = om3.wrenches(Z3, 0.0)
+        for k in range(N):
+            p = Z3[k, 3:6]; n2 = p @ p
+            q = np.concatenate([[1 - n2], 2 * p]) / (1 + n2) if rot == O.ROT_MRP else np.concatenate([[1.0], p]) / np.sqrt(1 + n2)
+            np.testing.assert_allclose(W3[k, :3], rotm(q) @ Z3[k, 12:15], rtol=0, atol=1e-13)
