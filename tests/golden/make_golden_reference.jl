@@ -178,6 +178,11 @@ function dyn_case(name)
     for k = 1:N
         z = knot(Z, t, dt, k, n, m)
         out["xdot"][k, :] = RD.dynamics(model, z)
+        if model isa RD.RigidBody     # wrenches(model, x, u, t) and its ForwardDiff Jacobian (what the default wrench_jacobian! is written to return, src/rigidbody.jl:315-320)
+            haskey(out, "W") || (out["W"] = zeros(N, 6); out["Fw"] = zeros(N, 6, n + m))
+            out["W"][k, :] = RD.wrenches(model, RD.state(z), RD.control(z), t[k])
+            out["Fw"][k, :, :] = ForwardDiff.jacobian(zz -> RD.wrenches(model, zz[SVector{n}(1:n)], zz[SVector{m}(n+1:n+m)], t[k]), Vector(z.z))
+        end
         RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), model, J, y, z); out["Jc"][k, :, :] = J
         for (rn, Q) in rules
             dm = RD.DiscretizedDynamics{Q}(model)

@@ -40,6 +40,9 @@ def test_oracle_matches_the_reference_dynamics(name):
         J, Y = M.jacobian(rule, O.FORWARD_AD, Z, t, dt)
         np.testing.assert_allclose(Y, d["xn_" + rn], rtol=0, atol=TOL)
         np.testing.assert_allclose(J, d["Jd_" + rn], rtol=0, atol=TOL * max(1.0, np.abs(d["Jd_" + rn]).max()))
+    if "W" in d:            # RigidBody models: wrenches(model, x, u, t) and its ForwardDiff Jacobian
+        np.testing.assert_allclose(M.wrenches(Z, t), d["W"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(M.wrench_jacobian(Z, t), d["Fw"], rtol=0, atol=TOL)
     if "Jfd_rk4" in d:      # FiniteDiff's step rule: the reference's own tests only hold 1e-6; report how close the restated rule is
         J, _ = M.jacobian(O.RK4, O.FINITE_DIFF, Z, t, dt)
         np.testing.assert_allclose(J, d["Jfd_rk4"], rtol=0, atol=1e-6 * max(1.0, np.abs(d["Jd_rk4"]).max()))
