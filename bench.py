@@ -457,7 +457,12 @@ def main():
                      "traffic": traffic, "traffic_source": tsrc,
                      "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
                      "kernel_source": "the kernel rdhip_jacobian dispatches to for this configuration (csrc/dispatch.hpp launch_jacobian); name as in profiles/r03/kernel_stats.csv",
-                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT},
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT,
+                     "kernel_ms_is": ("time per launch of the job, HIP events around the timed region on the streams the launches go to.  With launch overlap on, consecutive launches "
+                                      "run on two streams and overlap in time: the rocprofv3 trace of this command shows it as the start-to-start interval of consecutive launches "
+                                      "(profiles/r03/summary.json: dominant_kernel.overlap_trace), while a launch's own DURATION (kernel_stats.csv) is longer because two launches share "
+                                      "the chip.  single_stream.kernel_ms is the same measurement with overlap off and agrees with the per-kernel average of "
+                                      "profiles/r03/kernel_stats_single_stream.csv") if not args.no_overlap else "time per launch, HIP events around the timed region (one stream)"},
     }
     if single:
         line["single_stream"] = single
