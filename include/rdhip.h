@@ -288,7 +288,7 @@ int rdhip_model_wrench_sparsity(const rdhip_model* model, int js[10]);
 #define RDHIP_TIME_MAJOR 1         /* knot k of trajectory j at index k*M + j: knot k of all trajectories contiguous */
 
 /* rdhip_rollout for either layout of the stack (rdhip_rollout = RDHIP_TRAJECTORY_MAJOR, the reference's "vector of trajectories").  Big batches
- * -- from two 64-trajectory groups per compute unit on, 32 768 trajectories on an MI355X -- are streamed through LDS in chunks of knot points as
+ * of models whose knot point is at least 128 bytes (the fp64 rigid bodies) -- from two 64-trajectory groups per compute unit on, 32 768 trajectories on an MI355X -- are streamed through LDS in chunks of knot points as
  * whole 16-byte units (csrc/rollout_stream.hpp; every run of the stack must start on a 16-byte boundary: Z 16-byte aligned and K (n+m) sizeof(T)
  * [trajectory-major] or M (n+m) sizeof(T) [time-major] a multiple of 16; other shapes take the one-lane-per-trajectory kernel).  That path
  * rewrites the CONTROLS of Z with the values it read (whole-line stores): Z must not be written concurrently by other work, which an in-place

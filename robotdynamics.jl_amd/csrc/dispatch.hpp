@@ -50,7 +50,10 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
         if ((forced || (!roll_env && (long long)grid >= 2LL * dev_info().cus)) && a.K >= 1) {
             typedef unsigned int V4 __attribute__((ext_vector_type(4)));
             constexpr int ZB = (Fn::NX + Fn::NU) * (int)sizeof(T);
-            const bool al = aligned16(a.Z) && ((a.time_major ? a.N : a.K) * ZB) % 16 == 0;
+            // (only where a knot point is big enough for the chunk traffic to dominate: with 76-byte fp32 rigid-body or 40-byte cartpole knot points the
+            // one compute wave per group and the two barriers per chunk are the bottleneck -- measured 0.32-0.34 against 0.46-0.48 for the one-lane
+            // kernel on fp32 satellite stacks, 0.16 against 0.25-0.49 for the cartpole)
+            const bool al = ZB >= 128 && aligned16(a.Z) && ((a.time_major ? a.N : a.K) * ZB) % 16 == 0;
             if (al && a.time_major) {
                 using L = StreamCfg<Fn, T, true>;
                 if constexpr (L::UNITS) {

@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(STREAM_THREADS, STREAM_WAVES_PER_SIMD) rollout
             for (int i = 0; i < UPT; ++i) {
                 const int u = i * NIOT + tid, r = u / UPR, o = u - r * UPR;
                 const bool ok = r < nr && o * USZ + USZ <= rb;
-                rin[i] = *reinterpret_cast<const U*>(run_ptr(k0, ok ? r : 0) + (ok ? o : 0) * USZ);
+                const U* src = reinterpret_cast<const U*>(run_ptr(k0, ok ? r : 0) + (ok ? o : 0) * USZ);
+                if constexpr (TM) rin[i] = __builtin_nontemporal_load(src); else rin[i] = *src;
             }
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
@@ -131,7 +132,9 @@ __global__ void __launch_bounds__(STREAM_THREADS, STREAM_WAVES_PER_SIMD) rollout
 #pragma unroll
                 for (int i = 0; i < UPT; ++i) {
                     const int u = i * NIOT + tid, r = u / UPR, o = u - r * UPR;
-                    if (r < nr && o * USZ + USZ <= rb) *reinterpret_cast<U*>(run_ptr(k0, r) + o * USZ) = rout[i];
+                    // (non-temporal: written once, not re-read by this launch; time-major stacks also LOAD non-temporally -- 0.50 -> 0.53-0.56 --, the
+                    // reference's layout does not: the runs of one trajectory's consecutive chunks share their first / last line)
+                    if (r < nr && o * USZ + USZ <= rb) __builtin_nontemporal_store(rout[i], reinterpret_cast<U*>(run_ptr(k0, r) + o * USZ));
                 }
             }
         }

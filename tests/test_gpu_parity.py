@@ -1442,8 +1442,9 @@ def test_streaming_rollout_of_big_batches(case):
     (csrc/rollout_stream.hpp: whole 16-byte units in, the states advanced in place, whole lines out -- the controls are written back unchanged).
     Against the oracle's sequential rollout of EVERY trajectory: both layouts, a ragged last group, step counts that are not multiples of the
     chunk, a single knot, a dt = 0 knot inside some trajectories, with and without a separate x0, fp32; shapes whose runs do not start on
-    16-byte boundaries (odd K in the reference's layout) take the one-lane-per-trajectory kernel and must give the same answer.  The controls,
-    the times and the knot points behind a trajectory's end must come back untouched."""
+    16-byte boundaries (odd K in the reference's layout) and models with small knot points (fp32 rigid bodies, the cartpole) take the
+    one-lane-per-trajectory kernel and must give the same answer.  The controls, the times and the knot points behind a trajectory's end must
+    come back untouched; implicit rules refuse time-major stacks."""
     parts = case.split("_")
     M, K = (int(v) for v in parts[3].split("x"))
     rng = np.random.default_rng(4242 + K)
@@ -1480,6 +1481,8 @@ def test_streaming_rollout_of_big_batches(case):
                 np.testing.assert_allclose(got[:, :, :n], ref[:, :, :n], rtol=0, atol=TOL)
                 np.testing.assert_array_equal(got[:, :, n:], data[:, :, n:])           # the controls: bit for bit
             assert torch.equal(stack["t"], t_before) and torch.equal(stack["dt"], dt_before)
+    with pytest.raises(Exception, match="trajectory-major"):
+        RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(model, RD.ImplicitMidpoint), stack, time_major=True)
 
 
 @pytest.mark.parametrize("case", ["satellite_tm_large", "satellite_traj_major", "cartpole_tm_large", "quadrotor_tm_host", "custom_tm_large",
