@@ -44,9 +44,10 @@ template <class T> struct RolloutTilesTM {
 };
 
 // the same for a TRAJECTORY-MAJOR stack (knot k of trajectory j at flat index j K + k -- how the reference holds a batch of trajectories): a tile
-// is 16 trajectories x 4 consecutive knots (GATHER tiles of the split-role loop: 16 runs of 4 slabs), item i = (chunk i / Q of 4 knots, quarter
-// group i % Q of 16 trajectories, Q = ceil(M / 16)), again in the order of production: group g's chunk c is complete when its progress word
-// reaches knot 4 c + 3
+// is 4 trajectories x 16 consecutive knots (GATHER tiles of the split-role loop: GATHER_NRUN runs of GATHER_RUN slabs -- long runs: with 4-knot
+// runs the chip wrote 3 072 scattered 8 KB pieces at a time and the one-launch call was no faster than two launches), item i = (chunk i / Q of GATHER_RUN knots, trajectory
+// group i % Q of GATHER_NRUN trajectories, Q = ceil(M / GATHER_NRUN)), again in the order of production: group g's chunk c is complete when its progress word
+// reaches knot GATHER_RUN (c + 1) - 1
 template <class T> struct RolloutTilesTJ {
     static constexpr bool RING = false, WAITS = true, GATHER = true;
     long long K, M; int Q;

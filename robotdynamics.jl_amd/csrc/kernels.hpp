@@ -194,10 +194,10 @@ template <class T> struct TileRef {
     long long N;      // knot points of the batch the tile belongs to
     long long k0;     // first knot point of the tile inside that batch
     // descriptors with GATHER: the tile's 64 slots are GATHER_NRUN runs of GATHER_RUN consecutive knot points, run r starting at knot k0 + r run_stride
-    // (16 trajectories x 4 knots of a trajectory-major stack); the first nruns runs and the first run_knots knots of every run exist
+    // (4 trajectories x 16 knots of a trajectory-major stack); the first nruns runs and the first run_knots knots of every run exist
     long long run_stride; int run_knots; int nruns;
 };
-constexpr int GATHER_RUN = 4, GATHER_NRUN = TILE / GATHER_RUN;
+constexpr int GATHER_RUN = 16, GATHER_NRUN = TILE / GATHER_RUN;      // (measured: runs of 4 / 8 / 16 knot points -> the one-launch call takes 0.97 / 0.955 / 0.905 of the two-launch time at 4 096 x 101)
 constexpr size_t SPLIT_GATHER_EXTRA = (size_t)GATHER_NRUN * 16;
 template <class BT, class = void> struct GatherOf { static constexpr bool value = false; };
 template <class BT> struct GatherOf<BT, decltype((void)BT::GATHER)> { static constexpr bool value = BT::GATHER; };
@@ -616,7 +616,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     constexpr int RB = OW * (int)sizeof(T);                                        // bytes of one knot point's slab
     constexpr int GRUN_BYTES = GATHER_RUN * RB + 16;
     constexpr size_t JB = L::J_BYTES + (GATHER ? SPLIT_GATHER_EXTRA : 0);
-    static_assert(!GATHER || (Fn::NEXT == 0 && NC == 4 && (GATHER_RUN * RB) % 16 == 0), "gather tiles: four copy waves of four runs each");
+    static_assert(!GATHER || (Fn::NEXT == 0 && NC == 4 && (GATHER_RUN * RB) % 16 == 0), "gather tiles: four copy waves of GATHER_NRUN / 4 runs each");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* jt = reinterpret_cast<T*>(smem);
     T* yt = reinterpret_cast<T*>(smem + JB);
@@ -801,7 +801,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         };
         TileRef<T> cur = bt.at(tile);
         if constexpr (GATHER) {
-            // gather tiles: copy wave w moves runs 4 w .. 4 w + 3.  A run is GATHER_RUN consecutive slabs = one contiguous piece of global memory that
+            // gather tiles: copy wave w moves runs RPW w .. RPW w + RPW - 1 (RPW = GATHER_NRUN / 4 = 1).  A run is GATHER_RUN consecutive slabs = one contiguous piece of global memory that
             // starts at byte A (only sizeof(T)-aligned); in LDS it sits at the same offset modulo 16 (padb = A & 15), so the wave moves the ALIGNED
             // 16-byte units that cover it -- whole 128-byte lines except at the two ends of the run (3 % of its lines) -- and handles the at most two
             // partly covered units element by element.

@@ -1543,7 +1543,7 @@ def test_rollout_then_jacobians_in_one_call(case):
 def test_fused_rollout_jacobian_overlaps_in_one_launch(case):
     """rdhip_rollout_jacobian on stacks of a rigid body is ONE launch (csrc/fused.hpp): rollout workgroups publish every finished chunk of 4 steps
     in a progress word, Jacobian workgroups on the other compute units consume the chunks behind them -- time-major stacks as 64-trajectory
-    slabs per knot, trajectory-major stacks (the reference's layout) as gathered tiles of 16 trajectories x 4 knots.  It must reproduce the
+    slabs per knot, trajectory-major stacks (the reference's layout) as gathered tiles of 4 trajectories x 16 knots.  It must reproduce the
     oracle's sequential rollout and Jacobians, agree with the two-call path (states bit for bit: rdhip_rollout runs the SAME kernel with rollout
     workgroups only; Jacobians to the last bit or two: the same column code in a separately compiled kernel), survive being called again
     (the words of an earlier call must not satisfy a later one) and being replayed from a captured graph; time-major stacks whose tiles do not
