@@ -3,7 +3,7 @@ root=$PWD
 out=$root/gpurun_out/pmc_stream; mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --pmc $c --output-format csv -d $out/$c -o s -- $root/robotdynamics.jl_amd/csrc/tune/tune_stream_4_3 > $out/$c.log 2>&1
+rocprofv3 --pmc $c --output-format csv -d $out/$c -o s -- $root/robotdynamics.jl_amd/csrc/tune/tune_stream > $out/$c.log 2>&1
 done
 find $out -name "*.db" -delete
 python3 - <<'P'
