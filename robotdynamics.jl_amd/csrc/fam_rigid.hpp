@@ -9,8 +9,10 @@ namespace rd {
 // waves carry similar totals (~740-830), and every wave carries ONE quaternion column ahead of everything expensive, so that the leading ten
 // columns (r, q, v: 53 % of a row) of a workgroup's first tile are final after a quarter of the arithmetic and their whole 128-byte lines
 // leave while the rest is computed (TablePlanS, kernels.hpp; tuning harness, back-to-back launches at N = 65 536: 28.1 -> 26.4 us).
-//   wave 0: r, q3, w10, uF13   wave 1: q4, v, w11, uF14, uF15 (+ f(z))   wave 2: q5, w12, tau18   wave 3: q6, tau16, tau17
-using SatPlan = TablePlanS<19, 4, 1, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 1, /*tau*/ 3, 3, 2>;
+//   wave 0: r, q3, w10, uF13   wave 1: q4, v, w11, uF14, uF15   wave 2: q5, w12, tau18   wave 3: q6, tau16, tau17 (+ f(z))
+// (round 3: f(z) from wave 3 instead of wave 1 -- the value wave keeps the primal outputs live through its first column, and on wave 1 that cost 12 bytes
+// of scratch per lane: 26.85 -> 26.15 us single stream in the same-box A/B of tune/tune_plan.hip, body-frame velocities 51.5 -> 47.7, other rules equal)
+using SatPlan = TablePlanS<19, 4, 3, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 1, 1, 1, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 1, /*tau*/ 3, 3, 2>;
 // Quadrotor columns: r 0-2, q 3-6, v 7-9, w 10-12, u 13-16 (each rotor thrust feeds both F and tau, ~310 per column)
 //   wave 0: q3, w10, u15   wave 1: q4, w11, u16   wave 2: r, q5, v, w12 (+ f(z))   wave 3: q6, u13, u14
 using QuadPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
@@ -19,8 +21,10 @@ template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WR
 template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls
-// (one attitude column per wave first: the leading nine columns r, phi, v are the early part of a first tile, like SatPlan's ten)
-using SatErrPlan = TablePlanS<18, 4, 0, 9, /*r*/ 3, 3, 3, /*phi*/ 0, 1, 2, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*uF*/ 0, 1, 2, /*tau*/ 3, 3, 3>;
+// Satellite (round 3, searched with tune/tune_errexp.hip: 25.3 -> 23.8 us in the same-box A/B; the round-2 plan r, v, tau x 3 | (phi, w, uF) x 3 spilled 64
+// bytes per lane on the value wave): (phi0 w0 tau0) (phi1 w1 tau1) (r v w2 uF0 + f(z)) (phi2 tau2 uF1 uF2); the early part of a first tile is r, phi.
+// Quadrotor: the round-2 plan stays (23.5 us; the satellite's shape costs 26.7 there -- every rotor column is as heavy as a torque column).
+using SatErrPlan = TablePlanS<18, 4, 2, 6, /*r*/ 2, 2, 2, /*phi*/ 0, 1, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*uF*/ 2, 3, 3, /*tau*/ 0, 1, 3>;
 using QuadErrPlan = TablePlanS<16, 4, 2, 9, /*r*/ 3, 3, 3, /*phi*/ 0, 1, 2, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { using Plan = SatErrPlan; };
 template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { using Plan = QuadErrPlan; };
