@@ -1483,6 +1483,12 @@ def test_streaming_rollout_of_big_batches(case):
             assert torch.equal(stack["t"], t_before) and torch.equal(stack["dt"], dt_before)
     with pytest.raises(Exception, match="trajectory-major"):
         RD.rollout_(RD.StaticReturn(), RD.DiscretizedDynamics(model, RD.ImplicitMidpoint), stack, time_major=True)
+    # host arrays, time-major, a small batch: rdhip_rollout_layout through the staging path and the latency-regime kernels
+    Ms = 70
+    hst = {"data": np.ascontiguousarray(cast(data[:Ms]).transpose(1, 0, 2)), "t": np.ascontiguousarray(t[:Ms].T), "dt": np.ascontiguousarray(dt[:Ms].T)}
+    RD.rollout_(RD.StaticReturn(), dm, hst, None, time_major=True)
+    refs = om.rollout(orule, data[:Ms], t[:Ms], dt[:Ms])
+    np.testing.assert_allclose(hst["data"].astype(np.float64).transpose(1, 0, 2)[:, :, :n], refs[:, :, :n], rtol=2e-4 if f32 else 0, atol=2e-4 if f32 else TOL)
 
 
 @pytest.mark.parametrize("case", ["satellite_tm_large", "satellite_traj_major", "cartpole_tm_large", "quadrotor_tm_host", "custom_tm_large",
