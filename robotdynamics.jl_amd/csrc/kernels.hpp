@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(Fn fn, long long K, long lo
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU;
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
+    // a latency chain: when the wave shares its SIMD with waves of another kernel (the mixed-model call runs this rollout next to the persistent
+    // Jacobian workgroups of the other model's fused launch, which poll and stream), it should win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     T x[NX], u[NU], y[NX];
     const long long ip = j * sj;                              // knot 0 of this trajectory
     {
