@@ -75,7 +75,10 @@ template <class T, int K> RD_DEV Dual<T, K> operator/(const Dual<T, K>& a, T b) 
 // sin and cos (each with its own extended-precision reduction) cost ~300, which made the cartpole kernels transcendental-bound.
 // Larger arguments fall back to the library.
 RD_DEV void sincos_(double x, double& sn, double& cs) {
-    if (__builtin_fabs(x) < 8.0e5) {
+    // the fast path runs unconditionally and the library fixes up the lanes it does not cover BEHIND it, under a wave-uniform test: a per-lane branch
+    // in front (two code paths, a merge with register copies, four times per RK4 step of the cartpole) cost the small-model kernels ~10 % of their
+    // instructions, and they are bound by fp64 issue
+    {
         const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
         double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x), t = r;
         double w = fn * 6.07710050630396597660e-11;
@@ -96,7 +99,11 @@ RD_DEV void sincos_(double x, double& sn, double& cs) {
         const double a = (n & 1) ? kc : ks, b = (n & 1) ? ks : kc;
         sn = (n & 2) ? -a : a;
         cs = ((n + 1) & 2) ? -b : b;
-    } else { sn = sin(x); cs = cos(x); }
+    }
+    const bool wide = !(__builtin_fabs(x) < 8.0e5);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0, 0)) {
+        if (wide) { sn = sin(x); cs = cos(x); }
+    }
 }
 // fp32: one shared three-constant Cody-Waite reduction by pi/2 (exact products inside the FMAs) and the Cephes single-precision polynomials on
 // [-pi/4, pi/4]: <= 1.6 ulp for |x| < 1e5 (checked against float64 sin / cos on 3 10^6 arguments per decade), ~22 instructions for both values.
