@@ -61,6 +61,33 @@ inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
     return (unsigned)(ntiles < g ? ntiles : g);
 }
 
+// the same with the kernel's REGISTER footprint taken into account (the LDS / thread bound above assumes the registers never limit residency: an fp32
+// tile kernel whose 67 KB of LDS would let two workgroups share a CU but whose 146 registers do not must get one workgroup per CU, or half of the
+// "persistent" grid queues behind the other half); asked from the runtime once per (kernel, device)
+inline unsigned tile_grid_occ(const void* kernel, size_t lds_bytes, int threads, long long ntiles) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> per_cu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return tile_grid(lds_bytes, threads, ntiles);
+    int per_cu = 0;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = per_cu_of[dev & 63].find(kernel);
+        if (it != per_cu_of[dev & 63].end()) per_cu = it->second;
+    }
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds_bytes) != hipSuccess || n < 1) { (void)hipGetLastError(); return tile_grid(lds_bytes, threads, ntiles); }
+        per_cu = n > 8 ? 8 : n;
+        std::lock_guard<std::mutex> g(mu);
+        per_cu_of[dev & 63][kernel] = per_cu;
+    }
+    const unsigned lds_bound = tile_grid(lds_bytes, threads, ntiles);
+    const long long g = (long long)dev_info().cus * per_cu;
+    const long long r = ntiles < g ? ntiles : g;
+    return (unsigned)(r < (long long)lds_bound ? r : (long long)lds_bound);
+}
+
 // implicit kernels: flag words of a context (word 0: whole batch; words 1 .. : one per 64-knot tile)
 constexpr long long IMPLICIT_FLAG_WORDS = 1 << 20;
 

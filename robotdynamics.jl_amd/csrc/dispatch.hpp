@@ -118,7 +118,7 @@ template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
 
@@ -129,7 +129,7 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
 
@@ -141,7 +141,7 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid(lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J);
+    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J);
     return hip_status(hipGetLastError());
 }
 
@@ -159,7 +159,7 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
     auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kern, dim3(tile_grid(lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
     return hip_status(hipGetLastError());
 }
 template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {
@@ -167,7 +167,7 @@ template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
     auto kern = jac_tile_multi_kernel<Fn, T, Plan, Body>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(tile_grid(lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
     return hip_status(hipGetLastError());
 }
 // several packed trajectories, one launch: the same kernel choice as launch_jacobian below, every body on a MultiBatch
@@ -192,7 +192,7 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
             constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
-            if constexpr (NC > 0) { if (al) return launch_split_multi<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>, (sizeof(T) == 4 ? 4 : 1)>(fn, a); }
+            if constexpr (NC > 0) { if (al) return launch_split_multi<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>, (sizeof(T) == 4 ? RD_F32_MINB : 1)>(fn, a); }
             return launch_tile_multi<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, a);
         } else {
             if constexpr (split_fits) { if (al) return launch_split_multi<Fn, T, DefPlan, 4, AdLoopBody<Fn, T, DefPlan>>(fn, a); }

@@ -9,6 +9,12 @@
 
 namespace rd {
 
+// register budget of the fp32 ForwardAD tile kernels, in waves per SIMD: 2 = up to 256 registers (the kernels take 146 and do not spill; one
+// workgroup per CU).  Rounds 1-3 asked for 4 (128 registers, two workgroups per CU by LDS): 68 bytes of scratch per lane and 30.3 instead of
+// 26.9 us for 131 072 fp32 satellite knot points (tune/tune_plan.hip -DTT=float, same-box A/B)
+#ifndef RD_F32_MINB
+#define RD_F32_MINB 2
+#endif
 constexpr int TILE = 64;   // knot points per wave = wave width on gfx950
 constexpr int ROLLOUT_PREFETCH = 4;   // rollout kernels: inputs are requested this many steps ahead
 
@@ -924,7 +930,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) { jac_split_loop<Fn, T, Plan, NC, Body, BT>(fn, bt, blockIdx.x, gridDim.x); }
 template <class Fn, class T, class Plan, int NC>
-__global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? 4 : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? RD_F32_MINB : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
     jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
