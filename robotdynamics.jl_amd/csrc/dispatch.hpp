@@ -56,7 +56,7 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
             const bool al = ZB >= 128 && aligned16(a.Z) && ((a.time_major ? a.N : a.K) * ZB) % 16 == 0;
             if (al && a.time_major) {
                 using L = StreamCfg<Fn, T, true>;
-                if constexpr (L::UNITS) {
+                if constexpr (L::UNITS && ZB >= 128) {
                     auto ks = rollout_stream_kernel<Fn, T, true, V4>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
@@ -64,7 +64,7 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
                 }
             } else if (al) {
                 using L = StreamCfg<Fn, T, false>;
-                if constexpr (L::UNITS) {
+                if constexpr (L::UNITS && ZB >= 128) {
                     auto ks = rollout_stream_kernel<Fn, T, false, V4>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
                     hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
@@ -182,7 +182,7 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
     if (ntiles == 0) return RDHIP_OK;
     const bool al = a.multi->aligned16;
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (NZ <= 10) {
+        if constexpr (NZ <= 10 && !UnrollPolicy<Mdl, RULE>::value) {
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_multi_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
@@ -230,7 +230,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (NZ <= 10) {
+        if constexpr (NZ <= 10 && !UnrollPolicy<Mdl, RULE>::value) {
             // small models: one wave = 64 knot points x all columns (no per-wave replication of the primal)
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_kernel<Fn, T>;

@@ -1018,7 +1018,9 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
                 # the same arithmetic per column as the single-batch launch; batches of <= 8 192 knot points take the column-split kernel there
                 # (a separately compiled instantiation of the same column code: FMA contraction may differ in the last bit), larger ones the
                 # very same tile loop
-                if N > 8192 or RD.state_dim(model) + RD.control_dim(model) <= 10:
+                # (small models: the single- and the multi-batch kernel are two instantiations of the same code as well -- they agreed bit for bit
+                # until an unrelated change to the translation unit moved the compiler's inlining: held to the last bits, not to equality)
+                if N > 8192:
                     assert torch.equal(J1, Js[b])
                 else:
                     np.testing.assert_allclose(host(J1), host(Js[b]), rtol=0, atol=1e-13)
