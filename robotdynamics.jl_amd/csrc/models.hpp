@@ -332,8 +332,10 @@ template <class T_> struct LieSatellite {
     }
     template <class S> RD_DEV void f(const S* x, const S* u, S* xd) const {
         const S* w = x;
+        // q = normalize(x[4:7]) (test/liemodel.jl:15): StaticArrays' normalize is inv(norm(a)) * a -- one reciprocal and four products, not four divisions
         const S nn = sqrt_(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
-        const S q[4] = {x[3] / nn, x[4] / nn, x[5] / nn, x[6] / nn};
+        const S inv = recip_(nn);
+        const S q[4] = {x[3] * inv, x[4] * inv, x[5] * inv, x[6] * inv};
         const S Jw[3] = {w[0] * Jd[0], w[1] * Jd[1], w[2] * Jd[2]};
         S c[3]; cross3(w, Jw, c);
 #pragma unroll
