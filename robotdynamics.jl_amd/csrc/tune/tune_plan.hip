@@ -16,7 +16,10 @@ using namespace rd;
 #ifndef RULE
 #define RULE RULE_RK4
 #endif
-#ifdef QUAD
+#if defined(PAIR)
+using Mdl = SatellitePair<TT>;
+constexpr int NZc = 20;
+#elif defined(QUAD)
 using Mdl = RigidBody<TT, WRENCH_QUADROTOR, BODYF, DIAG>;
 constexpr int NZc = 17;
 #else
@@ -26,7 +29,14 @@ constexpr int NZc = 19;
 using Fn = Fun<Mdl, RULE>;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 // columns: r0 r1 r2 | q0 q1 q2 q3 | v0 v1 v2 | w0 w1 w2 | uF0 uF1 uF2 | tau0 tau1 tau2
-#ifdef QUAD
+#if defined(PAIR)
+using P0 = TablePlan<20, 4, 0, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;        // shipped (PairPlan)
+using P1 = TablePlan<20, 4, 1, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;
+using P2 = TablePlan<20, 4, 2, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;
+using P3 = TablePlan<20, 4, 3, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;
+using P4 = TablePlanS<20, 4, 0, 7, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;
+using P5 = TablePlanS<20, 4, 2, 4, 0, 1, 2, 3, 0, 0, 2, 0, 1, 2, 3, 1, 1, 3, 0, 2, 2, 1, 3, 3>;    // one q1 column per wave first (early 4), value from wave 2
+#elif defined(QUAD)
 using P0 = TablePlanS<17, 4, 2, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;     // shipped (QuadPlan)
 using P1 = TablePlanS<17, 4, 0, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;
 using P2 = TablePlanS<17, 4, 1, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;
@@ -57,7 +67,7 @@ template <class Plan> void run(const char* name, const Fn& fn, long long N, cons
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps; sum += us; if (us < best) best = us;
     }
-    printf("%-4s %8.2f us (best %8.2f)  frac %.3f\n", name, sum / 5, best, N * (NZc * sizeof(TT) + 16.0 + 13.0 * (NZc + 1) * sizeof(TT)) / (sum / 5 * 1e-6) / 8e12);
+    printf("%-4s %8.2f us (best %8.2f)  frac %.3f\n", name, sum / 5, best, N * (NZc * sizeof(TT) + 16.0 + (double)Mdl::NX * (NZc + 1) * sizeof(TT)) / (sum / 5 * 1e-6) / 8e12);
 }
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 400;
@@ -66,9 +76,13 @@ int main(int argc, char** argv) {
     for (long long k = 0; k < N; ++k) { for (int i = 0; i < NZc; ++i) hz[k * NZc + i] = (TT)(0.5 + 0.8 * ((k * NZc + i) * 2654435761u % 1000) / 1000.0); ht[k] = 0.1 * k; }
     TT *Z, *J[4], *Y[4]; double *t, *dt;
     CK(hipMalloc(&Z, N * NZc * sizeof(TT))); CK(hipMalloc(&t, N * 8)); CK(hipMalloc(&dt, N * 8));
-    for (int b = 0; b < 4; ++b) { CK(hipMalloc(&J[b], N * 13 * NZc * sizeof(TT))); CK(hipMalloc(&Y[b], N * 13 * sizeof(TT))); }
+    for (int b = 0; b < 4; ++b) { CK(hipMalloc(&J[b], N * Mdl::NX * NZc * sizeof(TT))); CK(hipMalloc(&Y[b], N * Mdl::NX * sizeof(TT))); }
     CK(hipMemcpy(Z, hz.data(), hz.size() * sizeof(TT), hipMemcpyHostToDevice)); CK(hipMemcpy(t, ht.data(), ht.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dt, hdt.data(), hdt.size() * 8, hipMemcpyHostToDevice));
+#if defined(PAIR)
+    double prm[18] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 2, 0, 0, 0, 2, 0, 0, 0, 2};
+#else
     double prm[16] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, -9.81, 0.175, 1.0, 0.0245};
+#endif
     Fn fn{Mdl::make(prm)};
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     for (int rep = 0; rep < 2; ++rep) {
