@@ -182,12 +182,12 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
     if (ntiles == 0) return RDHIP_OK;
     const bool al = a.multi->aligned16;
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (NZ <= 10 && !UnrollPolicy<Mdl, RULE>::value) {
+        if constexpr (NZ <= 10 && !(UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0)) {       // (a small model with a split-role plan of its own -- LieSatellite -- takes the tile loop)
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_multi_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             constexpr int W = SmallLds<Fn, T>::WAVES;
-            hipLaunchKernelGGL(kern, dim3(tile_grid(lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+            hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
@@ -230,14 +230,14 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
     if (a.N == 0) return RDHIP_OK;
     Fn fn{m};
     if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (NZ <= 10 && !UnrollPolicy<Mdl, RULE>::value) {
+        if constexpr (NZ <= 10 && !(UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0)) {       // (a small model with a split-role plan of its own -- LieSatellite -- takes the tile loop)
             // small models: one wave = 64 knot points x all columns (no per-wave replication of the primal)
             constexpr size_t lds = SmallLds<Fn, T>::BYTES;
             auto kern = jac_ad_small_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             const long long ntiles = (a.N + TILE - 1) / TILE;
             constexpr int W = SmallLds<Fn, T>::WAVES;
-            hipLaunchKernelGGL(kern, dim3(tile_grid(lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+            hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
