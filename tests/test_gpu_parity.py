@@ -1971,3 +1971,30 @@ def test_single_knot_point_api_reads_like_the_reference():
         RD.jacobian_(RD.StaticReturn(), RD.UserDefined(), RD.SatellitePair(), np.zeros((14, 20)), np.zeros(14), RD.KnotPoint(np.ones(14), np.ones(6), 0.0, 0.1))
     with pytest.raises(ValueError):
         RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dmodel, RD.alloc_jacobians(dmodel, 3), None, RD.PackedTrajectory(4, 1, np.zeros((2, 5)), 0.0, 0.1))
+
+
+def test_dispatch_reaches_the_fast_kernels():
+    """Not a benchmark: a guard against silent dispatch regressions (a template condition once sent the cartpole to the generic unrolled tile kernel:
+    176 instead of 41 us at 1 M knot points, every parity test still green).  Thresholds are half of what the kernels reach on the slowest box seen."""
+    rng = np.random.default_rng(5)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    for model, gen, N, floor in ((RD.Cartpole(), lambda N: rng.random((N, 5)), 1 << 20, 0.35),
+                                 (RD.Satellite(), lambda N: H.rand_rigid(rng, N, 6), 1 << 18, 0.35)):
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        Z = traj(model, gen(N), np.arange(N) * 0.1, np.full(N, 0.1), "cuda")
+        Js = [RD.alloc_jacobians(dm, N, Z.data) for _ in range(2)]
+        Ys = [torch.empty((N, n), dtype=torch.float64, device="cuda") for _ in range(2)]
+        calls = [RD.prepare_jacobian(sig, AD, dm, Js[b], Ys[b], Z) for b in range(2)]
+        for i in range(30):
+            calls[i % 2]()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            calls[i % 2]()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        frac = N * ((n + m) * 8 + 16 + n * (n + m) * 8 + n * 8) / (us * 1e-6) / 8e12
+        assert frac > floor, (type(model).__name__, us, frac)
