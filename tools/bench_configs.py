@@ -247,10 +247,12 @@ def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
              {"trajectories": M, "knots": K, "kernel_launches_per_call": RD.rollout_jacobian_(sig, AD, fun, J, stack, time_major=tm)})
 
 
-def c5_case(reps, rng):
-    """One GPU's share of BASELINE config 5: 512 Cartpole + 512 Satellite trajectories x 256 knots, fp32, rollouts + all Jacobians:
+def c5_case(reps, rng, M=512):
+    """BASELINE config 5 (M = 512: one GPU's share of the 8-GPU split; M = 4096: the whole workload on ONE GPU): M Cartpole + M Satellite
+    trajectories x 256 knots, fp32, rollouts + all Jacobians:
     (a) four calls (rollout_, jacobian_ per model), (b) one rdhip_rollout_jacobian call per model, (c) ONE rdhip_rollout_jacobian_multi call."""
-    M, K, dtype = 512, 256, np.float32
+    K, dtype = 256, np.float32
+    tag = "C5 share" if M == 512 else "C5 whole"
     sig, AD = RD.StaticReturn(), RD.ForwardAD()
     funs, stacks_tm, stacks_tj, Js, flats, alg = [], [], [], [], [], 0
     for model, mctl in ((RD.Cartpole(), 1), (RD.Satellite(), 6)):
@@ -271,16 +273,16 @@ def c5_case(reps, rng):
             RD.rollout_(sig, funs[p], stacks_tj[p])
             RD.jacobian_(sig, AD, funs[p], Js[p], None, flats[p])
     us = timed(four, reps, warm=2)
-    emit("C5 share (512 cartpole + 512 satellite x 256, fp32): rollout_ + jacobian_ per model (four calls)", 2 * M * K, "f32", us, alg)
+    emit(f"{tag} ({M} cartpole + {M} satellite x 256, fp32): rollout_ + jacobian_ per model (four calls)", 2 * M * K, "f32", us, alg)
 
     def two(i):
         for p in range(2):
             RD.rollout_jacobian_(sig, AD, funs[p], Js[p], stacks_tm[p], time_major=True)
     us = timed(two, reps, warm=2)
-    emit("C5 share: rollout_jacobian_ per model, time-major (two calls)", 2 * M * K, "f32", us, alg)
+    emit(f"{tag}: rollout_jacobian_ per model, time-major (two calls)", 2 * M * K, "f32", us, alg)
     call = RD.PreparedRolloutJacobianMulti(sig, AD, funs, Js, stacks_tm, None, time_major=True)
     us = timed(lambda i: call(), reps, warm=2)
-    emit("C5 share: ONE call (rdhip_rollout_jacobian_multi), time-major", 2 * M * K, "f32", us, alg)
+    emit(f"{tag}: ONE call (rdhip_rollout_jacobian_multi), time-major", 2 * M * K, "f32", us, alg, {"trajectories": 2 * M, "knots": K})
 
 
 def multi_case(name, model, gen, nbatch, per, rule, dtype, reps, singles=True, diff=None):
@@ -384,6 +386,26 @@ def main():
         rollout_case("cartpole RK4 rollout fp64 262144 traj x 32 knots", cart, 262144, 32, RD.RK4, f64, 5, rng, tm=True)
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        return
+    if a.only == "c5full":
+        c5_case(10, rng, M=4096)
+        rollout_case("C5 whole: cartpole RK4 rollout fp32 4096 traj x 256 knots", cart, 4096, 256, RD.RK4, f32, 10, rng, tm=True)
+        rollout_case("C5 whole: satellite RK4 rollout fp32 4096 traj x 256 knots", sat, 4096, 256, RD.RK4, f32, 10, rng, tm=True)
+        jac_case("C5 whole: cartpole RK4 jacobian fp32 (4096 traj x 256 knots)", cart, rng.random((1 << 20, 5)), RD.RK4, AD, f32, a.reps, with_y=False)
+        jac_case("C5 whole: satellite RK4 jacobian fp32 (4096 traj x 256 knots)", sat, rigid_inputs(1 << 20, 6, rng), RD.RK4, AD, f32, a.reps, with_y=False)
+        return
+    if a.only == "body":
+        Zs = rigid_inputs(65536, 6, rng)
+        Zq = rigid_inputs(65536, 4, rng, 0.6, 1.9)
+        jac_case("C3 satellite RK4 jacobian ForwardAD (+x_next) [flagship, same box]", sat, Zs, RD.RK4, AD, f64, a.reps)
+        jac_case("body-frame satellite RK4 jacobian ForwardAD", RD.Satellite(bodyframe=True), Zs, RD.RK4, AD, f64, a.reps)
+        jac_case("body-frame full-inertia satellite RK4 jacobian ForwardAD", RD.Satellite(mass=1.5, J=np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]]), bodyframe=True), Zs, RD.RK4, AD, f64, a.reps)
+        jac_case("quadrotor RK4 jacobian ForwardAD [same box]", quad, Zq, RD.RK4, AD, f64, a.reps)
+        jac_case("body-frame quadrotor RK4 jacobian ForwardAD", RD.Quadrotor(bodyframe=True), Zq, RD.RK4, AD, f64, a.reps)
+        jac_case("body-frame satellite RK3 jacobian ForwardAD", RD.Satellite(bodyframe=True), Zs, RD.RK3, AD, f64, a.reps)
+        jac_case("body-frame satellite continuous jacobian ForwardAD", RD.Satellite(bodyframe=True), Zs, None, AD, f64, a.reps)
+        jac_case("body-frame satellite RK4 jacobian FiniteDifference", RD.Satellite(bodyframe=True), Zs, RD.RK4, FD, f64, a.reps)
+        jac_case("body-frame satellite RK4 jacobian fp32", RD.Satellite(bodyframe=True), rigid_inputs(131072, 6, rng), RD.RK4, AD, f32, a.reps)
         return
     if a.only in ("c5", "rolljac"):
         c5_case(10, rng)
