@@ -166,24 +166,32 @@ def secondary_metrics(dev, reps):
     us = _timed_us(lambda i: RD.rollout_(RD.StaticReturn(), dm, stack), 20, warm=2)
     out["rollout_rk4_satellite_fp32"] = {"trajectories": Mr, "knot_points_per_trajectory": Kr, "value": Mr * (Kr - 1) / (us * 1e-6), "unit": "simulated steps/s",
                                          "us_per_launch": us, "us_per_step": us / (Kr - 1)}
-    # C5's share of one GPU in ONE call: 512 Cartpole + 512 Satellite trajectories x 256 knots, fp32, rollouts + all Jacobians (rdhip_rollout_jacobian_multi)
-    try:
+    # BASELINE config 5 in ONE call (rdhip_rollout_jacobian_multi: rollouts + all Jacobians, fp32, time-major): (a) the WHOLE workload on this one GPU --
+    # 4 096 Cartpole + 4 096 Satellite trajectories x 256 knots, the N = 1 point of its scaling curve -- and (b) one GPU's share of the 8-GPU split
+    # (512 + 512).  Algorithmic bytes per simulated + linearised knot point: satellite 1 080 (Jacobian) + 52 (the state the rollout
+    # writes), cartpole 116 + 16.
+    def c5_case(Mc):
         funs, stacks, Jc = [], [], []
         for mdl, mctl in ((RD.Cartpole(), 1), (sat, NU)):
             n = RD.state_dim(mdl)
-            zz = synthetic_inputs(Mr * Kr, 13)[0] if n == 13 else np.random.default_rng(14).random((Mr * Kr, n + mctl))
+            zz = synthetic_inputs(Mc * Kr, 13)[0] if n == 13 else np.random.default_rng(14).random((Mc * Kr, n + mctl))
             fun = RD.DiscretizedDynamics(mdl, RD.RK4)
-            st = {"data": torch.as_tensor(zz.astype(np.float32).reshape(Kr, Mr, n + mctl)).to(dev),
-                  "t": torch.as_tensor(np.ascontiguousarray(np.broadcast_to((np.arange(Kr) * 0.01)[:, None], (Kr, Mr)))).to(dev),
-                  "dt": torch.full((Kr, Mr), 0.01, dtype=torch.float64, device=dev)}
-            funs.append(fun); stacks.append(st); Jc.append(RD.alloc_jacobians(fun, Mr * Kr, st["data"]))
+            st = {"data": torch.as_tensor(zz.astype(np.float32).reshape(Kr, Mc, n + mctl)).to(dev),
+                  "t": torch.as_tensor(np.ascontiguousarray(np.broadcast_to((np.arange(Kr) * 0.01)[:, None], (Kr, Mc)))).to(dev),
+                  "dt": torch.full((Kr, Mc), 0.01, dtype=torch.float64, device=dev)}
+            funs.append(fun); stacks.append(st); Jc.append(RD.alloc_jacobians(fun, Mc * Kr, st["data"]))
         c5 = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stacks, None, time_major=True)
         us = _timed_us(lambda i: c5(), 20, warm=2)
-        out["c5_share_one_call_fp32"] = {"trajectories": 2 * Mr, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mr * Kr / (us * 1e-6),
-                                         "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi"}
-        del funs, stacks, Jc, c5
-    except Exception as e:
-        out["c5_share_one_call_fp32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        alg = Mc * Kr * ((1080 + 52) + (116 + 16))
+        return {"trajectories": 2 * Mc, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mc * Kr / (us * 1e-6),
+                "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi", "dtype": "f32",
+                "algorithmic_bytes": alg, "bytes_per_knot": {"satellite": 1080 + 52, "cartpole": 116 + 16},
+                "GBps": alg / (us * 1e-6) / 1e9, "frac_of_hbm_peak": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    for key, Mc in (("c5_whole_one_gpu_one_call_fp32", 4096), ("c5_share_one_call_fp32", Mr)):
+        try:
+            out[key] = c5_case(Mc)
+        except Exception as e:
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # 16 x 4096: separate launches vs one fused launch
     nbt, per = 16, 4096
     Zs = []
@@ -359,10 +367,13 @@ def main():
 
     wd.arm(args.phase_timeout, "set-up, warm-up and timed region", rank)
     N = args.knots
-    Zn, t, dt = synthetic_inputs(N, seed=3 + rank)
     model = RD.Satellite()                       # mass 1, J = I3 (examples/single_satellite.jl:33-35)
     dmodel = RD.DiscretizedDynamics(model, RD.RK4)
-    Z = RD.PackedTrajectory(NX, NU, Zn, t, dt).to(dev)
+    # NBUF distinct input batches as well (different seeds, separate Z / t / dt arrays): step i reads batch i % NBUF and writes output buffer i % NBUF
+    host_in = [synthetic_inputs(N, seed=3 + rank + 1000 * b) for b in range(NBUF)]
+    Zn, t, dt = host_in[0]
+    Zs = [RD.PackedTrajectory(NX, NU, *host_in[b]).to(dev) for b in range(NBUF)]
+    Z = Zs[0]
     Js = [RD.alloc_jacobians(dmodel, N, Z.data) for _ in range(NBUF)]
     Ys = [torch.empty((N, NX), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     sig, diff = RD.StaticReturn(), RD.ForwardAD()
@@ -376,7 +387,8 @@ def main():
     bctx = L.Context(local_rank)
     if not args.no_overlap:
         bctx.set_overlap(True)
-    calls = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Z, ctx=bctx) for b in range(NBUF)]
+    calls = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Zs[b], ctx=bctx) for b in range(NBUF)]
+    calls_same_input = [RD.prepare_jacobian(sig, diff, dmodel, Js[b], Ys[b], Z, ctx=bctx) for b in range(NBUF)]      # (rounds 1-3: one input batch for every step)
 
     def step(i):
         calls[i % NBUF]()
@@ -410,19 +422,27 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = _time.perf_counter() - t0
-    # the same K steps on ONE stream (overlap off), as an extra: what the headline was measured as in rounds 1 and 2
-    single = None
-    if not args.no_overlap:
-        bctx.set_overlap(False)
+    kernel_name = L.last_kernel_name()                  # the kernel the library dispatched the timed calls to (rdhip_last_kernel_name), not a literal
+    # The same K steps on ONE stream (overlap off): back-to-back launches of the dominant kernel ALONE on the chip.  HIP events around them / K =
+    # the kernel's average launch duration (plus the ~1 us gap between launches of one stream) -- this is what `roofline` describes and what the
+    # per-kernel average of a rocprofv3 --kernel-trace of `bench.py --no-overlap` agrees with.
+    def timed_single(fns, nsteps):
         for i in range(min(args.warmup, 200)):
-            step(i)
+            fns[i % NBUF]()
         bctx.synchronize()
         bctx.timer_start()
-        for i in range(args.steps):
-            step(i)
-        s_ms = bctx.timer_stop() / args.steps
-        single = {"kernel_ms": s_ms, "frac_of_hbm_peak": N * BYTES_PER_KNOT / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "launch overlap off: every launch on the context's one stream"}
+        for i in range(nsteps):
+            fns[i % NBUF]()
+        return bctx.timer_stop() / nsteps
+    if not args.no_overlap:
+        bctx.set_overlap(False)
+        s_ms = timed_single(calls, args.steps)
+    else:
+        s_ms = kern_ms
+    same_ms = timed_single(calls_same_input, max(200, args.steps // 4))     # one input batch for every step: does rotating the 11 MB of inputs move the time?
+    if not args.no_overlap:
         bctx.set_overlap(True)
+    single = {"kernel_ms": s_ms, "frac_of_hbm_peak": N * BYTES_PER_KNOT / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "launch overlap off: every launch on the context's one stream"}
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -430,13 +450,16 @@ def main():
     elapsed = float(el.item())
     value = world * N * args.steps / elapsed
 
-    achieved = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9
+    achieved = N * BYTES_PER_KNOT / (s_ms * 1e-3) / 1e9                 # the kernel alone (single stream)
+    achieved_ov = N * BYTES_PER_KNOT / (kern_ms * 1e-3) / 1e9            # job-level: consecutive launches overlapped on the context's two streams
     traffic = tsrc = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived HBM bytes per launch, measured in a separate rocprofv3 run
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             traffic = tj.get("bytes_per_launch")
+            if N != N_PER_GPU or (tj.get("kernel") and tj.get("kernel") != kernel_name):
+                traffic = None                         # the committed counters belong to another kernel / size: say nothing rather than something stale
             try:
                 commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles/hbm_traffic.json"], capture_output=True, text=True, timeout=10).stdout.strip()
             except Exception:
@@ -451,18 +474,22 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Satellite RigidBody{QuatRotation} (n=13,m=6) RK4 discrete dynamics + ForwardAD Jacobian (BASELINE configs[2])",
                    "knot_points_per_gpu": N, "knot_points_total": world * N, "dt": 0.1, "outputs": "J 13x19 + x_next per knot point",
-                   "output_buffers_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective",
+                   "output_buffers_rotated": NBUF, "input_batches_rotated": NBUF, "sharding": f"{world} x contiguous knot-point blocks, no data-path collective",
                    "launch_overlap": (not args.no_overlap), "context": "one rdhip context that owns its stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": tsrc,
-                     "kernel": "rd::jac_ad_split_kernel<Fun<RigidBody<double,SATELLITE,world,diagJ>,RK4>,double,TablePlanS<19,4,1,10,...>,4>",
-                     "kernel_source": "the kernel rdhip_jacobian dispatches to for this configuration (csrc/dispatch.hpp launch_jacobian); name as in profiles/r03/kernel_stats.csv",
-                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT,
-                     "kernel_ms_is": ("time per launch of the job, HIP events around the timed region on the streams the launches go to.  With launch overlap on, consecutive launches "
-                                      "run on two streams and overlap in time: the rocprofv3 trace of this command shows it as the start-to-start interval of consecutive launches "
-                                      "(profiles/r03/summary.json: dominant_kernel.overlap_trace), while a launch's own DURATION (kernel_stats.csv) is longer because two launches share "
-                                      "the chip.  single_stream.kernel_ms is the same measurement with overlap off and agrees with the per-kernel average of "
-                                      "profiles/r03/kernel_stats_single_stream.csv") if not args.no_overlap else "time per launch, HIP events around the timed region (one stream)"},
+                     "kernel": kernel_name, "kernel_source": "rdhip_last_kernel_name() after the timed region: the kernel the library dispatched these calls to",
+                     "kernel_ms": s_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT,
+                     "kernel_ms_is": "average launch duration of the dominant kernel ALONE on the chip: HIP events (rdhip_timer_*, on the context's stream) around K back-to-back "
+                                     "launches on ONE stream, / K; agrees with the per-kernel average of the rocprofv3 --kernel-trace of `bench.py --no-overlap` "
+                                     "(profiles/r04/kernel_stats_single_stream.csv)",
+                     "inputs": {"distinct_input_batches": NBUF, "kernel_ms_one_input_batch": same_ms,
+                                "note": "steps rotate over NBUF separate Z/t/dt arrays (different seeds) as well as NBUF outputs; kernel_ms_one_input_batch = the same "
+                                        "measurement with every step reading batch 0 (rounds 1-3)"},
+                     "overlapped": {"ms_per_launch_overlapped": kern_ms, "achieved": achieved_ov, "frac": achieved_ov / HBM_PEAK_GBS, "launch_overlap": (not args.no_overlap),
+                                    "is": "job-level throughput of the timed region that `value` comes from: with rdhip_ctx_set_overlap(1) consecutive launches alternate between the "
+                                          "context's two streams and overlap in time (two launches share the chip; each one's own duration is LONGER than kernel_ms), so this is "
+                                          "time per launch of the job, not a kernel duration"}},
     }
     if single:
         line["single_stream"] = single

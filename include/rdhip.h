@@ -96,6 +96,10 @@ int rdhip_ctx_fence(rdhip_ctx* ctx);
 void* rdhip_ctx_stream(rdhip_ctx* ctx);
 /* message of the last failure on this context (ctx == NULL: last failure of a context-less call on this thread) */
 const char* rdhip_last_error(rdhip_ctx* ctx);
+/* Name (demangled, NUL-terminated, truncated to `capacity`) of the kernel the CALLING HOST THREAD launched last through the library: which
+ * specialisation a call such as jacobian!(sig, diff, fun, J, y, z) (src/functionbase.jl:242) was dispatched to -- the reference resolves that by
+ * Julia method dispatch (`@which`); here a benchmark or a test asks instead of assuming (bench.py's roofline.kernel).  Empty before the first launch. */
+int rdhip_last_kernel_name(char* buf, int capacity);
 /* HIP-event stopwatch on the context's stream (for hosts without their own event API) */
 int rdhip_timer_start(rdhip_ctx* ctx);
 int rdhip_timer_stop(rdhip_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
@@ -305,7 +309,11 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * latency chain -- for the RigidBody{QuatRotation} models (satellite, quadrotor), explicit rules, RDHIP_FORWARD_AD, RDHIP_TIME_MAJOR data with
  * 16-byte aligned J and M * n * (n+m) * sizeof(T) a multiple of 16 (M even in fp64, a multiple of 4 in fp32) and at most half as many 64-trajectory
  * groups as the device has compute units; every other combination runs the two launches back to back.  rdhip_ctx_last_rollout_jacobian_launches
- * says which (1 = overlapped).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only. */
+ * says which (1 = overlapped).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
+ * The Jacobian workgroups of the overlapped launch hold their compute unit while they wait for the rollout workgroups of the SAME launch; the
+ * library therefore keeps at most one such launch in flight per device and process (a second one, from any context, is ordered behind the first by
+ * an event edge).  Outside its reach: launches replayed from captured graphs side by side, and other processes sharing the GPU -- do not run two of
+ * those concurrently on one device. */
 int rdhip_rollout_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long K, long long M, int layout,
                            void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace);
 int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
@@ -313,8 +321,9 @@ int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
  * `for p in models: rollout!(sig, dmodel[p], Z[p], x0[p]); jacobian! along it`, src/trajectories.jl:436-441 + src/functionbase.jl:242-257): model p has
  * its own stack (K[p] knots x M[p] trajectories, arrays Z[p], t[p], dt[p], X0[p] or NULL, J[p]; rule[p] its quadrature rule; X0 itself may be NULL).
  * With device pointers every model runs on its own internal stream between one fork and one join on the context's stream: the rollouts' latency
- * chains (a handful of compute units each) run side by side and the Jacobian workgroups share the rest of the chip; results are those of the
- * single-model calls, and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
+ * chains (a handful of compute units each) run side by side and the Jacobian workgroups share the rest of the chip (ONE model of the call -- the one
+ * with the most Jacobian bytes among those that have it -- takes the overlapped single launch of rdhip_rollout_jacobian, the others their two
+ * launches: see there); results are those of the single-model calls, and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
  * the other.  (HIP maps streams onto a few hardware queues -- four by default, GPU_MAX_HW_QUEUES: a process that keeps many other streams busy
  * can find two models of a call on one queue, i.e. running one after the other: measured 281 instead of 160 us for the C5 share.) */
 int rdhip_rollout_jacobian_multi(rdhip_ctx* ctx, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype,

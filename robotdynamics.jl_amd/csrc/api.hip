@@ -2,11 +2,13 @@
 // host<->device staging for RDHIP_HOST calls, and dispatch into the per-family kernel launchers.
 // No compute happens on the CPU here; without a GPU every compute entry point returns RDHIP_ERR_NO_DEVICE.
 #include <cmath>
+#include <cxxabi.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -41,6 +43,7 @@ struct rdhip_ctx {
     unsigned long long* d_progress = nullptr;
     unsigned long long roll_epoch = 0;
     int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
+    bool allow_fused = true;              // rdhip_rollout_jacobian_multi lets ONE model of a call take the fused (spin-waiting) launch
     // Launch overlap (rdhip_ctx_set_overlap): consecutive rdhip_jacobian calls on device arrays alternate between the context's stream and one
     // internal stream, with an event edge only where a call touches memory a call still in flight on the OTHER stream touches; everything else
     // joins first (side_join).  A launch's prologue then runs under its predecessor's tail, which one stream cannot do.
@@ -209,6 +212,18 @@ int rdhip_ctx_synchronize(rdhip_ctx* c) {
 }
 void* rdhip_ctx_stream(rdhip_ctx* c) { if (c && c->device >= 0) (void)side_join(c); return c ? (void*)c->stream : nullptr; }      // (overlap mode: what has been issued so far is ordered on it)
 const char* rdhip_last_error(rdhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int rdhip_last_kernel_name(char* buf, int capacity) {
+    if (!buf || capacity < 1) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_last_kernel_name: no buffer");
+    buf[0] = 0;
+    const LastKernel k = last_kernel();
+    const char* raw = k.host_fn ? hipKernelNameRefByPtr(k.host_fn, nullptr) : k.mod_fn ? hipKernelNameRef(k.mod_fn) : nullptr;
+    if (!raw) { (void)hipGetLastError(); return RDHIP_OK; }     // nothing launched on this thread yet
+    int st = 0;
+    char* dem = abi::__cxa_demangle(raw, nullptr, nullptr, &st);
+    std::snprintf(buf, (size_t)capacity, "%s", (st == 0 && dem) ? dem : raw);
+    std::free(dem);
+    return RDHIP_OK;
+}
 // ---- HIP graphs: record a sequence of device-memory calls once, replay it with one launch (small batches are launch-bound) ----
 struct rdhip_graph { hipGraph_t graph; hipGraphExec_t exec; int device; };
 int rdhip_graph_begin_capture(rdhip_ctx* c) {
@@ -241,6 +256,7 @@ int rdhip_graph_launch(rdhip_ctx* c, rdhip_graph* g) {
     if (c->capturing) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_launch: the context is capturing");
     if (g->device != c->device) return fail(c, RDHIP_ERR_INVALID_ARG, "rdhip_graph_launch: the graph was captured on device %d, the context is on device %d", g->device, c->device);
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = side_join(c); if (rc) return rc; }     // ORDERING RULE (rdhip.h): behind everything issued so far, the internal stream of the overlap mode included
     HIP_TRY(c, hipGraphLaunch(g->exec, c->stream));
     return RDHIP_OK;
 }
@@ -525,6 +541,32 @@ static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, con
         case RDHIP_MODEL_QUADROTOR: return fam_quadrotor_rolljac(d, rule, diff, dtype, a);
         default: return RDHIP_ERR_UNSUPPORTED;
     }
+}
+
+// At most ONE spin-waiting launch in flight per device and process.  The Jacobian workgroups of a fused rollout -> Jacobians launch (fused.hpp) hold
+// their compute unit while they wait for progress words.  ONE such launch cannot deadlock (its producers have the lowest workgroup indices, every
+// XCD places its share of them first, and kernels that do not wait for anybody drain by themselves); TWO in flight can: workgroups are dealt
+// round-robin to the 8 XCDs, each XCD arbitrates between hardware queues on its own, so launch A's consumers can fill one XCD and launch B's
+// another while each launch's remaining producers are queued behind the other's consumers.  So a fused launch is ordered behind the previous
+// fused launch on the device (an event edge when that one went to another stream), and rdhip_rollout_jacobian_multi gives the fused form to one
+// model per call (the others run their two launches, whose workgroups wait for nobody, beside it).  Not covered: launches replayed from captured
+// graphs and other processes on the same GPU (rdhip.h says so).
+static std::mutex g_fused_mu;
+static hipEvent_t g_fused_done[64] = {};
+static hipStream_t g_fused_stream[64] = {};
+static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& f, bool capturing) {
+    std::lock_guard<std::mutex> g(g_fused_mu);
+    const int slot = c->device & 63;
+    if (!capturing) {
+        if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
+        if (g_fused_stream[slot] && g_fused_stream[slot] != f.stream && hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
+    }
+    const int k = family_rolljac(d, rule, diff, dtype, f);
+    if (k == RDHIP_OK && !capturing) {
+        if (hipEventRecord(g_fused_done[slot], f.stream) != hipSuccess) return RDHIP_ERR_HIP;
+        g_fused_stream[slot] = f.stream;
+    }
+    return k;
 }
 
 static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype, LaunchArgs a, int flag_set = 0) {
@@ -983,15 +1025,16 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     LaunchArgs j{}; j.stream = c->stream; j.N = N; j.Z = r.Z; j.t = r.t; j.dt = r.dt; j.J = dJ;
     if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
     c->last_rolljac_launches = 0;
-    if (!implicit) {
+    LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1;
+    if (!implicit && c->allow_fused && family_rolljac(d, rule, diff, dtype, f) == RDHIP_OK) {      // (probe: nothing is launched)
         // ONE launch: rollout workgroups + Jacobian workgroups that consume finished chunks through progress words (fused.hpp)
-        LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS;
+        f.probe = 0;
         const bool capturing = stream_is_capturing(c);
         // a captured launch is replayed with the epoch it was recorded with: its words are cleared by a memset node in front of it instead
         if (capturing) HIP_TRY(c, hipMemsetAsync(c->d_progress, 0, (size_t)PROGRESS_WORDS * sizeof(unsigned long long), c->stream));
         c->roll_epoch = (c->roll_epoch + 1) & 0x7fffffffULL; if (c->roll_epoch == 0) c->roll_epoch = 1;
         f.pbase = c->roll_epoch << 32;
-        const int kf = family_rolljac(d, rule, diff, dtype, f);
+        const int kf = fused_launch(c, d, rule, diff, dtype, f, capturing);
         if (kf != RDHIP_ERR_UNSUPPORTED) { c->last_rolljac_launches = 1; const int k = kernel_status(c, kf, what); return memspace == RDHIP_HOST ? s.finish(k) : k; }
     }
     int k = kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
@@ -1020,21 +1063,38 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         return RDHIP_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = side_join(c); if (rc) return rc; }     // the fork event below must sit behind the overlap mode's internal stream as well (ORDERING RULE, rdhip.h)
     if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     for (int p = 1; p < nmodels; ++p) {
         if (!c->child[p - 1]) { const int rc = rdhip_ctx_create(c->device, nullptr, RDHIP_STREAM_OWN, &c->child[p - 1]); if (rc) return fail(c, rc, "%s: %s", what, rdhip_last_error(nullptr)); }
         if (!c->join_ev[p - 1]) HIP_TRY(c, hipEventCreateWithFlags(&c->join_ev[p - 1], hipEventDisableTiming));
     }
     HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));      // the children start behind the work already queued on this context
+    // ONE model of the call takes the fused (spin-waiting) launch -- the one with the most Jacobian bytes among those that have it; the others run
+    // rollout and Jacobians as two launches on their streams (see fused_launch)
+    int fused_model = -1; double fused_bytes = -1;
+    for (int p = 0; p < nmodels; ++p) {
+        if (!Z[p] || !t[p] || !dt[p] || !J[p] || K[p] <= 0 || Mt[p] <= 0 || rule[p] < RDHIP_EULER || rule[p] > RDHIP_RK4) continue;
+        const ModelDesc& d = models[p]->d;
+        LaunchArgs f{}; f.N = Mt[p]; f.K = K[p]; f.Z = Z[p]; f.t = t[p]; f.dt = dt[p]; f.J = J[p]; f.time_major = (layout == RDHIP_TIME_MAJOR);
+        f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1;
+        const double bytes = (double)K[p] * (double)Mt[p] * d.n * (d.n + d.m);
+        if (family_rolljac(d, rule[p], diff, dtype, f) == RDHIP_OK && bytes > fused_bytes) { fused_model = p; fused_bytes = bytes; }
+    }
     int rc0 = RDHIP_OK;
     for (int p = 1; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes model 0 last
         rdhip_ctx* ch = c->child[p - 1];
         HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
+        ch->allow_fused = (p == fused_model);
         rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
         HIP_TRY(c, hipEventRecord(c->join_ev[p - 1], ch->stream));
     }
-    if (rc0 == RDHIP_OK) rc0 = rdhip_rollout_jacobian(c, models[0], rule[0], diff, dtype, K[0], Mt[0], layout, Z[0], t[0], dt[0], X0 ? X0[0] : nullptr, J[0], memspace);
+    if (rc0 == RDHIP_OK) {
+        c->allow_fused = (fused_model == 0);
+        rc0 = rdhip_rollout_jacobian(c, models[0], rule[0], diff, dtype, K[0], Mt[0], layout, Z[0], t[0], dt[0], X0 ? X0[0] : nullptr, J[0], memspace);
+        c->allow_fused = true;
+    }
     for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results
     return rc0;
 }

@@ -27,6 +27,17 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t lds) {
 }
 
 
+// the kernel the calling host thread launched last through the library (rdhip_last_kernel_name: a benchmark or a test names the kernel a call was
+// dispatched to instead of assuming it); compiled-in kernels by their host stub, hipRTC kernels by their module function
+struct LastKernel { const void* host_fn; hipFunction_t mod_fn; };
+inline LastKernel& last_kernel() { static thread_local LastKernel k{nullptr, nullptr}; return k; }
+#define RD_LAUNCH(kern, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                  \
+        auto rd_kern_ = (kern);                                                                           \
+        rd::last_kernel() = rd::LastKernel{reinterpret_cast<const void*>(rd_kern_), nullptr};             \
+        hipLaunchKernelGGL(rd_kern_, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
+
 // compute units and LDS per compute unit of the current device, from the runtime (a CPX / NPS-partitioned MI355X reports 32 CUs per
 // partition, not 256: the persistent grids are sized from this, never from a constant); cached per device ordinal
 struct DevInfo { int cus; size_t lds_per_cu; };
@@ -146,6 +157,7 @@ struct LaunchArgs {
     unsigned long long* progress;   // fused rollout -> Jacobians: one progress word per 64-trajectory group (context workspace, zero at allocation)
     unsigned long long pbase;       //   (call epoch << 32): words of earlier calls compare below
     int progress_words;             //   capacity of `progress`
+    int probe;                      //   != 0: say whether the fused launch exists for these arguments (RDHIP_OK / RDHIP_ERR_UNSUPPORTED) without launching it
     const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
                               // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED BEFORE launching anything and the caller
                               // loops over the batches

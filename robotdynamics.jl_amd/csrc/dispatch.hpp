@@ -32,7 +32,7 @@ template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
     if (a.N == 0) return RDHIP_OK;
     const unsigned grid = (unsigned)((a.N + 255) / 256);
-    hipLaunchKernelGGL((eval_kernel<Fn, T>), dim3(grid), dim3(256), 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y);
+    RD_LAUNCH((eval_kernel<Fn, T>), dim3(grid), dim3(256), 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
 template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
@@ -59,7 +59,7 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
                 if constexpr (L::UNITS && ZB >= 128) {
                     auto ks = rollout_stream_kernel<Fn, T, true, V4>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
-                    hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                    RD_LAUNCH(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
                     return hip_status(hipGetLastError());
                 }
             } else if (al) {
@@ -67,12 +67,12 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
                 if constexpr (L::UNITS && ZB >= 128) {
                     auto ks = rollout_stream_kernel<Fn, T, false, V4>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(ks), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
-                    hipLaunchKernelGGL(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                    RD_LAUNCH(ks, dim3(grid), dim3(STREAM_THREADS), L::BYTES, a.stream, fn, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
                     return hip_status(hipGetLastError());
                 }
             }
             if (!forced) {
-                hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                RD_LAUNCH((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
                 return hip_status(hipGetLastError());
             }
         }
@@ -94,8 +94,8 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
                         constexpr size_t ldsf = FusedLds<Fn, T, Cas, R, Plan, 4>::BYTES;
                         auto kf = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, 4>;
                         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), ldsf) != hipSuccess) return RDHIP_ERR_HIP;
-                        hipLaunchKernelGGL(kf, dim3(grid), dim3(FUSED_THREADS), ldsf, a.stream, fn, a.K, a.N, (int)grid, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0,
-                                           (T*)nullptr, (unsigned long long*)nullptr, 0ULL);
+                        RD_LAUNCH(kf, dim3(grid), dim3(FUSED_THREADS), ldsf, a.stream, fn, a.K, a.N, (int)grid, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0,
+                                           (T*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL);
                         return hip_status(hipGetLastError());
                     }
                 }
@@ -103,11 +103,11 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
             constexpr size_t lds = CascadeLds<Fn, Cas, R>::BYTES;
             auto kern = rollout_cascade_kernel<Fn, T, Cas, R>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3((Cas::NB + 1) * TILE), lds, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+            RD_LAUNCH(kern, dim3(grid), dim3((Cas::NB + 1) * TILE), lds, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
             return hip_status(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+    RD_LAUNCH((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }
 // (tile_grid: common.hpp -- persistent grids are sized from the device's reported CU count and LDS size)
@@ -118,7 +118,7 @@ template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, Plan::NG * TILE, ntiles)), dim3(Plan::NG * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
 
@@ -129,7 +129,7 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
 
@@ -141,7 +141,7 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J);
+    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J);
     return hip_status(hipGetLastError());
 }
 
@@ -159,7 +159,7 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
     auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
     return hip_status(hipGetLastError());
 }
 template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {
@@ -167,7 +167,7 @@ template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
     auto kern = jac_tile_multi_kernel<Fn, T, Plan, Body>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
     return hip_status(hipGetLastError());
 }
 // several packed trajectories, one launch: the same kernel choice as launch_jacobian below, every body on a MultiBatch
@@ -187,7 +187,7 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
             auto kern = jac_ad_small_multi_kernel<Fn, T>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             constexpr int W = SmallLds<Fn, T>::WAVES;
-            hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+            RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
@@ -237,7 +237,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
             const long long ntiles = (a.N + TILE - 1) / TILE;
             constexpr int W = SmallLds<Fn, T>::WAVES;
-            hipLaunchKernelGGL(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+            RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
             return hip_status(hipGetLastError());
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
@@ -254,7 +254,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
                     constexpr size_t lds = ColSplitLds<Fn, T>::BYTES;
                     auto kern = jac_ad_colsplit_kernel<Fn, T, Plan>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-                    hipLaunchKernelGGL(kern, dim3((unsigned)(32 * ((ntiles + 7) / 8))), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+                    RD_LAUNCH(kern, dim3((unsigned)(32 * ((ntiles + 7) / 8))), dim3(4 * TILE), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
                     return hip_status(hipGetLastError());
                 }
             }
@@ -317,20 +317,35 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             const long long cus = dev_info().cus;
             // the rollout workgroups must leave most of the chip to the Jacobians (and all of them must be resident together with consumers)
             if (G > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
+            if (a.probe) return RDHIP_OK;
+            // Two-phase split (fused.hpp): the rollout workgroups produce G tiles per step, the nj Jacobian workgroups consume nj tiles per tile time;
+            // while the rollout runs, the consumers get through  A = nj (K - 1) step / tile_time  tiles.  If that is (nearly) everything the
+            // consumers keep up and there is no second phase; otherwise the tiles behind A are shared by ALL workgroups, the former rollout
+            // workgroups included.  tile_time / step, measured (tune/tune_c5.hip, satellite RK4): 3.4 us / 0.47 us in fp32, 6.9 / 0.62 in fp64.
+            auto split_of = [&](long long ntiles, long long nj) -> long long {
+                double ratio = sizeof(T) == 4 ? 7.2 : 11.0 * 4.0 / rule_stages<RULE>();
+                if (const char* e = getenv("RDHIP_FUSED_RATIO")) { const double v = atof(e); if (v > 0) ratio = v; }      // tuning switch
+                const double A = (double)nj * (double)(K - 1) / ratio;
+                if (G < 8 || A >= 0.85 * (double)ntiles) return 0;
+                long long sp = (long long)A; sp -= sp % G;
+                return sp < G ? 0 : sp;
+            };
             if (a.time_major) {
                 auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC, true>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 const long long ntiles = K * G;
                 long long nj = cus - G; if (nj > ntiles) nj = ntiles;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
-                                   a.progress, a.pbase);
+                if (const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS")) { const long long v = atoll(e); if (v >= 1 && v < nj) nj = v; }     // test / tuning switch: fewer Jacobian workgroups
+                RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                   a.progress, a.pbase, split_of(ntiles, nj));
             } else {
                 auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC, false>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 const long long ntiles = ((K + GATHER_RUN - 1) / GATHER_RUN) * ((M + GATHER_NRUN - 1) / GATHER_NRUN);
                 long long nj = cus - G; if (nj > ntiles) nj = ntiles;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, K, 1LL, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
-                                   a.progress, a.pbase);
+                if (const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS")) { const long long v = atoll(e); if (v >= 1 && v < nj) nj = v; }
+                RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, K, 1LL, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                   a.progress, a.pbase, split_of(ntiles, nj));
             }
             return hip_status(hipGetLastError());
         }
@@ -415,7 +430,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     if (a.N == 0) return RDHIP_OK;
     const unsigned grid = (unsigned)((a.N + TILE - 1) / TILE);
     if (mode == 2) {
-        hipLaunchKernelGGL((implicit_midpoint_error_kernel<Mdl, T>), dim3(grid), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J2, (T*)a.J);
+        RD_LAUNCH((implicit_midpoint_error_kernel<Mdl, T>), dim3(grid), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J2, (T*)a.J);
         return hip_status(hipGetLastError());
     }
     constexpr size_t lds = ImplicitLds<Mdl, T>::BYTES;
@@ -445,18 +460,18 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 auto kr = rollout_cascade_kernel<RFn, T, Cas, 4>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kr), ldsr) != hipSuccess) return RDHIP_ERR_HIP;
                 const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
-                hipLaunchKernelGGL(kr, dim3(gridr), dim3((Cas::NB + 1) * TILE), ldsr, a.stream, RFn{m, a.newton_iters, a.newton_tol, a.flag}, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                RD_LAUNCH(kr, dim3(gridr), dim3((Cas::NB + 1) * TILE), ldsr, a.stream, RFn{m, a.newton_iters, a.newton_tol, a.flag}, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
                 auto kern = implicit_rollout_kernel<Mdl, T>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-                hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
+                RD_LAUNCH(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
                 return hip_status(hipGetLastError());
             }
         }
-        if (a.flag) hipLaunchKernelGGL((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
+        if (a.flag) RD_LAUNCH((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_rollout_kernel<Mdl, T>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
+        RD_LAUNCH(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
         return hip_status(hipGetLastError());
     }
     if (mode == 1) {
@@ -472,7 +487,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 // tiles that need the exact solve are redone by their own workgroup behind the loop (implicit.hpp IftBody)
                 if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && !(ift_mode && ift_mode[0] == '3'))
                     return launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, a.flag, a.newton_iters, IftBody<IFn, T, IPlan>::HELPER ? 2 : 1, nullptr}, a);
-                hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
+                RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
                 LaunchArgs b = a;
                 b.Y = nullptr;
                 // (the tile kernel reads x_next from a.Y; its flag words are per tile, which the gated kernel behind it scans when word 0 carries this call's epoch)
@@ -480,21 +495,21 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 if (rc) return rc;
                 auto kern = implicit_midpoint_kernel<Mdl, T, true>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-                hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags & 1);
+                RD_LAUNCH(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags & 1);
                 return hip_status(hipGetLastError());
             }
         }
-        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
+        if (a.flag) RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
+        RD_LAUNCH(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
     } else {
-        if (a.flag) hipLaunchKernelGGL((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
+        if (a.flag) RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
         auto kern = implicit_midpoint_kernel<Mdl, T, false>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, gate, tile_flags);
+        RD_LAUNCH(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, gate, tile_flags);
     }
     return hip_status(hipGetLastError());
 }

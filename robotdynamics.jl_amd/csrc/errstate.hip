@@ -307,9 +307,9 @@ static inline unsigned nblk(long long work) { return (unsigned)((work + 255) / 2
 template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G) {
     if (N == 0) return RDHIP_OK;
     if (d.nrot == 0) {   // EuclideanState: G = I (always cleared, src/statevectortype.jl:149-155)
-        hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d.n, d.e, N, (T*)G, 1);
+        RD_LAUNCH((fill_identity_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d.n, d.e, N, (T*)G, 1);
     } else if (d.rot != RDHIP_ROT_QUAT) {
-        hipLaunchKernelGGL((errstate3_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, clear, (T*)G);
+        RD_LAUNCH((errstate3_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, clear, (T*)G);
     } else if (clear) {
         // 32 knot points per tile (40 KB for a rigid body: four workgroups per CU; 64-knot tiles, two per CU, ran 3 % slower; 16-knot tiles 1.5 %)
         constexpr int TK = 32;
@@ -317,13 +317,13 @@ template <class T> static int errstate_T(const LieDesc& d, hipStream_t s, long l
         if (lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
             auto kern = errstate_tile_kernel<T, 0, TK>;
             if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 80 * 1024) != hipSuccess) return RDHIP_ERR_HIP;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)nullptr, 0, (T*)G);
+            RD_LAUNCH(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)nullptr, 0, (T*)G);
         } else {
-            hipLaunchKernelGGL((errstate_clear_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
+            RD_LAUNCH((errstate_clear_kernel<T>), dim3(nblk(N * d.n * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
         }
     } else {
         const long long per = (d.n - 4 * d.nrot) + 12 * d.nrot;
-        hipLaunchKernelGGL((errstate_pattern_kernel<T>), dim3(nblk(N * per)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
+        RD_LAUNCH((errstate_pattern_kernel<T>), dim3(nblk(N * per)), dim3(256), 0, s, d, N, (const T*)X, ldx, (T*)G);
     }
     return st(hipGetLastError());
 }
@@ -408,14 +408,14 @@ template <class T> static int sdiff_T(const LieDesc& d, hipStream_t s, long long
     if (N == 0) return RDHIP_OK;
     const size_t lds = (size_t)128 * (ldx + ldx0 + (d.e | 1)) * sizeof(T);
     if (ldx <= 16 && ldx0 <= 16 && lds <= 64 * 1024) {
-        hipLaunchKernelGGL((state_diff_tile_kernel<T, 16>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        RD_LAUNCH((state_diff_tile_kernel<T, 16>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
         return st(hipGetLastError());
     }
     if (ldx <= 32 && ldx0 <= 32 && lds <= 64 * 1024) {
-        hipLaunchKernelGGL((state_diff_tile_kernel<T, 32>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        RD_LAUNCH((state_diff_tile_kernel<T, 32>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
         return st(hipGetLastError());
     }
-    hipLaunchKernelGGL((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+    RD_LAUNCH((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
     return st(hipGetLastError());
 }
 int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX) {
@@ -424,7 +424,7 @@ int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, c
 template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H) {
     if (N == 0) return RDHIP_OK;
     if (d.nrot == 0) {   // EuclideanState: nablaG .= 0 (src/statevectortype.jl:147)
-        hipLaunchKernelGGL((fill_identity_kernel<T>), dim3(nblk(N * d.e * d.e)), dim3(256), 0, s, d.e, d.e, N, (T*)H, 0);
+        RD_LAUNCH((fill_identity_kernel<T>), dim3(nblk(N * d.e * d.e)), dim3(256), 0, s, d.e, d.e, N, (T*)H, 0);
         return st(hipGetLastError());
     }
     constexpr int TK = 64;
@@ -432,11 +432,11 @@ template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long
     if (clear && lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
         auto kern = errstate_tile_kernel<T, 1, TK>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 80 * 1024) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, (T*)H);
+        RD_LAUNCH(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, (T*)H);
         return st(hipGetLastError());
     }
     const long long per = clear ? (long long)d.e * d.e : 9LL * d.nrot;
-    hipLaunchKernelGGL((nabla_errstate_kernel<T>), dim3(nblk(N * per)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, clear, (T*)H);
+    RD_LAUNCH((nabla_errstate_kernel<T>), dim3(nblk(N * per)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, clear, (T*)H);
     return st(hipGetLastError());
 }
 int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H) {
@@ -446,20 +446,20 @@ int launch_nabla_errstate(const LieDesc& d, int dtype, hipStream_t s, long long 
 int launch_project_errexp(const LieDesc& d, int dtype, hipStream_t s, long long pairs, int m, const void* Z, const void* J, void* E) {
     if (pairs <= 0) return RDHIP_OK;
     const long long work = pairs * d.e * (d.e + m);
-    if (dtype == RDHIP_F64) hipLaunchKernelGGL((project_errexp_kernel<double>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const double*)Z, (const double*)J, (double*)E);
-    else hipLaunchKernelGGL((project_errexp_kernel<float>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const float*)Z, (const float*)J, (float*)E);
+    if (dtype == RDHIP_F64) RD_LAUNCH((project_errexp_kernel<double>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const double*)Z, (const double*)J, (double*)E);
+    else RD_LAUNCH((project_errexp_kernel<float>), dim3(nblk(work)), dim3(256), 0, s, d, pairs, m, (const float*)Z, (const float*)J, (float*)E);
     return st(hipGetLastError());
 }
 int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E) {
     if (pairs <= 0) return RDHIP_OK;
-    if (dtype == RDHIP_F64) hipLaunchKernelGGL((sub_next_state_kernel<double>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const double*)Z, (double*)E);
-    else hipLaunchKernelGGL((sub_next_state_kernel<float>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const float*)Z, (float*)E);
+    if (dtype == RDHIP_F64) RD_LAUNCH((sub_next_state_kernel<double>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const double*)Z, (double*)E);
+    else RD_LAUNCH((sub_next_state_kernel<float>), dim3(nblk(pairs * n)), dim3(256), 0, s, pairs, n, nz, (const float*)Z, (float*)E);
     return st(hipGetLastError());
 }
 int launch_fill_neg_identity(int dtype, hipStream_t s, long long pairs, int n, int nz, void* J2) {
     if (pairs <= 0) return RDHIP_OK;
-    if (dtype == RDHIP_F64) hipLaunchKernelGGL((fill_neg_identity_kernel<double>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (double*)J2);
-    else hipLaunchKernelGGL((fill_neg_identity_kernel<float>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (float*)J2);
+    if (dtype == RDHIP_F64) RD_LAUNCH((fill_neg_identity_kernel<double>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (double*)J2);
+    else RD_LAUNCH((fill_neg_identity_kernel<float>), dim3(nblk(pairs * n * nz)), dim3(256), 0, s, pairs, n, nz, (float*)J2);
     return st(hipGetLastError());
 }
 

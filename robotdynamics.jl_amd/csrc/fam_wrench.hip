@@ -80,10 +80,10 @@ template <class Fn, class T> static int launch_wrench(const Fn& fn, const Launch
         constexpr size_t lds = (size_t)TILE * ((6 * NZ) | 1) * sizeof(T);
         auto kern = wrench_kernel<Fn, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TILE), lds, a.stream, fn, a.N, (const T*)a.Z, (T*)a.J);
+        RD_LAUNCH(kern, dim3(grid), dim3(TILE), lds, a.stream, fn, a.N, (const T*)a.Z, (T*)a.J);
     } else {
         constexpr size_t lds = (size_t)TILE * 7 * sizeof(T);
-        hipLaunchKernelGGL((wrench_kernel<Fn, T, false>), dim3(grid), dim3(TILE), lds, a.stream, fn, a.N, (const T*)a.Z, (T*)a.Y);
+        RD_LAUNCH((wrench_kernel<Fn, T, false>), dim3(grid), dim3(TILE), lds, a.stream, fn, a.N, (const T*)a.Z, (T*)a.Y);
     }
     return hipGetLastError() == hipSuccess ? RDHIP_OK : RDHIP_ERR_HIP;
 }

@@ -12,8 +12,9 @@
 //                            which they become available -- with time-major data tile (k, g) is knot k of group g's 64 trajectories, one
 //                            contiguous slab -- whose compute waves poll the producer's progress word before they request a tile's inputs.
 //
-// Producers never wait for consumers and lower workgroup indices are dispatched first, so the launch cannot deadlock however many workgroups are
-// resident.  The Jacobian store stream then runs UNDER the rollout chain, a few steps behind it, and what is left after the last step is the tail
+// Producers never wait for consumers and lower workgroup indices are dispatched first, so ONE such launch cannot deadlock however many workgroups
+// are resident; two of them in flight on one device could (each one's consumers holding the compute units the other's producers are queued for),
+// which is why the library keeps at most one in flight per device (api.hip fused_launch).  The Jacobian store stream then runs UNDER the rollout chain, a few steps behind it, and what is left after the last step is the tail
 // of one chunk.  Results are bit-identical to rdhip_rollout followed by rdhip_jacobian: the same rollout waves, the same column code.
 #pragma once
 #include "cascade.hpp"
@@ -34,12 +35,18 @@ template <class T> struct RolloutTilesTM {
         return TileRef<T>{Z, t, dt, J, nullptr, end, k0};       // (nk = end - k0; slabs are addressed by the flat knot index k0)
     }
     // every wave that is about to request the tile's inputs polls the word itself (a scalar-uniform load; words of earlier calls carry a smaller
-    // epoch and compare below).  The consumer has never touched these lines before, and the producer's stores were written through before the
-    // word was: no cache invalidation is needed on this side.
+    // epoch and compare below).  The producer's stores were written through before the word was.  On this side the tile's STATES are then read
+    // with agent-scope loads that bypass the non-coherent caches (jac_split_loop: descriptors with WAITS): when tile slabs are not multiples of
+    // 128 bytes (M not a multiple of 64; K (n+m) sizeof(T) not a multiple of 128 for trajectory-major stacks) this CU may already hold the line
+    // that two neighbouring tiles share, read for the earlier tile BEFORE the later one's part was produced.  (An agent-scope acquire FENCE
+    // here instead -- buffer_inv sc1 per tile and wave -- invalidates far more than that line: measured 575 instead of 294 us for 4 096 x 256
+    // fp32 knots, the rollout workgroups themselves twice as slow.)  The compiler barrier keeps the tile's loads behind the poll; the hardware
+    // issues a wave's loads in order and the poll's value has arrived before the branch on it is taken.
     RD_DEV void wait(long long item) const {
         const long long k = item / G; const long long g = item - k * G;
         const unsigned long long need = pbase | (unsigned long long)(k + 1);
         while (__hip_atomic_load(progress + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+        asm volatile("" ::: "memory");
     }
 };
 
@@ -67,6 +74,7 @@ template <class T> struct RolloutTilesTJ {
         const long long last = (c + 1) * GATHER_RUN < K ? (c + 1) * GATHER_RUN : K;            // knots 0 .. last - 1 are needed
         const unsigned long long need = pbase | (unsigned long long)last;
         while (__hip_atomic_load(progress + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+        asm volatile("" ::: "memory");
     }
 };
 
@@ -79,10 +87,15 @@ template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedL
 // (sj, sk): strides of the rollout's data, (K, 1) = the knots of a trajectory contiguous, (1, M) = time-major.  The SAME kernel serves rdhip_rollout
 // for these models (grid = G, no Jacobian workgroups, any strides): "rollout, then Jacobians" in two calls and in one are the same machine code
 // and give the same bits.  TM: the Jacobian workgroups' tiles are time-major slabs (RolloutTilesTM) or gathered from a trajectory-major stack (RolloutTilesTJ).
+// `split` (0 = none): the Jacobian workgroups first share the tiles [0, split) -- what the rollout produces while its workgroups are busy -- and then
+// EVERY workgroup of the grid, the former rollout workgroups included, shares [split, ntiles).  A big Monte-Carlo batch (BASELINE config 5 on one
+// GPU: 64 rollout groups on a quarter of the chip) produces tiles twice as fast as the other three quarters consume them; without the second
+// phase the quarter that rolled out idles for the second half of the launch (measured: 295 us for 4 096 x 256 fp32 satellite knots, the rollout
+// workgroups done at 120-135 us).  The host picks `split` from the ratio of the two rates (dispatch.hpp).
 template <class Fn, class T, class Cas, int R, class Plan, int NC, bool TM = true>
 __global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
                                                                             const double* __restrict__ tt, const double* __restrict__ dtt, const T* __restrict__ X0,
-                                                                            T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase) {
+                                                                            T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase, long long split) {
     if ((int)blockIdx.x < G) {
         // ---- rollout of trajectories 64 blockIdx.x ..: the waves of rollout_cascade_kernel, publishing (progress == nullptr: nobody listens) ----
         using L = CascadeLds<Fn, Cas, R>;
@@ -93,18 +106,45 @@ __global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn 
         const int nfull = (whole && K >= 2) ? (int)((K - 1) / L::S) : 0;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         unsigned long long* pword = progress ? progress + blockIdx.x : nullptr;
+#if defined(RD_FUSED_STAMP)   // tuning only (tune/tune_c5.hip): start / end of every workgroup's role, 100 MHz wall clock, in the unused upper progress words
+        if (threadIdx.x == 0 && progress) progress[2048 + blockIdx.x] = wall_clock64();
+#endif
         if (wave <= Cas::NB) CascadeWaves<Fn, T, Cas, R, 0, true>::run(wave, fn, K, M, sj, sk, Z, tt, dtt, X0, nfull, pword, pbase);
         __syncthreads();                                   // every wave has seen its own stores acknowledged
         if (threadIdx.x == 0) pub_progress(pword, pbase, K);
-        return;
+#if defined(RD_FUSED_STAMP)
+        if (threadIdx.x == 0 && progress) progress[1024 + blockIdx.x] = wall_clock64();
+#endif
+        if (split <= 0 || !J) return;
+        // second phase: this workgroup joins the Jacobian workgroups on the tiles behind `split` (every trajectory is complete by the time ANY rollout
+        // workgroup gets here only for its own group: the tiles' progress words are still polled)
+        __syncthreads();
     }
-    if constexpr (TM) {
-        const RolloutTilesTM<T> rt{K, M, G, Z, tt, dtt, J, progress, pbase};
-        jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
-    } else {
-        const RolloutTilesTJ<T> rt{K, M, (int)((M + GATHER_NRUN - 1) / GATHER_NRUN), Z, tt, dtt, J, progress, pbase};
-        jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, blockIdx.x - G, gridDim.x - G);
+#if defined(RD_FUSED_STAMP)
+    if (threadIdx.x == 0 && progress) progress[2048 + blockIdx.x] = wall_clock64();
+#endif
+    const bool producer = (int)blockIdx.x < G;
+    // ONE call site for the tile loop (its unrolled column code is ~30 KB of instructions: a second inlined copy would not fit the instruction cache
+    // next to the first -- measured: the whole launch 2x slower), walked once or twice
+    const int first_phase = (split > 0 && producer) ? 1 : 0, last_phase = split > 0 ? 1 : 0;
+#pragma clang loop unroll(disable)
+    for (int phase = first_phase; phase <= last_phase; ++phase) {
+        // phase 0: the Jacobian workgroups on [0, split) (or on everything); phase 1: every workgroup on [split, ntiles), the former rollout
+        // workgroups with the lowest indices (they arrive first)
+        const unsigned wg = phase == 0 ? blockIdx.x - G : blockIdx.x, nwg = phase == 0 ? gridDim.x - G : gridDim.x;
+        const long long tb = phase == 0 ? 0 : split, te = (phase == 0 && split > 0) ? split : -1;
+        if (phase > first_phase) __syncthreads();          // (the loop's waves leave it at different times: the LDS tile is reused)
+        if constexpr (TM) {
+            const RolloutTilesTM<T> rt{K, M, G, Z, tt, dtt, J, progress, pbase};
+            jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, wg, nwg, tb, te);
+        } else {
+            const RolloutTilesTJ<T> rt{K, M, (int)((M + GATHER_NRUN - 1) / GATHER_NRUN), Z, tt, dtt, J, progress, pbase};
+            jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, rt, wg, nwg, tb, te);
+        }
     }
+#if defined(RD_FUSED_STAMP)
+    if (threadIdx.x == 0 && progress) progress[(producer ? 3072 : 1024) + blockIdx.x] = wall_clock64();
+#endif
 }
 
 }  // namespace rd

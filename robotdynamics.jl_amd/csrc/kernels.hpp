@@ -566,7 +566,9 @@ __global__ void col_probe_kernel(Fn fn, const T* __restrict__ Z, T* __restrict__
 // copy is a linear 16-byte sweep over the tile, which is one contiguous slab of global memory).
 // tile stores are streaming (written once, never re-read by this kernel): the non-temporal hint measured 3-5 % faster
 // than plain stores on MI355X (less dirty data left in L2 for the end-of-kernel write-back); -DRD_PLAIN_STORES reverts
-#if defined(RD_PLAIN_STORES)
+#if defined(RD_ABLATE) && RD_ABLATE == 3      // tuning only: no tile stores (what does the arithmetic alone cost?)
+#define RD_TILE_STORE(p, v) do { if (lane == 99) *(p) = (v); } while (0)
+#elif defined(RD_PLAIN_STORES)
 #define RD_TILE_STORE(p, v) (*(p) = (v))
 #else
 #define RD_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
@@ -603,9 +605,18 @@ template <class T> RD_DEV TileRef<T> ring_get(const long long* slot) {
 // workgroups of the same launch: the fused rollout -> Jacobians kernel, fused.hpp)
 template <class BT, class = void> struct WaitsOf { static constexpr bool value = false; };
 template <class BT> struct WaitsOf<BT, decltype((void)BT::WAITS)> { static constexpr bool value = BT::WAITS; };
+// tile inputs of a descriptor with WAITS were written by other workgroups of the SAME launch (possibly on another XCD, i.e. behind another L2): they
+// are read with agent-scope loads, which bypass the non-coherent caches -- a plain load could be served from a line this compute unit cached
+// while it read a neighbouring tile, before this tile's part of the line was produced (tiles that do not start on 128-byte lines)
+template <bool COHERENT, class T> RD_DEV T tile_load(const T* p) {
+    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
 // wg / nwg: this workgroup's index among the nwg workgroups that share the tiles (the whole grid unless the launch has other roles as well)
+// [t_begin, t_end): the part of the descriptor's tiles this call walks (t_end < 0: all of them) -- the fused rollout -> Jacobians kernel runs the loop
+// twice, over the tiles produced while the rollout workgroups were busy and over the rest, which those workgroups then share (fused.hpp)
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
-RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg) {
+RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg, long long t_begin = 0, long long t_end = -1) {
     // per batch: N = knot points that produce output; inputs of N + Fn::NEXT knot points are read (a body with NEXT = 1 also sees x_{k+1})
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
     constexpr int NA = AuxOf<Fn>::N;
@@ -638,9 +649,14 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     constexpr bool HELPER = HelperOf<Body>::value;
     constexpr int NCC = HELPER ? NC - 1 : NC;                // copy waves that copy
     constexpr int JPLc = (L::JU + NCC * TILE - 1) / (NCC * TILE), YPLc = (L::YU + NCC * TILE - 1) / (NCC * TILE);
+    // NPASS = 2 (two copy waves, fp32): the copy waves take the tile out of LDS in two halves -- the first half's stores are issued in front of
+    // barrier B, the second half's behind it -- and hold half a tile in registers at a time: 64 data registers instead of 128, which is what lets
+    // a six-wave workgroup stay under the 168 registers of three waves per SIMD, i.e. TWO workgroups per compute unit (see UnrollPolicy / F32_NC)
+    constexpr int NPASS = (sizeof(T) == 4 && NCC == 2 && !GATHER) ? 2 : 1;
+    constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long ntiles = bt.ntiles();
+    const long long ntiles = (t_end >= 0 && t_end < bt.ntiles()) ? t_end : bt.ntiles();
     // tile schedule of this workgroup: tile, tile + tstep, ... < tend.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  For long
     // launches (>= 64 tiles per workgroup, i.e. from ~1 M knot points on a whole chip) every XCD walks its OWN contiguous eighth of the tiles,
     // strided over its workgroups: each XCD's L2 and address-translation caches then see one sequential stream instead of every 8th slab of a
@@ -658,7 +674,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         const long long ntx = (ntiles + 7) / 8, xcd = wg & 7;
         tile = xcd * ntx + (wg >> 3);
         tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
-    } else { tile = wg; tend = ntiles; tstep = nwg; }
+    } else { tile = t_begin + wg; tend = ntiles; tstep = nwg; }
     if (tile >= tend) return;
     const long long tile0 = tile;
 
@@ -690,12 +706,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             T z0[ZPT]; double t0;
             if constexpr (GATHER) {
 #pragma unroll
-                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[gather_z(cur, e < TILE * NZ ? e : 0)]; }
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<WaitsOf<BT>::value>(Z + gather_z(cur, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 t0 = tp[gather_knot(cur, threadIdx.x & (TILE - 1))];
             } else {
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = Z[(e < nin * NZ) ? k0 * NZ + e : 0]; }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<WaitsOf<BT>::value>(Z + ((e < nin * NZ) ? k0 * NZ + e : 0)); }
             {
                 const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 const int idx = threadIdx.x & (TILE - 1);
@@ -730,12 +746,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
             if constexpr (GATHER) {
 #pragma unroll
-                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[gather_z(nx, e < TILE * NZ ? e : 0)]; }
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<WaitsOf<BT>::value>(Z + gather_z(nx, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 tpre = tp[gather_knot(nx, threadIdx.x & (TILE - 1))];
             } else {
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = Z[(e < nin1 * NZ) ? k1 * NZ + e : 0]; }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<WaitsOf<BT>::value>(Z + ((e < nin1 * NZ) ? k1 * NZ + e : 0)); }
             {
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 const int idx = threadIdx.x & (TILE - 1);
@@ -855,7 +871,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
-            V4 jv[JPLc], yv[YPLc];
+            V4 jv[JPP], yv[YPLc];
             bool skip_early = false;
             if constexpr (ES > 0) {
                 if (first) {
@@ -876,31 +892,39 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 }
             }
             __syncthreads();                               // barrier A
-#pragma unroll
-            for (int r = 0; r < JPLc; ++r) { const int u = r * (NCC * TILE) + ct; jv[r] = jsrc[u < L::JU ? u : 0]; }
-#pragma unroll
-            for (int r = 0; r < YPLc; ++r) { const int u = r * (NCC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
-            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the tile is in registers
-            __syncthreads();                               // barrier B
-            // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
-            // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
-            const long long nxt_tile = tile + tstep;
-            TileRef<T> nxt;
-            if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
-            else nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
-            __builtin_amdgcn_sched_barrier(0);
             // number of valid bytes of a ragged last tile is nk*OW*sizeof(T), a multiple of sizeof(T) only
             const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
             V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
+            TileRef<T> nxt;
 #pragma unroll
-            for (int r = 0; r < JPLc; ++r) {
-                const int u = r * (NCC * TILE) + ct;
-                if (ES > 0 && skip_early && early_line(u)) continue;
-                if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
-                else if (u * 16 < jbytes) {                // partial last unit of a ragged tile: element-wise
-                    const T* pv = reinterpret_cast<const T*>(&jv[r]);
-                    T* pd = reinterpret_cast<T*>(jdst + u);
-                    for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= jbytes) pd[q] = pv[q];
+            for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+                for (int r = 0; r < JPP; ++r) { const int u = (ps * JPP + r) * (NCC * TILE) + ct; jv[r] = jsrc[(ps * JPP + r < JPLc && u < L::JU) ? u : 0]; }
+                if (ps == NPASS - 1) {
+#pragma unroll
+                    for (int r = 0; r < YPLc; ++r) { const int u = r * (NCC * TILE) + ct; yv[r] = ysrc[u < L::YU ? u : 0]; }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this part of the tile is in registers
+                if (ps == NPASS - 1) {
+                    __syncthreads();                       // barrier B
+                    // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
+                    // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
+                    const long long nxt_tile = tile + tstep;
+                    if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
+                    else nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < JPP; ++r) {
+                    if (ps * JPP + r >= JPLc) continue;
+                    const int u = (ps * JPP + r) * (NCC * TILE) + ct;
+                    if (ES > 0 && skip_early && early_line(u)) continue;
+                    if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
+                    else if (u * 16 < jbytes) {            // partial last unit of a ragged tile: element-wise
+                        const T* pv = reinterpret_cast<const T*>(&jv[r]);
+                        T* pd = reinterpret_cast<T*>(jdst + u);
+                        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) if (u * 16 + (q + 1) * (int)sizeof(T) <= jbytes) pd[q] = pv[q];
+                    }
                 }
             }
             if (Y) {

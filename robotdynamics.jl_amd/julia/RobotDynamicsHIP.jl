@@ -81,6 +81,13 @@ mutable struct Context
 end
 last_error(p::Ptr{Cvoid}) = unsafe_string(ccall((:rdhip_last_error, librdhip), Cstring, (Ptr{Cvoid},), p))
 last_error(ctx::Context) = last_error(ctx.ptr)
+"demangled name of the kernel this host thread launched last through the library (which specialisation a call was dispatched to; `@which` for kernels)"
+function last_kernel_name()
+    buf = zeros(UInt8, 1024)
+    rc = GC.@preserve buf ccall((:rdhip_last_kernel_name, librdhip), Cint, (Ptr{UInt8}, Cint), pointer(buf), 1024)
+    rc == 0 || throw(RdhipError(rc, last_error(C_NULL)))
+    return GC.@preserve buf unsafe_string(pointer(buf))
+end
 
 const _default_ctx = Ref{Union{Nothing,Context}}(nothing)
 function default_context()

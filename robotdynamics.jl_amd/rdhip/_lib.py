@@ -54,6 +54,7 @@ _SIGS = {
     "rdhip_ctx_fence": (C.c_int, [_P]),
     "rdhip_ctx_stream": (_P, [_P]),
     "rdhip_last_error": (C.c_char_p, [_P]),
+    "rdhip_last_kernel_name": (C.c_int, [C.c_char_p, C.c_int]),
     "rdhip_timer_start": (C.c_int, [_P]),
     "rdhip_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "rdhip_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_ulonglong]),
@@ -141,6 +142,13 @@ def check(rc, ctx_handle=None):
     if rc == ERR_NO_DEVICE:
         raise NoDeviceError(rc, msg)
     raise RdhipError(rc, msg)
+
+
+def last_kernel_name():
+    """Demangled name of the kernel this host thread launched last through the library ('' before the first launch)."""
+    buf = C.create_string_buffer(1024)
+    check(lib().rdhip_last_kernel_name(buf, 1024))
+    return buf.value.decode()
 
 
 def device_count():

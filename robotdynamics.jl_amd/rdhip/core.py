@@ -1838,9 +1838,11 @@ class PreparedRolloutJacobianMulti:
     models / Js / Zs / x0s list one entry per model (Zs[p] = {"data", "t", "dt"} stacks as for rollout_jacobian_).  Argument checking happens once;
     calling the object re-issues the call (array contents may change, their memory may not)."""
 
-    def __init__(self, sig, diff, models, Js, Zs, x0s=None, time_major=False):
+    def __init__(self, sig, diff, models, Js, Zs, x0s=None, time_major=False, ctx=None):
+        """ctx: an rdhip Context that owns its stream to issue the call on instead of torch's current stream (see PreparedJacobian)."""
         if not isinstance(sig, FunctionSignature) or not isinstance(diff, DiffMethod):
             raise TypeError("sig must be a FunctionSignature and diff a DiffMethod")
+        self._own_ctx = ctx
         nm = len(models)
         if not (len(Js) == len(Zs) == nm) or (x0s is not None and len(x0s) != nm):
             raise ValueError("models, Js, Zs (and x0s) must list one entry per model")
@@ -1881,7 +1883,10 @@ class PreparedRolloutJacobianMulti:
     def __call__(self):
         if self._nm == 0:
             return
-        ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
+        if self._own_ctx is not None and self._space == L.DEVICE:
+            ctx = self._own_ctx
+        else:
+            ctx = L.context_for(self._dev, torch.cuda.current_stream(self._dev).cuda_stream) if self._space == L.DEVICE else self._ctx
         rc = L.lib().rdhip_rollout_jacobian_multi(ctx.handle, *self._args)
         if rc:
             L.check(rc, ctx.handle)
