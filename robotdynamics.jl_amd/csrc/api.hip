@@ -154,11 +154,13 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
+static void fused_forget_stream(int device, hipStream_t s);
 int rdhip_ctx_destroy(rdhip_ctx* c) {
     if (!c) return RDHIP_OK;
     if (c->device < 0) { delete c; return RDHIP_OK; }      // dry context: nothing on any device
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    fused_forget_stream(c->device, c->stream);             // (synchronised above: nothing fused is in flight on it any more)
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -554,18 +556,23 @@ static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, con
 static std::mutex g_fused_mu;
 static hipEvent_t g_fused_done[64] = {};
 static hipStream_t g_fused_stream[64] = {};
+static void fused_forget_stream(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> g(g_fused_mu);
+    if (g_fused_stream[device & 63] == s) g_fused_stream[device & 63] = nullptr;
+}
 static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& f, bool capturing) {
     std::lock_guard<std::mutex> g(g_fused_mu);
     const int slot = c->device & 63;
-    if (!capturing) {
+    if (!capturing && g_fused_stream[slot] && g_fused_stream[slot] != f.stream) {
+        // the previous fused launch went to ANOTHER stream: an event recorded there now (behind that launch) and waited for here.  Consecutive
+        // fused launches on one stream -- a solver's loop -- cost nothing extra.
         if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
-        if (g_fused_stream[slot] && g_fused_stream[slot] != f.stream && hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
+        // (a borrowed stream its owner has destroyed meanwhile: recording fails, and whatever ran on it has been waited for by the destruction)
+        if (hipEventRecord(g_fused_done[slot], g_fused_stream[slot]) != hipSuccess) (void)hipGetLastError();
+        else if (hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
     }
     const int k = family_rolljac(d, rule, diff, dtype, f);
-    if (k == RDHIP_OK && !capturing) {
-        if (hipEventRecord(g_fused_done[slot], f.stream) != hipSuccess) return RDHIP_ERR_HIP;
-        g_fused_stream[slot] = f.stream;
-    }
+    if (k == RDHIP_OK && !capturing) g_fused_stream[slot] = f.stream;
     return k;
 }
 
@@ -1081,18 +1088,26 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         const double bytes = (double)K[p] * (double)Mt[p] * d.n * (d.n + d.m);
         if (family_rolljac(d, rule[p], diff, dtype, f) == RDHIP_OK && bytes > fused_bytes) { fused_model = p; fused_bytes = bytes; }
     }
-    int rc0 = RDHIP_OK;
-    for (int p = 1; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes model 0 last
-        rdhip_ctx* ch = c->child[p - 1];
+    // The context's OWN stream takes the model with the fused launch (the longest piece of the call): consecutive calls then follow each other on one
+    // stream, kernel behind kernel, and the event round trips of fork and join fall on the shorter models, which have the slack (same box, the whole
+    // of BASELINE config 5 on one GPU: 343 us with model 0 -- the cartpole -- on the context's stream, 294 us this way; one GPU's share: 170 / 171 us).
+    static const char* main_env = getenv("RDHIP_MULTI_MAIN");      // tuning switch: "0" = model 0 on the context's own stream whatever it is
+    const int main_model = (fused_model >= 0 && !(main_env && main_env[0] == '0')) ? fused_model : 0;
+    int rc0 = RDHIP_OK, slot = 0;
+    for (int p = 0; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes its model last
+        if (p == main_model) continue;
+        rdhip_ctx* ch = c->child[slot];
         HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
-        ch->allow_fused = (p == fused_model);
+        ch->allow_fused = false;
         rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
-        HIP_TRY(c, hipEventRecord(c->join_ev[p - 1], ch->stream));
+        HIP_TRY(c, hipEventRecord(c->join_ev[slot], ch->stream));
+        ++slot;
     }
     if (rc0 == RDHIP_OK) {
-        c->allow_fused = (fused_model == 0);
-        rc0 = rdhip_rollout_jacobian(c, models[0], rule[0], diff, dtype, K[0], Mt[0], layout, Z[0], t[0], dt[0], X0 ? X0[0] : nullptr, J[0], memspace);
+        const int p = main_model;
+        c->allow_fused = (fused_model == p);
+        rc0 = rdhip_rollout_jacobian(c, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         c->allow_fused = true;
     }
     for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results

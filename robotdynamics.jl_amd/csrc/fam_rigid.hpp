@@ -17,8 +17,8 @@ using SatPlan = TablePlanS<19, 4, 3, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 
 //   wave 0: q3, w10, u15   wave 1: q4, w11, u16   wave 2: r, q5, v, w12 (+ f(z))   wave 3: q6, u13, u14
 using QuadPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
 // every rule of the rigid bodies gets the compile-time-column (structural zeros folded) split-role kernel
-template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
-template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
+template <class T, bool B, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D, GZ>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
+template <class T, bool B, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls
 // Satellite (round 3, searched with tune/tune_errexp.hip: 25.3 -> 23.8 us in the same-box A/B; the round-2 plan r, v, tau x 3 | (phi, w, uF) x 3 spilled 64
@@ -26,15 +26,15 @@ template <class T, bool B, bool D, int RULE> struct UnrollPolicy<RigidBody<T, WR
 // Quadrotor: the round-2 plan stays (23.5 us; the satellite's shape costs 26.7 there -- every rotor column is as heavy as a torque column).
 using SatErrPlan = TablePlanS<18, 4, 2, 6, /*r*/ 2, 2, 2, /*phi*/ 0, 1, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*uF*/ 2, 3, 3, /*tau*/ 0, 1, 3>;
 using QuadErrPlan = TablePlanS<16, 4, 2, 9, /*r*/ 3, 3, 3, /*phi*/ 0, 1, 2, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
-template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>, RULE> { using Plan = SatErrPlan; };
-template <class T, bool B, bool D, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>, RULE> { using Plan = QuadErrPlan; };
+template <class T, bool B, bool D, bool GZ, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D, GZ>, RULE> { using Plan = SatErrPlan; };
+template <class T, bool B, bool D, bool GZ, int RULE> struct ErrPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D, GZ>, RULE> { using Plan = QuadErrPlan; };
 
 // FiniteDifference along the cascade: a column costs the blocks it can change -- r, v, uF: the r,v block (~141 fp64 instructions of an RK4
 // step); q: q + r,v (~231); w, tau and the quadrotor's rotors: everything (~312).  Four waves of ~900-1090, the early part (r, q, v) spread evenly.
 using SatFdPlan = TablePlanS<19, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*uF*/ 2, 2, 3, /*tau*/ 0, 1, 3>;
 using QuadFdPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v*/ 3, 3, 3, /*w*/ 0, 1, 2, /*u*/ 0, 1, 3, 3>;
-template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D>> { static constexpr bool value = true; using Plan = SatFdPlan; };
-template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D>> { static constexpr bool value = true; using Plan = QuadFdPlan; };
+template <class T, bool B, bool D, bool GZ> struct FdPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D, GZ>> { static constexpr bool value = true; using Plan = SatFdPlan; };
+template <class T, bool B, bool D, bool GZ> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D, GZ>> { static constexpr bool value = true; using Plan = QuadFdPlan; };
 
 #define RD_RIGID_VARIANT_DECL(name)                                                                       \
     int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                     \
@@ -43,8 +43,9 @@ template <class T, bool B, bool D> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);         \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                    \
     int name##_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);
-#define RD_RIGID_VARIANT_DEFINE(name, WRENCH, BODY, DIAG)                                                 \
-    template <class T> using name##_M = RigidBody<T, WRENCH, BODY, DIAG>;                                 \
+#define RD_RIGID_VARIANT_DEFINE(name, WRENCH, BODY, DIAG) RD_RIGID_VARIANT_DEFINE_GZ(name, WRENCH, BODY, DIAG, false)
+#define RD_RIGID_VARIANT_DEFINE_GZ(name, WRENCH, BODY, DIAG, GZ)                                          \
+    template <class T> using name##_M = RigidBody<T, WRENCH, BODY, DIAG, GZ>;                             \
     int name##_eval(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_eval<name##_M>(md, rule, dtype, a); } \
     int name##_jacobian(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a) { return dispatch_jacobian<name##_M>(md, rule, diff, dtype, a); } \
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a) { return dispatch_rollout<name##_M>(md, rule, dtype, a); } \

@@ -79,6 +79,13 @@ template <class T> struct RolloutTilesTJ {
 };
 
 constexpr int FUSED_THREADS = 8 * TILE;
+// register budget of the fp32 fused kernel, in waves per SIMD (tuning switch).  Its two roles need 129 (rollout) and 146 (Jacobian tile loop) registers
+// on their own; left alone (1: one workgroup per CU, up to 256) the allocator takes 218 for the combined kernel; capped at 168 (3) it spills 180 bytes
+// per lane and the whole-C5 satellite half runs 3 % slower (264 -> 272 us, tune/tune_c5.hip) -- the other model's kernels of a mixed-model call find
+// room beside a fused workgroup either way (the cartpole's kernels take 58-72 registers)
+#ifndef RD_FUSED_F32_MINW
+#define RD_FUSED_F32_MINW 1
+#endif
 template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedLds {
     static constexpr size_t ROLL = CascadeLds<Fn, Cas, R>::BYTES, JAC = SplitLds<Fn, T, Plan, NC>::BYTES + SPLIT_GATHER_EXTRA;
     static constexpr size_t BYTES = ROLL > JAC ? ROLL : JAC;
@@ -93,7 +100,7 @@ template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedL
 // phase the quarter that rolled out idles for the second half of the launch (measured: 295 us for 4 096 x 256 fp32 satellite knots, the rollout
 // workgroups done at 120-135 us).  The host picks `split` from the ratio of the two rates (dispatch.hpp).
 template <class Fn, class T, class Cas, int R, class Plan, int NC, bool TM = true>
-__global__ void __launch_bounds__(FUSED_THREADS, 1) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
+__global__ void __launch_bounds__(FUSED_THREADS, (sizeof(T) == 4 ? RD_FUSED_F32_MINW : 1)) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
                                                                             const double* __restrict__ tt, const double* __restrict__ dtt, const T* __restrict__ X0,
                                                                             T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase, long long split) {
     if ((int)blockIdx.x < G) {

@@ -20,7 +20,7 @@ using namespace rd;
 using Mdl = SatellitePair<TT>;
 constexpr int NZc = 20;
 #elif defined(QUAD)
-using Mdl = RigidBody<TT, WRENCH_QUADROTOR, BODYF, DIAG>;
+using Mdl = RigidBody<TT, WRENCH_QUADROTOR, BODYF, DIAG, BODYF>;
 constexpr int NZc = 17;
 #else
 using Mdl = RigidBody<TT, WRENCH_SATELLITE, BODYF, DIAG>;
@@ -45,7 +45,11 @@ using P4 = TablePlanS<17, 4, 2, 7, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 
 using P5 = TablePlanS<17, 4, 2, 10, 3, 3, 3, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 2, 0, 1>;
 #else
 using P0 = TablePlanS<19, 4, 3, 10, 0, 0, 0, 0, 1, 2, 3, 1, 1, 1, 0, 1, 2, 0, 1, 1, 3, 3, 2>;     // SatPlan (value from wave 3)
+#if BODYF
+using P1 = TablePlanS<19, 4, 0, 10, 0, 0, 0, 0, 1, 2, 3, 0, 0, 0, 0, 1, 2, 1, 1, 1, 2, 3, 3>;     // body frame: (r q3 v w10) (q4 w11 uF) (q5 w12 tau16) (q6 tau17 tau18)
+#else
 using P1 = TablePlanS<19, 4, 3, 10, 0, 0, 0, 0, 1, 2, 3, 0, 1, 3, 0, 1, 2, 0, 1, 1, 3, 3, 2>;     // v spread 0, 1, 3
+#endif
 using P2 = TablePlanS<19, 4, 3, 10, 0, 0, 0, 0, 1, 2, 3, 0, 1, 1, 0, 1, 2, 0, 0, 1, 3, 3, 2>;     // v 0,1,1; uF 0,0,1
 using P3 = TablePlanS<19, 4, 3, 10, 0, 0, 0, 0, 1, 2, 3, 0, 0, 1, 0, 1, 2, 0, 1, 1, 3, 3, 2>;     // v 0,0,1
 using P4 = TablePlanS<19, 4, 2, 10, 0, 0, 0, 0, 1, 2, 3, 0, 1, 3, 0, 1, 2, 0, 1, 1, 3, 3, 2>;     // v spread, value from wave 2
