@@ -124,8 +124,8 @@ int rdhip_memcpy_d2h(rdhip_ctx* ctx, void* dst, const void* src, unsigned long l
 /* host-only object (no GPU needed).  rotation: the R of RigidBody{R} / LieState{R,P} (src/rigidbody.jl:46, src/liestate.jl:75-83).  RDHIP_ROT_QUAT serves
  * every operator.  RDHIP_ROT_MRP / RDHIP_ROT_RP (n = 12 rigid bodies, src/rigidbody.jl:80-94, test/rigidbody_test.jl:79-98): dynamics, the explicit rules
  * and ImplicitMidpoint, ForwardAD / FiniteDifference Jacobians, rollout, errstate_jacobian!, state_diff for the SATELLITE and QUADROTOR kinds;
- * errstate_jacobian! and state_diff for every LieState; RDHIP_USER_DEFINED -> RDHIP_ERR_NOT_IMPLEMENTED (the reference's analytic Jacobian is
- * QuatRotation-only, src/rigidbody.jl:260); nabla-errstate_jacobian! and rdhip_error_expansion -> RDHIP_ERR_UNSUPPORTED (not pinned by any test). */
+ * rdhip_error_expansion (Jacobian stack + projection with the 3 x 3 blocks, two launches); errstate_jacobian!, state_diff and nabla-errstate_jacobian!
+ * for every LieState; RDHIP_USER_DEFINED -> RDHIP_ERR_NOT_IMPLEMENTED (the reference's analytic Jacobian is QuatRotation-only, src/rigidbody.jl:260). */
 int rdhip_model_create(int kind, int rotation, int velocity_frame, const double* params, int nparams, rdhip_model** out);
 int rdhip_model_destroy(rdhip_model* model);
 /* A user-defined ContinuousDynamics model (the reference's `dynamics(model, x, u)` method, src/dynamics.jl:23-45), given as HIP source:
@@ -243,7 +243,8 @@ int rdhip_dynamics_error_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int 
  * with [A_k B_k] = the ForwardAD Jacobian of discrete_dynamics(DiscretizedDynamics{rule}(model), z_k) (src/discretized_dynamics.jl:169)
  * and G = errstate_jacobian! (src/liestate.jl:262-298; identity for EuclideanState models, src/statevectortype.jl:149-155).
  * Fused into the Jacobian kernel for the compiled-in LieGroupModels (the n x (n+m) Jacobian never reaches memory); EuclideanState
- * models return [A_k B_k]; unaligned outputs of the other LieGroupModels go through a workspace Jacobian stack and a projection kernel.
+ * models return [A_k B_k]; unaligned outputs of the other LieGroupModels and MRP / RodriguesParam states go through a workspace Jacobian stack
+ * and a projection kernel (not capturable into a graph).
  * Ebar: e x (e+m) x (N-1), each slab column-major; Y: n x (N-1) or NULL receives f(z_k).  Device pointers must be 16-byte aligned. */
 int rdhip_error_expansion(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long N,
                           const void* Z, const double* t, const double* dt, void* Ebar, void* Y, int memspace);
@@ -265,7 +266,9 @@ int rdhip_state_diff(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long l
                      const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace);
 
 /* nabla-errstate_jacobian!(model, nablaG, x, xbar) (v0.3: nabla^2 differential!): src/statevectortype.jl:137-147,
- * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian.  QuatRotation states only (RDHIP_ERR_UNSUPPORTED otherwise). */
+ * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian.  Rotation blocks grad^2-differential(R(x), xbar_rot): QuatRotation
+ * -(q . xbar_q) I (q normalised); MRP / RodriguesParam: the second derivative of delta -> params(p * R(delta)) at 0 contracted with xbar_rot --
+ * MRP (b.p)(8 p p' - 2 (1 + p.p) I) + 2 (p c' + c p'), c = (1 - p.p) b - 2 p x b; RodriguesParam 2 (b.g) g g' + g c' + c g', c = b - g x b. */
 int rdhip_nabla_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
                                   const void* X, int ldx, const void* Xbar, int ldxbar, int clear, void* nablaG, int memspace);
 

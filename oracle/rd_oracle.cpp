@@ -785,11 +785,47 @@ int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const do
     }
     return 0;
 }
-// nabla-errstate_jacobian!(model, nablaG, x, xbar): Euclidean -> 0 ; Lie: 3x3 diagonal blocks -(q . xbar_q) I
-// (src/liestate.jl:300-320; only those blocks are written unless clear != 0)
+// grad^2-differential(p, b) of the three-parameter rotations [3P, Rotations.jl; restated from its definition]: the contraction with b of the second
+// derivative of the composition map delta -> params(p * R(delta)) at delta = 0 (delta in the rotation's own parameters) -- the derivative with respect
+// to delta of grad-differential(p * R(delta))' b.  From the composition laws, with a = p.p:
+//   MRP             (1 - |d|^2) p + (1 - a) d + 2 p x d  over  1 + a |d|^2 - 2 p.d
+//                   second order terms: p (4 (p.d)^2 - (1 + a) |d|^2) + 2 (p.d) A0 d,   A0 = (1 - a) I + 2 skew(p)
+//                   =>  (b.p) (8 p p' - 2 (1 + a) I) + 2 (p c' + c p'),   c = A0' b = (1 - a) b - 2 p x b
+//   RodriguesParam  g + d + g x d  over  1 - g.d
+//                   second order terms: g (g.d)^2 + (g.d) B0 d,   B0 = I + skew(g)
+//                   =>  2 (b.g) g g' + g c' + c g',   c = B0' b = b - g x b
+// (for a quaternion the same definition with the Cayley map gives -(q.b) I: the unit test of test/liestate.jl:93-99 and the formula below).
+// Held against tests/golden/make_golden_rot3.py, which differentiates the composition twice by automatic differentiation.
+static void rot3_hessian(int rot, const double p[3], const double b[3], double H[3][3]) {
+    const double a = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], bp = b[0] * p[0] + b[1] * p[1] + b[2] * p[2];
+    const double pxb[3] = {p[1] * b[2] - p[2] * b[1], p[2] * b[0] - p[0] * b[2], p[0] * b[1] - p[1] * b[0]};
+    double c[3];
+    for (int i = 0; i < 3; ++i) c[i] = rot == ROT_MRP ? (1.0 - a) * b[i] - 2.0 * pxb[i] : b[i] - pxb[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        if (rot == ROT_MRP) H[i][j] = bp * (8.0 * p[i] * p[j] - ((i == j) ? 2.0 * (1.0 + a) : 0.0)) + 2.0 * (p[i] * c[j] + c[i] * p[j]);
+        else H[i][j] = 2.0 * bp * p[i] * p[j] + p[i] * c[j] + c[i] * p[j];
+    }
+}
+// nabla-errstate_jacobian!(model, nablaG, x, xbar): Euclidean -> 0 ; Lie: 3x3 diagonal blocks grad^2-differential(R(x_rot), xbar_rot): -(q . xbar_q) I for
+// quaternions (src/liestate.jl:300-320; only those blocks are written unless clear != 0)
 int oracle_nabla_errstate_jacobian(const OModel* M, int N, const double* X, int ldx, const double* Xb, int ldxb, int clear, double* dG) {
     OLie s; int lie = model_lie(*M, &s); int n = M->n; int e = lie ? lie_errdim(s) : n;
-    if (lie && s.rot != ROT_QUAT) return -2;
+    if (lie && s.rot != ROT_QUAT) {
+        for (int k = 0; k < N; ++k) {
+            const double* x = X + (size_t)k * ldx; const double* xb = Xb + (size_t)k * ldxb; double* Hk = dG + (size_t)k * e * e;
+            if (clear) for (int i = 0; i < e * e; ++i) Hk[i] = 0;
+            int r = 0, c = 0;
+            for (int v = 0; v < s.nP; ++v) {
+                r += s.P[v]; c += s.P[v];
+                if (v < s.nP - 1) {
+                    double H[3][3]; rot3_hessian(s.rot, x + r, xb + r, H);
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Hk[(c + i) + (c + j) * e] = H[i][j];
+                    r += 3; c += 3;
+                }
+            }
+        }
+        return 0;
+    }
     for (int k = 0; k < N; ++k) {
         const double* x = X + (size_t)k * ldx; const double* xb = Xb + (size_t)k * ldxb; double* Hk = dG + (size_t)k * e * e;
         if (!lie) { for (int i = 0; i < e * e; ++i) Hk[i] = 0; continue; }

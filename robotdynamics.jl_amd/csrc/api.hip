@@ -481,14 +481,13 @@ static int check_common(rdhip_ctx* c, const rdhip_model* M, int dtype, long long
     return RDHIP_OK;
 }
 // what a MRP / RodriguesParam model can do: op 0 = dynamics-type calls (the RigidBody{MRP|RodriguesParam} satellites and quadrotors, models.hpp
-// RigidBody3), op 1 = errstate_jacobian! (any LieState{MRP|RodriguesParam,P}: the 3 x 3 blocks of errstate.hip), op 2 = everything whose
-// Rotations.jl formula could not be pinned (nabla-errstate_jacobian!, the fused error-state expansion)
-static int check_rotation(rdhip_ctx* c, const rdhip_model* M, int op = 2) {
+// RigidBody3, and custom models; the error-state expansion builds on them), op 1 = the error-state maps (any LieState{MRP|RodriguesParam,P}: the 3 x 3
+// blocks of errstate.hip)
+static int check_rotation(rdhip_ctx* c, const rdhip_model* M, int op) {
     if (M->d.lie_nP == 0 || M->d.rot == RDHIP_ROT_QUAT) return RDHIP_OK;
     if (op == 1) return RDHIP_OK;
-    if (op == 0 && (M->d.kind == RDHIP_MODEL_SATELLITE || M->d.kind == RDHIP_MODEL_QUADROTOR || M->d.kind == RDHIP_MODEL_CUSTOM)) return RDHIP_OK;   // (a custom model's dynamics are the user's source)
-    return fail(c, RDHIP_ERR_UNSUPPORTED, op == 0 ? "MRP / RodriguesParam dynamics exist for the RigidBody satellite and quadrotor only"
-                                                   : "QuatRotation models only (the MRP / RodriguesParam form of this operator is not pinned by the reference's tests)");
+    if (M->d.kind == RDHIP_MODEL_SATELLITE || M->d.kind == RDHIP_MODEL_QUADROTOR || M->d.kind == RDHIP_MODEL_CUSTOM) return RDHIP_OK;   // (a custom model's dynamics are the user's source)
+    return fail(c, RDHIP_ERR_UNSUPPORTED, "MRP / RodriguesParam dynamics exist for the RigidBody satellite and quadrotor only");
 }
 static thread_local const ModelDesc* g_jit_model = nullptr;     // set by family_* for custom models so that kernel_status can report the JIT error
 static int kernel_status(rdhip_ctx* c, int rc, const char* what) {
@@ -895,10 +894,11 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
     if (!Z || !t || !dt || !Ebar) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
-    rc = check_rotation(c, M, 2); if (rc) return rc;
+    rc = check_rotation(c, M, 0); if (rc) return rc;
     const ModelDesc& d = M->d;
-    const bool rigid = d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR;
-    const bool lie_fused = d.kind == RDHIP_MODEL_SATELLITE_PAIR || d.kind == RDHIP_MODEL_LIE_SATELLITE;   // compiled-in LieGroupModels: fused kernel too
+    const bool quat = d.lie_nP == 0 || d.rot == RDHIP_ROT_QUAT;       // MRP / RodriguesParam states: Jacobian stack + the generic projection (3 x 3 blocks)
+    const bool rigid = quat && (d.kind == RDHIP_MODEL_SATELLITE || d.kind == RDHIP_MODEL_QUADROTOR);
+    const bool lie_fused = quat && (d.kind == RDHIP_MODEL_SATELLITE_PAIR || d.kind == RDHIP_MODEL_LIE_SATELLITE);   // compiled-in LieGroupModels: fused kernel too
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const int nz = d.n + d.m;
     Stage s(c);
     LaunchArgs a{}; a.stream = c->stream; a.N = P; a.Z = Z; a.t = t; a.dt = dt; a.J = Ebar; a.Y = Y;
@@ -910,7 +910,7 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
     int k;
     if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
     else if (lie_fused && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) k = fam_lie_errexp(d, rule, dtype, a);
-    else if (d.kind == RDHIP_MODEL_CUSTOM && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) {
+    else if (quat && d.kind == RDHIP_MODEL_CUSTOM && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) {
         k = jit_errexp(d.jit, rule, dtype, a); if (k) g_jit_model = &d;          // custom LieGroupModels: the same fused kernel, JIT-compiled
     }
     else if (!rigid) {
@@ -965,7 +965,6 @@ int rdhip_nabla_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype,
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (N > 0 && (!X || !Xb || !H)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     if (ldx < M->d.n || ldxb < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
-    rc = check_rotation(c, M, 2); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
     if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_nabla_errstate(M->lie, dtype, c->stream, N, X, ldx, Xb, ldxb, clear, H), what);
     Stage s(c);
@@ -1080,25 +1079,35 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
     // ONE model of the call takes the fused (spin-waiting) launch -- the one with the most Jacobian bytes among those that have it; the others run
     // rollout and Jacobians as two launches on their streams (see fused_launch)
     int fused_model = -1; double fused_bytes = -1;
+    double jbytes[4] = {0, 0, 0, 0};
     for (int p = 0; p < nmodels; ++p) {
         if (!Z[p] || !t[p] || !dt[p] || !J[p] || K[p] <= 0 || Mt[p] <= 0 || rule[p] < RDHIP_EULER || rule[p] > RDHIP_RK4) continue;
         const ModelDesc& d = models[p]->d;
         LaunchArgs f{}; f.N = Mt[p]; f.K = K[p]; f.Z = Z[p]; f.t = t[p]; f.dt = dt[p]; f.J = J[p]; f.time_major = (layout == RDHIP_TIME_MAJOR);
         f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1;
-        const double bytes = (double)K[p] * (double)Mt[p] * d.n * (d.n + d.m);
-        if (family_rolljac(d, rule[p], diff, dtype, f) == RDHIP_OK && bytes > fused_bytes) { fused_model = p; fused_bytes = bytes; }
+        jbytes[p] = (double)K[p] * (double)Mt[p] * d.n * (d.n + d.m) * (dtype == RDHIP_F64 ? 8.0 : 4.0);
+        if (family_rolljac(d, rule[p], diff, dtype, f) == RDHIP_OK && jbytes[p] > fused_bytes) { fused_model = p; fused_bytes = jbytes[p]; }
     }
-    // The context's OWN stream takes the model with the fused launch (the longest piece of the call): consecutive calls then follow each other on one
-    // stream, kernel behind kernel, and the event round trips of fork and join fall on the shorter models, which have the slack (same box, the whole
-    // of BASELINE config 5 on one GPU: 343 us with model 0 -- the cartpole -- on the context's stream, 294 us this way; one GPU's share: 170 / 171 us).
-    static const char* main_env = getenv("RDHIP_MULTI_MAIN");      // tuning switch: "0" = model 0 on the context's own stream whatever it is
-    const int main_model = (fused_model >= 0 && !(main_env && main_env[0] == '0')) ? fused_model : 0;
+    // The context's OWN stream takes the model whose part of the call is expected to take longest: consecutive calls then follow each other on one
+    // stream, kernel behind kernel, and the event round trips of fork and join (~7 us before a child stream starts, ~20 us between the end of a child's
+    // last kernel and the next call's first) fall on the models that have the slack.  Estimate per model: a rollout is a chain of K - 1 steps of
+    // ~0.5 us, its Jacobians a stream at ~5 TB/s -- one after the other, or overlapped for the model with the fused launch.  Same-box A/B: the whole
+    // of BASELINE config 5 on one GPU (the satellite's fused launch is the long part) 343 us with the cartpole on the context's stream, 294 us with
+    // the satellite there; one GPU's share of it (both rollouts ~120 us, the cartpole's Jacobians behind its own) 160 us / 174 us.
+    static const char* main_env = getenv("RDHIP_MULTI_MAIN");      // tuning switch: a model index
+    int main_model = 0; double longest = -1;
+    for (int p = 0; p < nmodels; ++p) {
+        const double chain = 0.5 * (double)(K[p] > 1 ? K[p] - 1 : 0), stream = jbytes[p] / 5.0e6;
+        const double est = p == fused_model ? (chain > stream ? chain : stream) : chain + stream;
+        if (est > longest) { longest = est; main_model = p; }
+    }
+    if (main_env && main_env[0] >= '0' && main_env[0] < '0' + nmodels) main_model = main_env[0] - '0';
     int rc0 = RDHIP_OK, slot = 0;
     for (int p = 0; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes its model last
         if (p == main_model) continue;
         rdhip_ctx* ch = c->child[slot];
         HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
-        ch->allow_fused = false;
+        ch->allow_fused = (p == fused_model);
         rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
         HIP_TRY(c, hipEventRecord(c->join_ev[slot], ch->stream));

@@ -154,6 +154,20 @@ template <class T> __device__ __forceinline__ T rot3_block(int rot, const T* p, 
     if (rot == RDHIP_ROT_MRP) return ((i == j) ? T(1) - (p0 * p0 + p1 * p1 + p2 * p2) : T(0)) + T(2) * (sk + pi * pj);
     return ((i == j) ? T(1) : T(0)) + sk + pi * pj;
 }
+// grad^2-differential(p, b) of the three-parameter rotations, entry (i, j): the contraction with b of the second derivative of delta -> params(p * R(delta))
+// at delta = 0 (src/liestate.jl:314 calls Rotations.jl's grad^2-differential; restated from that definition, oracle/rd_oracle.cpp rot3_hessian):
+//   MRP  (b.p) (8 p p' - 2 (1 + p.p) I) + 2 (p c' + c p'),  c = (1 - p.p) b - 2 p x b        RodriguesParam  2 (b.g) g g' + g c' + c g',  c = b - g x b
+template <class T> __device__ __forceinline__ T rot3_hessian_entry(int rot, const T* p, const T* b, int i, int j) {
+    const T a = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], bp = b[0] * p[0] + b[1] * p[1] + b[2] * p[2];
+    const T pxb[3] = {p[1] * b[2] - p[2] * b[1], p[2] * b[0] - p[0] * b[2], p[0] * b[1] - p[1] * b[0]};
+    const T pi = p[i], pj = p[j];
+    if (rot == RDHIP_ROT_MRP) {
+        const T ci = (T(1) - a) * b[i] - T(2) * pxb[i], cj = (T(1) - a) * b[j] - T(2) * pxb[j];
+        return bp * (T(8) * pi * pj - ((i == j) ? T(2) * (T(1) + a) : T(0))) + T(2) * (pi * cj + ci * pj);
+    }
+    const T ci = b[i] - pxb[i], cj = b[j] - pxb[j];
+    return T(2) * bp * pi * pj + pi * cj + ci * pj;
+}
 template <class T>
 __global__ void __launch_bounds__(256) errstate3_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, int clear, T* __restrict__ G) {
     const long long per = (long long)d.n * d.e;
@@ -222,7 +236,13 @@ __global__ void __launch_bounds__(256) nabla_errstate_kernel(LieDesc d, long lon
     if (clear) { c = p / d.e; r = p - c * d.e; }
     else { const int rot = p / 9, ij = p - rot * 9; c = d.rot_col0[rot] + ij / 3; r = d.rot_col0[rot] + ij % 3; }
     T val = T(0);
-    if (r == c) {
+    if (d.rot != RDHIP_ROT_QUAT) {
+        for (int rot = 0; rot < d.nrot; ++rot) {
+            const int c0 = d.rot_col0[rot];
+            if (r >= c0 && r < c0 + 3 && c >= c0 && c < c0 + 3)
+                val = rot3_hessian_entry<T>(d.rot, X + k * ldx + d.rot_row0[rot], Xb + k * ldxb + d.rot_row0[rot], r - c0, c - c0);
+        }
+    } else if (r == c) {
         for (int rot = 0; rot < d.nrot; ++rot) {
             if (r >= d.rot_col0[rot] && r < d.rot_col0[rot] + 3) {
                 const T* q = X + k * ldx + d.rot_row0[rot]; const T* b = Xb + k * ldxb + d.rot_row0[rot];
@@ -262,7 +282,7 @@ __global__ void __launch_bounds__(256) fill_neg_identity_kernel(long long pairs,
     J2[idx] = ((rc / n) == (rc % n)) ? T(-1) : T(0);
 }
 
-// E[k] = G(x_{k+1})' [A_k G(x_k) | B_k] from a stack of n x (n+m) Jacobians, any LieState{QuatRotation,P}: one thread per output element.
+// E[k] = G(x_{k+1})' [A_k G(x_k) | B_k] from a stack of n x (n+m) Jacobians, any LieState{R,P} (quaternion 4 x 3 or MRP / RodriguesParam 3 x 3 blocks): one thread per output element.
 // (RigidBody models use the fused kernel of kernels.hpp instead; this is the general composite for the other LieGroupModels.)
 template <class T> __device__ __forceinline__ T lh_entry(const T* q, T inv, int i, int j) {
     const int s = LH_IDX[i][j];
@@ -282,7 +302,10 @@ __global__ void __launch_bounds__(256) project_errexp_kernel(LieDesc d, long lon
     // row side: error row r <- state rows
     int rs[4]; T rw[4]; int nr = 1;
     if (d.err_src[r] >= 0) { rs[0] = d.err_src[r]; rw[0] = T(1); }
-    else {
+    else if (d.rot != RDHIP_ROT_QUAT) {                   // LieState{MRP | RodriguesParam, P}: the 3 x 3 blocks of errstate3_kernel
+        const int rot = -1 - d.err_src[r], s0 = d.rot_row0[rot], j = r - d.rot_col0[rot];
+        nr = 3; for (int i = 0; i < 3; ++i) { rs[i] = s0 + i; rw[i] = rot3_block<T>(d.rot, x2 + s0, i, j); }
+    } else {
         const int rot = -1 - d.err_src[r], s0 = d.rot_row0[rot], j = r - d.rot_col0[rot];
         const T* q = x2 + s0; const T inv = rsqrt_<T>(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         nr = 4; for (int i = 0; i < 4; ++i) { rs[i] = s0 + i; rw[i] = lh_entry<T>(q, inv, i, j); }
@@ -291,7 +314,10 @@ __global__ void __launch_bounds__(256) project_errexp_kernel(LieDesc d, long lon
     int cs[4]; T cw[4]; int nc = 1;
     if (c >= d.e) { cs[0] = d.n + (c - d.e); cw[0] = T(1); }
     else if (d.err_src[c] >= 0) { cs[0] = d.err_src[c]; cw[0] = T(1); }
-    else {
+    else if (d.rot != RDHIP_ROT_QUAT) {
+        const int rot = -1 - d.err_src[c], s0 = d.rot_row0[rot], j = c - d.rot_col0[rot];
+        nc = 3; for (int i = 0; i < 3; ++i) { cs[i] = s0 + i; cw[i] = rot3_block<T>(d.rot, x1 + s0, i, j); }
+    } else {
         const int rot = -1 - d.err_src[c], s0 = d.rot_row0[rot], j = c - d.rot_col0[rot];
         const T* q = x1 + s0; const T inv = rsqrt_<T>(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         nc = 4; for (int i = 0; i < 4; ++i) { cs[i] = s0 + i; cw[i] = lh_entry<T>(q, inv, i, j); }
@@ -429,7 +455,7 @@ template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long
     }
     constexpr int TK = 64;
     const size_t lds = (size_t)TK * d.e * d.e * sizeof(T);
-    if (clear && lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
+    if (clear && d.rot == RDHIP_ROT_QUAT && lds <= 80 * 1024 && (reinterpret_cast<uintptr_t>(H) & 15) == 0) {
         auto kern = errstate_tile_kernel<T, 1, TK>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 80 * 1024) != hipSuccess) return RDHIP_ERR_HIP;
         RD_LAUNCH(kern, dim3((unsigned)((N + TK - 1) / TK)), dim3(256), lds, s, d, N, (const T*)X, ldx, (const T*)Xb, ldxb, (T*)H);

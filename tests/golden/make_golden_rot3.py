@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/{dyn,err}_*_{mrp,rp}*.npz -- "restatement-derived" golden vectors for RigidBody{MRP} / RigidBody{RodriguesParam}
+"""Generate tests/golden/{dyn,err,nab,exp}_*_{mrp,rp}*.npz -- "restatement-derived" golden vectors for RigidBody{MRP} / RigidBody{RodriguesParam}
 and LieState{MRP|RodriguesParam,P} (src/rigidbody.jl:80-107,213-236; src/liestate.jl:262-298; test/rigidbody_test.jl:79-98; test/liestate.jl:56-68).
 
 Independent of oracle/rd_oracle.cpp and of the kernels: nothing here uses the closed forms (1 - p.p) I + 2 (skew(p) + p p') or
@@ -8,6 +8,10 @@ I + skew(g) + g g'.  Kinematics and the error-state blocks come from their DEFIN
     grad-differential(R)  = d/d(delta) params(R * R_type(delta))                                    at delta = 0     (Rotations.jl)
 with params(q) = v / (1 + w) for MRP, v / w for RodriguesParam, and R_type(delta) the unit quaternion of delta in the same parameters.
 A rotation acts on a vector through its unit quaternion.  state_diff = Rodrigues parameters of R0^-1 R (CayleyMap), through scipy.
+Round 4 (second stage, own random stream, so that the files of the first stage stay bit-identical):
+    grad^2-differential(R, b) = the Hessian of delta -> b . params(R * R_type(delta))                at delta = 0     (nab_*.npz; src/liestate.jl:300-320)
+    error-state expansion     = G(x_{k+1})' d/d(delta, u) f_d(x_k (+) delta, u_k)                    at delta = 0     (exp_*_{mrp,rp}_*.npz)
+(the quaternion fixtures of make_golden.py hold the same two definitions, where they reproduce Rotations.jl's -(q.b) I.)
 
 Run (build container only; torch + scipy, no GPU):  python tests/golden/make_golden_rot3.py"""
 import os
@@ -16,7 +20,7 @@ import sys
 import numpy as np
 import torch
 from scipy.spatial.transform import Rotation as SciRot
-from torch.func import jacfwd
+from torch.func import hessian, jacfwd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -145,6 +149,62 @@ def main():
     print("wrote", nfix, "fixtures to", HERE)
 
 
+def compose3(rot, P):
+    blocks, n = lie_layout(P)
+
+    def comp(x, d):
+        out, c = [], 0
+        for b in blocks:
+            if b[0] == "v":
+                out.append(x[b[1]:b[1] + b[2]] + d[c:c + b[2]]); c += b[2]
+            else:
+                out.append(from_quat(rot, MG.qmul(to_quat(rot, x[b[1]:b[1] + 3]), to_quat(rot, d[c:c + 3])))); c += 3
+        return torch.cat(out)
+    return comp, n
+
+
+def second_stage():
+    """nab_* and exp_* fixtures on the inputs of the first stage's files (loaded, not regenerated)."""
+    rng = np.random.default_rng(20261001)
+    nfix = 0
+    for rot, rtag in ((MRP, "mrp"), (RP, "rp")):
+        for tag, P in (("rigid", (3, 6)), ("p323", (3, 2, 3))):
+            comp, n = compose3(rot, P)
+            X = np.load(os.path.join(HERE, f"err_{tag}_{rtag}.npz"))["X"]
+            Xbar = rng.standard_normal(X.shape)
+            Xt, Xb = torch.as_tensor(X), torch.as_tensor(Xbar)
+            dG = torch.stack([hessian(lambda d: Xb[k] @ comp(Xt[k], d))(torch.zeros(n)) for k in range(X.shape[0])]).numpy()
+            np.savez_compressed(os.path.join(HERE, f"nab_{tag}_{rtag}.npz"), X=X, Xbar=Xbar, dG=dG, P=np.asarray(P), rot=np.asarray(rot)); nfix += 1
+        comp, n = compose3(rot, (3, 6))
+        e = n
+        for ftag in ("world", "body"):
+            for kind in ("satellite", "satfull", "quadrotor"):
+                d = np.load(os.path.join(HERE, f"dyn_{kind}_{rtag}_{ftag}.npz"))
+                Z, dts, frame = d["Z"], d["dt"], int(d["frame"])
+                if kind == "quadrotor":
+                    quad = (float(d["mass"]), [float(g) for g in d["gravity"]], float(d["L"]), float(d["kf"]), float(d["km"]))
+                    f, _, m = rigid_body3(rot, float(d["mass"]), d["J"], "quad", 4, frame, quad)
+                else:
+                    f, _, m = rigid_body3(rot, float(d["mass"]), d["J"], "sat", 6, frame)
+                Zt, dtt = torch.as_tensor(Z), torch.as_tensor(dts)
+                out = {}
+                for rule in ("rk3", "rk4"):
+                    step = MG.rk_step(f, rule)
+                    Es, errs = [], []
+                    for k in range(Z.shape[0] - 1):
+                        x, u, h = Zt[k, :n], Zt[k, n:], dtt[k]
+                        errs.append(step(x, u, h) - Zt[k + 1, :n])
+                        G2 = jacfwd(lambda dd: comp(Zt[k + 1, :n], dd))(torch.zeros(e))
+                        Jdu = jacfwd(lambda du: step(comp(x, du[:e]), u + du[e:], h))(torch.zeros(e + m))
+                        Es.append(G2.T @ Jdu)
+                    out["E_" + rule] = torch.stack(Es).numpy()
+                    out["err_" + rule] = torch.stack(errs).numpy()
+                np.savez_compressed(os.path.join(HERE, f"exp_{kind}_{rtag}_{ftag}.npz"), **out); nfix += 1
+    print("second stage: wrote", nfix, "fixtures to", HERE)
+
+
 if __name__ == "__main__":
     torch.set_default_dtype(torch.float64)
-    main()
+    if "--second-stage-only" not in sys.argv:
+        main()
+    second_stage()

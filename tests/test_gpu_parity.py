@@ -119,7 +119,7 @@ def test_golden_errstate(tag, mk, where):
 def test_golden_errstate_three_parameter_rotations(rtag, where):
     """errstate_jacobian! / state_diff of LieState{MRP,P} and LieState{RodriguesParam,P} (src/liestate.jl:262-298, :210-260): the rigid body's (3, 6)
     and test/liestate.jl:56-68's (3, 2, 3), against blocks differentiated from the composition map params(R * R(delta)) (make_golden_rot3.py) and
-    against the oracle's closed forms; G is not cleared unless asked; the second-order map is not offered for these rotations."""
+    against the oracle's closed forms; G is not cleared unless asked; the second-order map against the Hessian of the same composition map."""
     R = RD.MRP if rtag == "mrp" else RD.RodriguesParam
     for tag, what, om in (("rigid", RD.Body(R), O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), rot=O.ROT_MRP if rtag == "mrp" else O.ROT_RP)), ("p323", RD.LieState(R, (3, 2, 3)), None)):
         d = H.load(f"err_{tag}_{rtag}")
@@ -146,8 +146,28 @@ def test_golden_errstate_three_parameter_rotations(rtag, where):
         np.testing.assert_allclose(host(RD.state_diff(what, X, X0)), d["dX"], rtol=0, atol=1e-9)
         if om is not None:
             np.testing.assert_allclose(host(G), om.errstate_jacobian(d["X"]), rtol=0, atol=TOL)
-        with pytest.raises(NotImplementedError):
-            RD.nabla_errstate_jacobian_(what, torch.zeros((N, e, e), dtype=torch.float64, device="cuda").transpose(1, 2) if where == "cuda" else np.zeros((N, e, e)).transpose(0, 2, 1), X, X0)
+        # nabla-errstate_jacobian! (src/liestate.jl:300-320): grad^2-differential blocks against the Hessian of delta -> xbar . (x (+) delta) (nab_*.npz), the
+        # oracle's closed forms, and "only the blocks are written" without clear
+        dn = H.load(f"nab_{tag}_{rtag}")
+        assert np.array_equal(dn["X"], d["X"])
+        Xb = torch.as_tensor(dn["Xbar"]).cuda() if where == "cuda" else dn["Xbar"]
+        mkH = lambda fill: (torch.full((N, e, e), fill, dtype=torch.float64, device="cuda").transpose(1, 2) if where == "cuda" else np.full((N, e, e), fill).transpose(0, 2, 1))     # noqa: E731
+        Hc = mkH(7.0)
+        RD.nabla_errstate_jacobian_(what, Hc, X, Xb, clear=True)
+        np.testing.assert_allclose(host(Hc), dn["dG"], rtol=0, atol=TOL * max(1.0, np.abs(dn["dG"]).max()))
+        Hp = mkH(7.0)
+        RD.nabla_errstate_jacobian_(what, Hp, X, Xb)               # blocks only
+        hp = host(Hp)
+        blk = np.zeros((e, e), dtype=bool)
+        c0 = 0
+        for i, pv in enumerate(tuple(int(v) for v in dn["P"])):
+            c0 += pv
+            if i < len(dn["P"]) - 1:
+                blk[c0:c0 + 3, c0:c0 + 3] = True; c0 += 3
+        np.testing.assert_allclose(hp[:, blk], dn["dG"][:, blk], rtol=0, atol=TOL * max(1.0, np.abs(dn["dG"]).max()))
+        assert np.all(hp[:, ~blk] == 7.0)
+        if om is not None:
+            np.testing.assert_allclose(host(Hc), om.nabla_errstate_jacobian(dn["X"], dn["Xbar"]), rtol=0, atol=TOL * max(1.0, np.abs(dn["dG"]).max()))
 
 
 def test_errstate_does_not_clear_by_default():
@@ -587,9 +607,13 @@ def test_state_diff_of_bare_liestates_quat_rp_mrp(where):
                 r += rp; c += 3
         a, b = (torch.as_tensor(X).cuda(), torch.as_tensor(X0).cuda()) if where == "cuda" else (X, X0)
         np.testing.assert_allclose(host(RD.state_diff(s, a, b)), exp, rtol=0, atol=1e-12)
-        if kind != "quat":      # the second-order map of MRP / RodriguesParam states is not built (formula unpinned)
-            with pytest.raises(NotImplementedError):
-                RD.nabla_errstate_jacobian_(s, np.zeros((N, 14, 14)).transpose(0, 2, 1), X, X0)
+        if kind != "quat":      # the second-order map of MRP / RodriguesParam states: symmetric 3 x 3 blocks, zero elsewhere
+            Hn = np.zeros((N, 14, 14)).transpose(0, 2, 1)
+            RD.nabla_errstate_jacobian_(s, Hn, X, X0, clear=True)
+            Hn = np.asarray(Hn)
+            np.testing.assert_allclose(Hn, Hn.transpose(0, 2, 1), rtol=0, atol=1e-14)
+            mask = np.zeros((14, 14), dtype=bool); mask[3:6, 3:6] = True; mask[8:11, 8:11] = True
+            assert np.all(Hn[:, ~mask] == 0) and np.abs(Hn[:, mask]).max() > 0
 
 
 def test_empty_batch_is_a_noop():

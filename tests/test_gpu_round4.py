@@ -82,6 +82,41 @@ def test_config5_whole_workload_on_one_gpu_in_one_call():
             np.testing.assert_allclose(Jg[:, j], Jo, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("kind", ["satellite", "satfull", "quadrotor"])
+@pytest.mark.parametrize("rtag", ["mrp", "rp"])
+@pytest.mark.parametrize("ftag", ["world", "body"])
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_error_state_expansion_of_three_parameter_rigid_bodies(kind, rtag, ftag, where):
+    """rdhip_error_expansion for RigidBody{MRP} / RigidBody{RodriguesParam}: E_k = G(x_{k+1})' [A_k G(x_k) | B_k] with the 3 x 3 blocks of
+    src/liestate.jl:262-298 (the reference generates errstate_jacobian! for any R) against exp_*_{mrp,rp}_*.npz -- G(x_{k+1})' d f_d(x_k (+) delta, u) /
+    d(delta, u) differentiated from the composition map itself (tests/golden/make_golden_rot3.py) -- and against the oracle's product; dynamics_error too."""
+    name = f"{kind}_{rtag}_{ftag}"
+    d, g = H.load("dyn_" + name), H.load("exp_" + name)
+    R = RD.MRP if rtag == "mrp" else RD.RodriguesParam
+    if kind == "quadrotor":
+        model = RD.Quadrotor(R, mass=float(d["mass"]), J=d["J"], gravity=d["gravity"], motor_dist=float(d["L"]), kf=float(d["kf"]), km=float(d["km"]), bodyframe=bool(d["frame"]))
+    else:
+        model = RD.Satellite(float(d["mass"]), d["J"], R, bodyframe=bool(d["frame"]))
+    om = H.oracle_model(name, d)
+    n, m, e = RD.state_dim(model), RD.control_dim(model), RD.errstate_dim(model)
+    assert (n, e) == (12, 12)
+    N = d["Z"].shape[0]
+    for Q, rn, orule in ((RD.RK4, "rk4", O.RK4), (RD.RK3, "rk3", O.RK3)):
+        dm = RD.DiscretizedDynamics(model, Q)
+        Z = RD.PackedTrajectory(n, m, d["Z"], d["t"], d["dt"])
+        if where == "cuda":
+            Z = Z.to("cuda")
+        E = RD.alloc_error_expansions(dm, N, Z.data)
+        y = RD.evaluate(dm, Z)[: N - 1] * 0
+        RD.error_expansion_(dm, E, y, Z)
+        scale = max(1.0, np.abs(g["E_" + rn]).max())
+        np.testing.assert_allclose(host(E), g["E_" + rn], rtol=0, atol=TOL * scale)
+        Eo, yo = om.error_expansion(orule, d["Z"], d["t"], d["dt"])
+        np.testing.assert_allclose(host(E), Eo, rtol=0, atol=TOL * scale)
+        np.testing.assert_allclose(host(y), yo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(RD.dynamics_error(dm, Z)), g["err_" + rn], rtol=0, atol=TOL)
+
+
 def test_overlap_mode_orders_the_multi_model_call_and_graph_launches_behind_the_internal_stream():
     """ORDERING RULE of rdhip_ctx_set_overlap (include/rdhip.h): every other operation on the context is ordered behind everything issued before it.
     An rdhip_jacobian that went to the INTERNAL stream is followed (a) by rdhip_rollout_jacobian_multi whose child streams write the same J, and

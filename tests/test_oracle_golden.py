@@ -88,7 +88,24 @@ def test_errstate(tag, mk):
     np.testing.assert_allclose(M.state_diff(d["X"], d["X0"]), d["dX"], rtol=0, atol=1e-9)
 
 
-EXP_CASES = ["cartpole", "satellite_world", "body_body", "satfull_world", "quadrotor_world", "satpair", "liesat"]
+@pytest.mark.parametrize("rtag,rot", [("mrp", O.ROT_MRP), ("rp", O.ROT_RP)])
+@pytest.mark.parametrize("tag", ["rigid", "p323"])
+def test_nabla_errstate_three_parameter_rotations(tag, rtag, rot):
+    """grad^2-differential of MRP / RodriguesParam (src/liestate.jl:300-320 calls it per rotation block; the oracle's closed forms) against the Hessian of
+    delta -> xbar . (x (+) delta) differentiated twice from the composition map (tests/golden/make_golden_rot3.py second_stage) -- the definition under
+    which the quaternion fixtures reproduce Rotations.jl's -(q . b) I."""
+    d = H.load(f"nab_{tag}_{rtag}")
+    P = tuple(int(v) for v in d["P"])
+    M = O.satellite(2.0, np.diag([2.0, 3.0, 1.0]), rot=rot) if P == (3, 6) else None
+    if M is None:
+        pytest.skip("the oracle's registry has no LieState{R,(3,2,3)} model; the GPU test covers it through a custom LieState model")
+    H_ = M.nabla_errstate_jacobian(d["X"], d["Xbar"])
+    np.testing.assert_allclose(H_, d["dG"], rtol=0, atol=TOL * max(1.0, np.abs(d["dG"]).max()))
+    assert np.abs(H_ - H_.transpose(0, 2, 1)).max() == 0 or np.allclose(H_, H_.transpose(0, 2, 1), atol=1e-14)     # a Hessian contraction is symmetric
+
+
+EXP_CASES = ["cartpole", "satellite_world", "body_body", "satfull_world", "quadrotor_world", "satpair", "liesat"] + \
+            [f"{k}_{r}_{f}" for k in ("satellite", "satfull", "quadrotor") for r in ("mrp", "rp") for f in ("world", "body")]
 
 
 @pytest.mark.parametrize("name", EXP_CASES)
