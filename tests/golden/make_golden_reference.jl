@@ -14,7 +14,8 @@
 #     just their placement), `∇²differential`, `rotation_error(q, q0, CayleyMap())`, and the MRP / RodriguesParam kinematics, rotations and
 #     error maps (keys of ref_mrp_body.npz / ref_rp_body.npz: the product SERVES RigidBody{MRP} / RigidBody{RodriguesParam} dynamics, Jacobians,
 #     rollouts, errstate_jacobian! and state_diff on the formulas of SURVEY App. A, pinned so far only by their definitions -- these files are
-#     what would confirm or refute them; ∇errstate_jacobian! and the fused error-state expansion stay RDHIP_ERR_UNSUPPORTED for them);
+#     what would confirm or refute them; since round 4 also ∇errstate_jacobian! -- ref_nab_*.npz, Rotations.jl's ∇²differential of MRP / RodriguesParam
+#     against the Hessian of the composition map the product implements -- and the error-state expansion, ref_exp_*_{mrp,rp}_*.npz);
 #   * the operators added since the first generator: ImplicitMidpoint (Newton solve + ImplicitFunctionTheorem Jacobian, ref_implicit_*.npz),
 #     rollout! (ref_rollout_*.npz) and explicitly time-dependent models (stage times t, t + h/2, t + h: ref_tv_*.npz);
 #   * ForwardDiff.jl: `max(0, x)` tie rule in the quadrotor wrench;
@@ -137,6 +138,11 @@ RD.LieState(::LG{R,P}) where {R,P} = RD.LieState(R, P)
 
 const QR = QuatRotation{Float64}
 S33(A) = SMatrix{3,3,Float64,9}(A)
+# the rotation type a fixture was generated for (key "rot": 0 QuatRotation, 1 MRP, 2 RodriguesParam; absent = QuatRotation)
+function rot_type(d)
+    r = haskey(d, "rot") ? Int(d["rot"][]) : 0
+    return r == 1 ? MRP{Float64} : r == 2 ? RodriguesParam{Float64} : QR
+end
 
 function model_for(name::String, d)
     if startswith(name, "cartpole")
@@ -147,9 +153,9 @@ function model_for(name::String, d)
         A, B = d["A"], d["B"]; n, m = size(B)
         return Lin{n,m}(SMatrix{n,n,Float64}(A), SMatrix{n,m,Float64}(B))
     elseif startswith(name, "satellite_") || startswith(name, "body_") || startswith(name, "satfull_")
-        return Sat{QR}(Float64(d["mass"][]), S33(d["J"]), d["frame"][] != 0)
+        return Sat{rot_type(d)}(Float64(d["mass"][]), S33(d["J"]), d["frame"][] != 0)
     elseif startswith(name, "quadrotor")
-        return Quad{QR}(Float64(d["mass"][]), S33(d["J"]), SVector{3,Float64}(d["gravity"]), Float64(d["L"][]), Float64(d["kf"][]), Float64(d["km"][]), d["frame"][] != 0)
+        return Quad{rot_type(d)}(Float64(d["mass"][]), S33(d["J"]), SVector{3,Float64}(d["gravity"]), Float64(d["L"][]), Float64(d["kf"][]), Float64(d["km"][]), d["frame"][] != 0)
     elseif startswith(name, "satpair")
         return Pair{QR}(S33(d["J1"]), S33(d["J2"]))
     elseif startswith(name, "liesat")
@@ -229,17 +235,38 @@ end
 function err_case(tag)
     d = npzread(joinpath(HERE, "err_$tag.npz"))
     P = Tuple(Int.(d["P"]))
-    model = LG{QR,P}()
-    X, Xb, X0 = d["X"], d["Xbar"], d["X0"]
+    model = LG{rot_type(d),P}()
+    X, X0 = d["X"], d["X0"]
+    Xb = haskey(d, "Xbar") ? d["Xbar"] : nothing          # (the MRP / RodriguesParam files of make_golden_rot3.py keep their second-order inputs in nab_*.npz)
     N, n = size(X); e = RD.errstate_dim(model)
     G = zeros(N, n, e); dG = zeros(N, e, e); dX = zeros(N, e)
     for k = 1:N
-        x, xb, x0 = SVector{n}(X[k, :]), SVector{n}(Xb[k, :]), SVector{n}(X0[k, :])
+        x, x0 = SVector{n}(X[k, :]), SVector{n}(X0[k, :])
         Gk = zeros(n, e); RD.errstate_jacobian!(model, Gk, x); G[k, :, :] = Gk
-        Hk = zeros(e, e); RD.∇errstate_jacobian!(model, Hk, x, xb); dG[k, :, :] = Hk
+        if Xb !== nothing
+            Hk = zeros(e, e); RD.∇errstate_jacobian!(model, Hk, x, SVector{n}(Xb[k, :])); dG[k, :, :] = Hk
+        end
         dX[k, :] = RD.state_diff(model, x, x0)
     end
-    npzwrite(joinpath(HERE, "ref_err_$tag.npz"), Dict("G" => G, "dG" => dG, "dX" => dX, "X" => X, "Xbar" => Xb, "X0" => X0, "P" => d["P"]))
+    out = Dict{String,Any}("G" => G, "dX" => dX, "X" => X, "X0" => X0, "P" => d["P"])
+    if Xb !== nothing
+        out["dG"] = dG; out["Xbar"] = Xb
+    end
+    npzwrite(joinpath(HERE, "ref_err_$tag.npz"), out)
+end
+
+# ------------------------------------------------------------------------------------------------ nab_* : ∇errstate_jacobian! of LieState{MRP | RodriguesParam, P} (src/liestate.jl:300-320)
+function nab_case(tag)
+    d = npzread(joinpath(HERE, "nab_$tag.npz"))
+    P = Tuple(Int.(d["P"]))
+    model = LG{rot_type(d),P}()
+    X, Xb = d["X"], d["Xbar"]
+    N, n = size(X); e = RD.errstate_dim(model)
+    dG = zeros(N, e, e)
+    for k = 1:N
+        Hk = zeros(e, e); RD.∇errstate_jacobian!(model, Hk, SVector{n}(X[k, :]), SVector{n}(Xb[k, :])); dG[k, :, :] = Hk
+    end
+    npzwrite(joinpath(HERE, "ref_nab_$tag.npz"), Dict("dG" => dG, "X" => X, "Xbar" => Xb, "P" => d["P"]))
 end
 
 # ------------------------------------------------------------------------------------------------ RigidBody{MRP} / RigidBody{RodriguesParam} (unpinned [3P] formulas)
@@ -395,6 +422,7 @@ function main()
     foreach(dyn_case, dyn)
     foreach(exp_case, [replace(basename(f), r"^exp_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "exp_") && endswith(f, ".npz")])
     foreach(err_case, [replace(basename(f), r"^err_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "err_") && endswith(f, ".npz")])
+    foreach(nab_case, [replace(basename(f), r"^nab_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "nab_") && endswith(f, ".npz")])
     three_param_case(MRP{Float64}, "mrp")
     three_param_case(RodriguesParam{Float64}, "rp")
     foreach(implicit_case, ["cartpole", "satellite_world", "quadrotor_world", "di2"])
