@@ -155,7 +155,7 @@ template <class T> __device__ __forceinline__ T rot3_block(int rot, const T* p, 
     return ((i == j) ? T(1) : T(0)) + sk + pi * pj;
 }
 // grad^2-differential(p, b) of the three-parameter rotations, entry (i, j): the contraction with b of the second derivative of delta -> params(p * R(delta))
-// at delta = 0 (src/liestate.jl:314 calls Rotations.jl's grad^2-differential; restated from that definition, oracle/rd_oracle.cpp rot3_hessian):
+// at delta = 0 (src/liestate.jl:314 calls Rotations.jl's grad^2-differential; restated from that definition, derivation in DESIGN.md section 4.6):
 //   MRP  (b.p) (8 p p' - 2 (1 + p.p) I) + 2 (p c' + c p'),  c = (1 - p.p) b - 2 p x b        RodriguesParam  2 (b.g) g g' + g c' + c g',  c = b - g x b
 template <class T> __device__ __forceinline__ T rot3_hessian_entry(int rot, const T* p, const T* b, int i, int j) {
     const T a = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], bp = b[0] * p[0] + b[1] * p[1] + b[2] * p[2];
