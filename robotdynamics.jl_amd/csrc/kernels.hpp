@@ -664,6 +664,17 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // points, +2 % at 1 M).  Short launches keep the plain order: with a handful of tiles per workgroup the XCD ranges cost 1-4 % (and 15 % for
     // 64 fused batches of 1 024 knot points); a contiguous range per WORKGROUP costs 5-9 % at every size.
     long long tile, tend, tstep;
+#if defined(RD_TILE_MAP_RUNTIME)                 // tuning (tune/tune_bign.hip): the order chosen at run time through a device global
+    // g_tile_map = 0: plain; 100 R + v (R = 1, 2, 4 ranges per XCD): every XCD walks R contiguous ranges of ntiles / (8 R) tiles, its workgroups split
+    // into R groups; v = 0: an XCD's ranges are adjacent (range xcd R + sub), v = 1: interleaved (range sub 8 + xcd)
+    const int mp_ = g_tile_map;
+    if (mp_ >= 100 && (nwg & 7) == 0) {
+        const int R = mp_ / 100, v = mp_ % 100;
+        const long long xcd = wg & 7, j = wg >> 3, sub = j % R, jj = j / R, nr = 8LL * R;
+        const long long rid = v == 0 ? xcd * R + sub : sub * 8 + xcd, ntr = (ntiles + nr - 1) / nr;
+        tile = rid * ntr + jj; tend = ((rid + 1) * ntr < ntiles) ? (rid + 1) * ntr : ntiles; tstep = (nwg >> 3) / R;
+    } else
+#endif
 #if defined(RD_TILE_MAP) && RD_TILE_MAP == 0     // tuning: the plain order
     if (false) {
 #elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: XCD ranges at every size
