@@ -458,7 +458,8 @@ def main():
         try:
             tj = json.load(open(tfile))
             traffic = tj.get("bytes_per_launch")
-            if N != N_PER_GPU or (tj.get("kernel") and tj.get("kernel") != kernel_name):
+            same = lambda a, b: a.replace(" ", "").split("(")[0] == b.replace(" ", "").split("(")[0]      # noqa: E731  (kernel<template arguments>, without the parameter list)
+            if N != N_PER_GPU or (tj.get("kernel") and not same(tj["kernel"], kernel_name)):
                 traffic = None                         # the committed counters belong to another kernel / size: say nothing rather than something stale
             try:
                 commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles/hbm_traffic.json"], capture_output=True, text=True, timeout=10).stdout.strip()
