@@ -573,6 +573,18 @@ __global__ void col_probe_kernel(Fn fn, const T* __restrict__ Z, T* __restrict__
 #else
 #define RD_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #endif
+// Tile stores of the copy waves as BUFFER stores: the tile slab's base in a scalar resource descriptor, ONE vector register with the lane's byte offset
+// (16 ct) for the whole sweep and the unit's offset (r x 4 096 bytes for four copy waves) as the instruction's scalar offset.  As global stores every
+// unit carried its own 64-bit per-lane address: the compiler hoisted those 2 x 31 registers out of the tile loop, and in the batch-table kernels (256
+// registers, rdhip_jacobian_multi) spilled some of them and reloaded them INSIDE the store sweep, each reload behind a wait for every store issued so far.
+#if defined(RD_ABLATE) && RD_ABLATE == 3
+#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) do { if (lane == 99) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 2); } while (0)
+#elif defined(RD_PLAIN_STORES)
+#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 0)
+#else
+#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 2)      // aux 2 = nt (streaming: written once, never re-read here)
+#endif
+RD_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, (short)0, 0x7fffffff, 0x00020000); }
 template <class Fn, class T, class Plan, int NC> struct SplitLds {
     static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT;
     static constexpr size_t J_ELEMS = (size_t)TILE * OW, Y_ELEMS = (size_t)TILE * NVAL, Z_ELEMS = (size_t)TIN * NZ;
@@ -891,11 +903,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     // what made every chunked store pattern slow), and the sweep behind barrier B skips them
                     __syncthreads();                       // barrier E
                     if (nk == TILE) {
-                        V4* jd = reinterpret_cast<V4*>(cur.J + k0 * OW);
+                        const __amdgpu_buffer_rsrc_t jr = tile_rsrc(cur.J + k0 * OW);
 #pragma unroll
                         for (int r = 0; r < JPLc; ++r) {
                             const int u = r * (NCC * TILE) + ct;
-                            if (u < L::JU && early_line(u)) RD_TILE_STORE(jd + u, jsrc[u]);
+                            if (u < L::JU && early_line(u)) RD_TILE_STORE_BUF(jr, (unsigned)ct * 16u, (unsigned)(r * (NCC * TILE) * 16), jsrc[u]);
                         }
                         skip_early = true;
                     }
@@ -906,6 +918,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             // number of valid bytes of a ragged last tile is nk*OW*sizeof(T), a multiple of sizeof(T) only
             const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
             V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
+            const __amdgpu_buffer_rsrc_t jrs = tile_rsrc(J + k0 * OW);
             TileRef<T> nxt;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
@@ -930,7 +943,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     if (ps * JPP + r >= JPLc) continue;
                     const int u = (ps * JPP + r) * (NCC * TILE) + ct;
                     if (ES > 0 && skip_early && early_line(u)) continue;
-                    if (u * 16 + 16 <= jbytes) RD_TILE_STORE(jdst + u, jv[r]);
+                    if (u * 16 + 16 <= jbytes) RD_TILE_STORE_BUF(jrs, (unsigned)ct * 16u, (unsigned)((ps * JPP + r) * (NCC * TILE) * 16), jv[r]);
                     else if (u * 16 < jbytes) {            // partial last unit of a ragged tile: element-wise
                         const T* pv = reinterpret_cast<const T*>(&jv[r]);
                         T* pd = reinterpret_cast<T*>(jdst + u);
@@ -940,10 +953,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             }
             if (Y) {
                 V4* ydst = reinterpret_cast<V4*>(Y + k0 * NVAL);
+                const __amdgpu_buffer_rsrc_t yrs = tile_rsrc(Y + k0 * NVAL);
 #pragma unroll
                 for (int r = 0; r < YPLc; ++r) {
                     const int u = r * (NCC * TILE) + ct;
-                    if (u * 16 + 16 <= ybytes) RD_TILE_STORE(ydst + u, yv[r]);
+                    if (u * 16 + 16 <= ybytes) RD_TILE_STORE_BUF(yrs, (unsigned)ct * 16u, (unsigned)(r * (NCC * TILE) * 16), yv[r]);
                     else if (u * 16 < ybytes) {
                         const T* pv = reinterpret_cast<const T*>(&yv[r]);
                         T* pd = reinterpret_cast<T*>(ydst + u);
