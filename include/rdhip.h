@@ -116,7 +116,7 @@ int rdhip_graph_launch(rdhip_ctx* ctx, rdhip_graph* graph);
 int rdhip_graph_destroy(rdhip_graph* graph);
 /* device memory helpers for hosts that do not own a device allocator (the Julia wrapper) */
 int rdhip_malloc(rdhip_ctx* ctx, void** ptr, unsigned long long bytes);
-int rdhip_free(rdhip_ctx* ctx, void* ptr);
+int rdhip_free(rdhip_ctx* ctx, void* ptr);                                   /* ctx may be NULL (finalizers of a garbage-collected host) */
 int rdhip_memcpy_h2d(rdhip_ctx* ctx, void* dst, const void* src, unsigned long long bytes); /* async on ctx stream */
 int rdhip_memcpy_d2h(rdhip_ctx* ctx, void* dst, const void* src, unsigned long long bytes); /* synchronous */
 

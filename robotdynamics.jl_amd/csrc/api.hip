@@ -287,9 +287,11 @@ int rdhip_malloc(rdhip_ctx* c, void** p, unsigned long long bytes) {
     HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMalloc(p, bytes ? bytes : 1)); return RDHIP_OK;
 }
 int rdhip_free(rdhip_ctx* c, void* p) {
-    if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");
-    if (c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
-    HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipFree(p)); return RDHIP_OK;
+    // ctx may be NULL: a garbage-collected host (the Julia module's finalizers run in no particular order) must be able to release device memory
+    // after the context it was allocated through is gone; hipFree finds the owning device from the pointer
+    if (c && c->device < 0) return fail(c, RDHIP_ERR_NO_DEVICE, "this context has no device (RDHIP_DRY_RUN)");
+    if (c) HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipFree(p)); return RDHIP_OK;
 }
 int rdhip_memcpy_h2d(rdhip_ctx* c, void* dst, const void* src, unsigned long long bytes) {
     if (!c) return fail(c, RDHIP_ERR_INVALID_ARG, "ctx is NULL");

@@ -171,7 +171,8 @@ function DeviceArray{T}(::UndefInitializer, dims::Vararg{Integer,N}; ctx::Contex
 end
 function unsafe_free!(d::DeviceArray)
     if d.own && d.ptr != C_NULL
-        ccall((:rdhip_free, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d.ctx.ptr, d.ptr)
+        # (finalizers run in no particular order: the context this array was allocated through may have been destroyed already -- rdhip_free takes NULL)
+        ccall((:rdhip_free, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, d.ptr)
         d.ptr = C_NULL
     end
     return nothing

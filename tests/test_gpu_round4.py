@@ -321,3 +321,17 @@ def test_bench_multi_process_control_path_on_one_gpu(backend):
         assert abs(out["value"] - 2 * 65536 * 5 / (out["ms_per_step"] * 1e-3 * 5)) < 1e-6 * out["value"]
     else:
         assert out.get("value") or out.get("error")
+
+
+def test_device_memory_outlives_its_context():
+    """rdhip_free(NULL, ptr): a garbage-collected host (the Julia module's finalizers run in no particular order) releases device memory after the
+    context it was allocated through has been destroyed."""
+    import ctypes as C
+    from rdhip import _lib as L
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.rdhip_ctx_create(0, None, L.STREAM_OWN, C.byref(h)) == 0
+    p = C.c_void_p()
+    assert lib.rdhip_malloc(h, C.byref(p), 1 << 20) == 0 and p.value
+    assert lib.rdhip_ctx_destroy(h) == 0
+    assert lib.rdhip_free(None, p) == 0
