@@ -18,7 +18,11 @@ using SatPlan = TablePlanS<19, 4, 3, 10, /*r*/ 0, 0, 0, /*q*/ 0, 1, 2, 3, /*v*/ 
 using QuadPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
 // every rule of the rigid bodies gets the compile-time-column (structural zeros folded) split-role kernel
 template <class T, bool B, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_SATELLITE, B, D, GZ>, RULE> { static constexpr bool value = true; using Plan = SatPlan; static constexpr int NC = 4; };
-template <class T, bool B, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, B, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
+template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, false, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
+// body-frame velocities: the same column assignment with f(z) from wave 3 (round 4, tune/tune_plan.hip -DQUAD -DBODYF=true: 32.7 -> 31.9 us; every plan tried
+// spills 170-370 bytes per lane there -- a body-frame rotor column is 685 fp64 instructions on its own)
+using QuadBodyPlan = TablePlanS<17, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
+template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, true, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadBodyPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls
 // Satellite (round 3, searched with tune/tune_errexp.hip: 25.3 -> 23.8 us in the same-box A/B; the round-2 plan r, v, tau x 3 | (phi, w, uF) x 3 spilled 64

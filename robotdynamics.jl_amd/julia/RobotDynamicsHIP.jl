@@ -520,6 +520,29 @@ function CustomRigidBody(m::Integer, f, forces_src::AbstractString, moments_src:
     cascade && set_cascade!(model, [2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [(j in force_only_controls) ? 2 : 0 for j in 0:m-1])
     return model
 end
+"""
+    wrench_model(m, forces_src, moments_src; mass=1.0, J=I, params=Float64[], preamble="")
+
+`wrenches(model, x, u, t)` / `wrench_jacobian!` (src/rigidbody.jl:244-248, :315-320) of a `CustomRigidBody`, for whole trajectories: a 13-output helper
+model built from the SAME two snippets whose first six outputs are `[F; M]` (the rest zero) -- `dynamics!(helper, W13, Z)[1:6, :]` are the wrenches,
+`jacobian!(StaticReturn(), ForwardAD(), helper, J, nothing, Z)[1:6, :, :]` is `d wrenches / d z`.  (The compiled-in satellite and quadrotor have
+`wrenches!` / `wrench_jacobian!` entry points of their own.)
+"""
+function wrench_model(m::Integer, forces_src::AbstractString, moments_src::AbstractString; mass=1.0, J=SMatrix{3,3,Float64}(I), params=Float64[],
+                      preamble::AbstractString="")
+    Js = SMatrix{3,3,Float64,9}(J)
+    p = Float64[mass; _inertia9(Js); _inertia9(inv(Js)); collect(Float64, params)]
+    src = """
+    const S* r = x; const S* q = x + 3; const S* v = x + 7; const S* w = x + 10; const T* P = p + 19;
+    (void)r; (void)P; (void)q; (void)v; (void)w;
+    S F[3], tau[3];
+    { $forces_src }
+    { $moments_src }
+    for (int i = 0; i < 3; ++i) { xdot[i] = F[i]; xdot[3 + i] = tau[i]; }
+    for (int i = 6; i < 13; ++i) xdot[i] = S(T(0));
+"""
+    return CustomModel(13, m, (x, u, t) -> error("wrench_model: GPU only"), src; params=p, preamble=preamble)
+end
 "JIT-compile one kernel of a custom model now (works without a GPU): `op` as in rdhip_model_precompile."
 precompile_kernel(model::AnyCustom, op::Integer, rule::Integer, ::Type{T}=Float64) where {T} =
     check(nothing, ccall((:rdhip_model_precompile, librdhip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), handle(model), op, rule, dtypecode(T)))

@@ -722,6 +722,20 @@ def rigid_body_source(forces, moments, bodyframe=False):
 """
 
 
+def wrench_source(forces, moments):
+    """The HIP body of a 13-output helper model whose first six outputs are wrenches(model, x, u, t) = [forces; moments] (src/rigidbody.jl:244-248) of a
+    CustomRigidBody (same snippets, same names as rigid_body_source); the other outputs are zero."""
+    return f"""
+    const S* r = x; const S* q = x + 3; const S* v = x + 7; const S* w = x + 10; const T* P = p + 19;
+    (void)r; (void)P; (void)q; (void)v; (void)w;
+    S F[3], tau[3];
+    {{ {forces} }}
+    {{ {moments} }}
+    for (int i = 0; i < 3; ++i) {{ xdot[i] = F[i]; xdot[3 + i] = tau[i]; }}
+    for (int i = 6; i < 13; ++i) xdot[i] = S(T(0));
+"""
+
+
 def CustomRigidBody(m, forces, moments, mass=1.0, J=None, params=(), bodyframe=False, preamble="", cascade=True, force_only_controls=()):
     """A user-defined RigidBody{QuatRotation} for the GPU: what `struct MyBody <: RigidBody{R}` + `forces` / `moments` methods are in the reference
     (src/rigidbody.jl:244-258; examples/single_satellite.jl:18-27), with the wrenches given as HIP source (see rigid_body_source).  `m` controls,
@@ -732,6 +746,7 @@ def CustomRigidBody(m, forces, moments, mass=1.0, J=None, params=(), bodyframe=F
     p = np.concatenate([[float(mass)], Jm.flatten(order="F"), np.linalg.inv(Jm).flatten(order="F"), np.asarray(params, dtype=np.float64).ravel()])
     model = CustomModel(13, int(m), rigid_body_source(forces, moments, bodyframe), params=p, preamble=preamble, liestate=(QuatRotation, (3, 6)))
     model.velocity_frame = "body" if bodyframe else "world"
+    model._wrench_parts = (forces, moments, p, preamble, int(m))       # wrenches / wrench_jacobian of a custom body: a helper model built from the same snippets
     if cascade:
         fo = {int(j) for j in force_only_controls}
         model.set_cascade([2, 2, 2, 1, 1, 1, 1, 2, 2, 2, 0, 0, 0], [2 if j in fo else 0 for j in range(int(m))])
@@ -939,6 +954,29 @@ def wrench_sparsity(model):
     return np.array(list(js), dtype=bool).reshape(5, 2).T
 
 
+def _custom_wrench_call(model, Z, jac):
+    """wrenches / wrench_jacobian! of a CustomRigidBody (the reference's default works for any RigidBody that defines forces and moments,
+    src/rigidbody.jl:244-248, :315-320): the two snippets compiled once more as a helper model whose first six outputs are [F; M]; its `dynamics` is the
+    wrench, the first six rows of its continuous ForwardAD Jacobian d wrenches / d z."""
+    if not hasattr(model, "_wrench_parts"):
+        raise NotImplementedError("wrenches are defined for RigidBody models (Satellite, Quadrotor, CustomRigidBody)")
+    if not hasattr(model, "_wrench_helper"):
+        forces, moments, p, preamble, m = model._wrench_parts
+        model._wrench_helper = CustomModel(13, m, wrench_source(forces, moments), params=p, preamble=preamble)
+    helper = model._wrench_helper
+    Z, single = _as_traj(model, _split_args(Z))
+    n, m = _check_traj(model, Z)
+    N = len(Z)
+    Z = PackedTrajectory(n, m, Z.data, Z.t, Z.dt * 0 + 1)       # wrenches(model, x, u, t) takes the control as given: no terminal-knot rule (as rdhip_wrenches)
+    if not jac:
+        Xd = _empty_like_data(Z.data, (N, n))
+        _eval_into(helper, Xd, Z)
+        return (Xd[:, :6].clone() if _is_torch(Xd) else np.ascontiguousarray(Xd[:, :6])), single
+    J = alloc_jacobians(helper, N, Z.data)
+    jacobian_(StaticReturn(), ForwardAD(), helper, J, None, Z)
+    return J[:, :6, :], single
+
+
 def _wrench_call(model, Z, out_shape, jac):
     Z, single = _as_traj(model, _split_args(Z))
     n, m = _check_traj(model, Z)
@@ -955,6 +993,9 @@ def _wrench_call(model, Z, out_shape, jac):
 def wrenches(model, *args):
     """wrenches(model, x, u, t) = [forces; moments] (src/rigidbody.jl:244-248): one knot point (x, u[, t]) / KnotPoint, or every knot point of a
     PackedTrajectory -> (N, 6)."""
+    if isinstance(_cm(model), CustomModel):
+        W, single = _custom_wrench_call(_cm(model), args, False)
+        return W[0] if single else W
     W, single = _wrench_call(model, args, lambda n, m: (6,), False)
     return W[0] if single else W
 
@@ -962,6 +1003,9 @@ def wrenches(model, *args):
 def wrench_jacobian(model, *args):
     """d wrenches / d z (what wrench_jacobian!(F, model, z) of src/rigidbody.jl:315-320 is written to return): (6, n+m) for one knot point,
     (N, 6, n+m) views for a PackedTrajectory (stored (N, n+m, 6): each slab column-major 6 x (n+m) like the reference's F)."""
+    if isinstance(_cm(model), CustomModel):
+        F, single = _custom_wrench_call(_cm(model), args, True)
+        return F[0] if single else F
     F, single = _wrench_call(model, args, lambda n, m: (n + m, 6), True)
     F = F.transpose(1, 2) if _is_torch(F) else F.transpose(0, 2, 1)
     return F[0] if single else F

@@ -335,3 +335,31 @@ def test_device_memory_outlives_its_context():
     assert lib.rdhip_malloc(h, C.byref(p), 1 << 20) == 0 and p.value
     assert lib.rdhip_ctx_destroy(h) == 0
     assert lib.rdhip_free(None, p) == 0
+
+
+@pytest.mark.parametrize("where", ["host", "cuda"])
+def test_wrenches_of_a_custom_rigid_body(where):
+    """wrenches(model, x, u, t) and wrench_jacobian!(F, model, z) work for ANY RigidBody that defines forces and moments (src/rigidbody.jl:244-248,
+    :315-320): for RD.CustomRigidBody -- the two functions given as HIP source -- the host composes them from the same snippets (a helper model whose
+    first six outputs are [F; M]).  The quadrotor of test/quadrotor.jl:56-96 written that way against the oracle's forward duals and against the
+    compiled-in quadrotor's rdhip_wrenches / rdhip_wrench_jacobian."""
+    from examples.custom_models import QUADROTOR_FORCES_SRC as forces, QUADROTOR_MOMENTS_SRC as moments
+    rng = np.random.default_rng(74)
+    model = RD.CustomRigidBody(4, forces, moments, mass=0.5, J=np.diag([0.0023, 0.0023, 0.004]), params=(0.0, 0.0, -9.81, 0.1750, 1.0, 0.0245))
+    ref_model, om = RD.Quadrotor(), O.quadrotor()
+    for N in (130, 1):
+        Zn = H.rand_rigid(rng, N, 4, 0.5, 1.5)
+        Zn[0, 13] = -0.3                                             # max(0, kf u): a rotor command below zero
+        t, dt = np.arange(N) * 0.1, np.full(N, 0.1); dt[-1] = 0.0   # (a terminal knot point: wrenches take the control as given)
+        Z = RD.PackedTrajectory(13, 4, Zn, t, dt)
+        if where == "cuda":
+            Z = Z.to("cuda")
+        W, F = RD.wrenches(model, Z), RD.wrench_jacobian(model, Z)
+        Wo, Fo = om.wrenches(Zn, t), om.wrench_jacobian(Zn, t)
+        assert tuple(W.shape) == (N, 6) and tuple(F.shape) == (N, 6, 17)
+        np.testing.assert_allclose(host(W), Wo, rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(F), Fo, rtol=0, atol=TOL * max(1.0, np.abs(Fo).max()))
+        np.testing.assert_allclose(host(W), host(RD.wrenches(ref_model, Z)), rtol=0, atol=TOL)
+        np.testing.assert_allclose(host(F), host(RD.wrench_jacobian(ref_model, Z)), rtol=0, atol=TOL)
+    with pytest.raises(NotImplementedError):
+        RD.wrenches(RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81)), RD.PackedTrajectory(4, 1, np.zeros((2, 5)), 0.0, 0.1))
