@@ -33,7 +33,7 @@ struct rdhip_ctx {
     // batch tables of rdhip_jacobian_multi calls with more batches than fit the kernel arguments: pinned host image + device copy, a ring of
     // slots so that a call never overwrites a table a kernel of an earlier call may still be reading (the slot's event says when it is free)
     // A solver re-issues the same call on the same arrays every iteration: a slot whose image equals the new table is reused without a copy.
-    struct TableSlot { void* host = nullptr; void* dev = nullptr; size_t cap = 0, used = 0; hipEvent_t done = nullptr; bool pending = false; };
+    struct TableSlot { void* host = nullptr; void* dev = nullptr; size_t cap = 0, used = 0; hipEvent_t done = nullptr; bool pending = false, unrecorded = false, hit = false; };
     static constexpr int NTSLOT = 8;
     TableSlot tslot[NTSLOT];
     unsigned tnext = 0;
@@ -736,8 +736,15 @@ static bool stream_is_capturing(rdhip_ctx* c) {
 static rdhip_ctx::TableSlot* upload_table(rdhip_ctx* c, const std::vector<MultiRecPod>& recs, const std::vector<unsigned>& tile0) {
     const size_t rec_bytes = recs.size() * sizeof(MultiRecPod), t0_bytes = tile0.size() * sizeof(unsigned), bytes = rec_bytes + t0_bytes;
     for (auto& sl : c->tslot)                              // the same table as an earlier call (same arrays, same lengths): its device copy is still valid
-        if (sl.used == bytes && sl.host && std::memcmp(sl.host, recs.data(), rec_bytes) == 0 && std::memcmp(static_cast<char*>(sl.host) + rec_bytes, tile0.data(), t0_bytes) == 0) return &sl;
+        if (sl.used == bytes && sl.host && std::memcmp(sl.host, recs.data(), rec_bytes) == 0 && std::memcmp(static_cast<char*>(sl.host) + rec_bytes, tile0.data(), t0_bytes) == 0) { sl.hit = true; return &sl; }
     rdhip_ctx::TableSlot& sl = c->tslot[c->tnext++ % rdhip_ctx::NTSLOT];
+    sl.hit = false;
+    // launches that found their table in the slot recorded no event (an event per launch is a barrier packet between back-to-back kernels: the next
+    // launch's prologue no longer runs under this one's drain, ~3 us of a 28 us call); before such a slot is overwritten, everything queued so far ends
+    if (sl.unrecorded) {
+        if (hipEventRecord(sl.done, c->stream) != hipSuccess || hipEventSynchronize(sl.done) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: waiting for the stream failed"); return nullptr; }
+        sl.unrecorded = false; sl.pending = false;
+    }
     if (sl.pending) { if (hipEventSynchronize(sl.done) != hipSuccess) { fail(c, RDHIP_ERR_HIP, "batch table: hipEventSynchronize failed"); return nullptr; } sl.pending = false; }
     sl.used = 0;
     if (sl.cap < bytes) {
@@ -828,7 +835,10 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
             if (k == RDHIP_ERR_UNSUPPORTED && g0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff): decided before anything was launched
             if (k) return kernel_status(c, k, what);
             ++c->last_multi_launches;
-            if (slot) { if (hipEventRecord(slot->done, c->stream) != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: hipEventRecord failed", what); slot->pending = true; }
+            if (slot) {
+                if (slot->hit) slot->unrecorded = true;            // the caller's arrays of an earlier call again (a solver's loop): no event, see upload_table
+                else { if (hipEventRecord(slot->done, c->stream) != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: hipEventRecord failed", what); slot->pending = true; }
+            }
         }
     }
     if (fused) return RDHIP_OK;

@@ -836,7 +836,7 @@ template <class Fn, class T, class Plan> struct IftBody {
         if (kpl > TILE) kpl = TILE;
         for (; tile < tend; tile += tstep) {
             if (__builtin_amdgcn_readfirstlane(fn.flag[1 + tile]) == 0) continue;
-            const TileRef<T> r = bt.at(tile);
+            const TileRef<T> r = at_uniform<T>(bt, tile);
             const int nk = (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE);
             for (int c0 = 0; c0 < nk; c0 += kpl)
                 implicit_exact_knots<Mdl, T, true>(fn.m, r.N, r.Z, r.t, r.dt, r.Y, r.J, fn.iters, fn.tol, r.k0 + c0, (nk - c0) < kpl ? (nk - c0) : kpl, smem, kpl);

@@ -280,6 +280,24 @@ template <class T> struct MultiBatch {
     }
 };
 
+// wave-uniform 64-bit value held in vector registers -> scalar registers
+RD_DEV long long uniform64(long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+template <class BT> struct LooksUp { static constexpr bool value = false; };
+template <class T> struct LooksUp<MultiBatch<T>> { static constexpr bool value = true; };
+// bt.at(tile) for a tile number that is the same in every lane of the wavefront: a descriptor with a table counts and subtracts in vector registers
+// (the compiler vectorises the branch-free search), so without this the tile's pointers and first knot point stay in VGPRs -- 14 registers across the
+// column code of a kernel at the 256-register limit, and a waterfall loop around every buffer store of the copy waves, whose resource must be scalar
+template <class T, class BT> RD_DEV TileRef<T> at_uniform(const BT& bt, long long tile) {
+    const TileRef<T> r = bt.at(tile);
+    if constexpr (!LooksUp<BT>::value) return r;
+    else return TileRef<T>{(const T*)uniform64((long long)r.Z), (const double*)uniform64((long long)r.t), (const double*)uniform64((long long)r.dt),
+                           (T*)uniform64((long long)r.J), (T*)uniform64((long long)r.Y), uniform64(r.N), uniform64(r.k0)};
+}
+
+
 // Default plan: one chunk, contiguous column ranges per wave, f(z) emitted by wave 0.
 template <int NZ, int NG_> struct ContiguousPlan {
     static constexpr int NG = NG_, NCHUNK = 1;
@@ -404,7 +422,7 @@ RD_DEV void jac_tile_loop(const Fn& fn, const BT& bt) {
 
     long long tile = blockIdx.x;
     if (tile >= ntiles) return;
-    TileRef<T> cur = bt.at(tile);
+    TileRef<T> cur = at_uniform<T>(bt, tile);
     {   // first tile: stage z, t, dt
         const long long k0 = cur.k0;
         const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
@@ -422,7 +440,7 @@ RD_DEV void jac_tile_loop(const Fn& fn, const BT& bt) {
         // ---- issue the prefetch of the next tile's inputs (registers; consumed after the compute phase)
         const long long nxt = tile + gridDim.x;
         const bool more = nxt < ntiles;
-        const TileRef<T> nx = bt.at(more ? nxt : tile);
+        const TileRef<T> nx = at_uniform<T>(bt, more ? nxt : tile);
         const long long k1 = nx.k0;
         const T* __restrict__ Zn = nx.Z;
         const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
@@ -597,10 +615,6 @@ template <class Fn, class T, class Plan, int NC> struct SplitLds {
 
 // LDS table of resolved tiles (descriptors with RING): one 64-byte entry per iteration of the workgroup.  Values are wave-uniform for the
 // reader, who turns them back into scalars (v_readfirstlane) so that addresses stay "scalar base + lane offset".
-RD_DEV long long uniform64(long long v) {
-    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-    return ((long long)hi << 32) | (unsigned int)lo;
-}
 template <class T> RD_DEV void ring_put(long long* slot, const TileRef<T>& r) {
     slot[0] = (long long)r.Z; slot[1] = (long long)r.t; slot[2] = (long long)r.dt; slot[3] = (long long)r.J; slot[4] = (long long)r.Y; slot[5] = r.N; slot[6] = r.k0;
 }
@@ -718,7 +732,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         fr.row = jt + lane * OW;
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
-        TileRef<T> cur = bt.at(tile);
+        TileRef<T> cur = at_uniform<T>(bt, tile);
         if constexpr (WaitsOf<BT>::value) bt.wait(tile);
         {   // first tile: all of a thread's loads are issued before any is waited for (a load -> wait -> LDS-write loop costs one memory
             // round trip per pass: five of them in front of the first arithmetic of the kernel)
@@ -760,7 +774,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
             TileRef<T> nx;
             if (RING_N > 0 && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
-            else nx = bt.at(more ? nxt : tile);
+            else nx = at_uniform<T>(bt, more ? nxt : tile);
             if constexpr (WaitsOf<BT>::value) { if (more) bt.wait(nxt); }
             const long long k1 = nx.k0;
             const T* __restrict__ Z = nx.Z;
@@ -818,13 +832,13 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     } else if (HELPER && wave == NG + NC - 1) {
         // =========================== helper wave =============================
         if constexpr (HELPER) {
-            Body::helper_tile(fn, bt.at(tile), hbuf);
+            Body::helper_tile(fn, at_uniform<T>(bt, tile), hbuf);
             __syncthreads();                                   // barrier 0
             bool first = ES > 0;
             for (int it = 0; tile < tend; tile += tstep, ++it) {
                 if (first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
                 const long long nxt = tile + tstep;
-                if (nxt < tend) Body::helper_tile(fn, bt.at(nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
+                if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
                 __syncthreads();                               // barrier A
                 __syncthreads();                               // barrier B
             }
@@ -847,7 +861,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const int l0 = (u >> 3) << 7, k = l0 / RB;
             return l0 + 128 <= k * RB + EB;
         };
-        TileRef<T> cur = bt.at(tile);
+        TileRef<T> cur = at_uniform<T>(bt, tile);
         if constexpr (GATHER) {
             // gather tiles: copy wave w moves runs RPW w .. RPW w + RPW - 1 (RPW = GATHER_NRUN / 4 = 1).  A run is GATHER_RUN consecutive slabs = one contiguous piece of global memory that
             // starts at byte A (only sizeof(T)-aligned); in LDS it sits at the same offset modulo 16 (padb = A & 15), so the wave moves the ALIGNED
@@ -867,7 +881,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the tile is in registers
                 __syncthreads();                           // barrier B
                 const long long nxt_tile = tile + tstep;
-                const TileRef<T> nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
+                const TileRef<T> nxt = at_uniform<T>(bt, nxt_tile < tend ? nxt_tile : tile);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < RPW; ++q) {
@@ -935,7 +949,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
                     const long long nxt_tile = tile + tstep;
                     if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
-                    else nxt = bt.at(nxt_tile < tend ? nxt_tile : tile);
+                    else nxt = at_uniform<T>(bt, nxt_tile < tend ? nxt_tile : tile);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1231,7 +1245,7 @@ RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
     long long tile = (long long)blockIdx.x * L::WAVES + wave;
     if (tile >= ntiles) return;
     constexpr int ZPT = (TILE * NZ + TILE - 1) / TILE;        // = NZ
-    TileRef<T> cur = bt.at(tile);
+    TileRef<T> cur = at_uniform<T>(bt, tile);
     T zpre[ZPT]; double tpre, hpre;
     auto request = [&](const TileRef<T>& r, bool live) {       // the tile's inputs -> registers (lane-contiguous; lanes past the end re-read element 0)
         const int nkr = live ? (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE) : 0;
@@ -1269,7 +1283,7 @@ RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
         // the next tile's inputs are requested now and consumed at the top of the next iteration
         const long long nxt = tile + tstep;
         const bool more = nxt < ntiles;
-        const TileRef<T> nx = bt.at(more ? nxt : tile);
+        const TileRef<T> nx = at_uniform<T>(bt, more ? nxt : tile);
         request(nx, more);
         __builtin_amdgcn_sched_barrier(0);
         fn.eval(xd, ud, t, h, yd);

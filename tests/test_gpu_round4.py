@@ -363,3 +363,32 @@ def test_wrenches_of_a_custom_rigid_body(where):
         np.testing.assert_allclose(host(F), host(RD.wrench_jacobian(ref_model, Z)), rtol=0, atol=TOL)
     with pytest.raises(NotImplementedError):
         RD.wrenches(RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=(1.0, 0.2, 0.5, 9.81)), RD.PackedTrajectory(4, 1, np.zeros((2, 5)), 0.0, 0.1))
+
+
+def test_batch_table_slots_are_reused_safely_without_an_event_per_launch():
+    """rdhip_jacobian_multi with more than 32 trajectories keeps its batch table on the device, in one of 8 slots per context; a call that finds its
+    table there (a solver calling with the same arrays again) records no event behind its launch, so a slot may be due for overwriting while launches
+    that read it are still queued -- the library must let them finish first.  20 different tables (three slot generations), each called three times
+    back to back with no synchronisation in between, every result against one rdhip_jacobian call per trajectory."""
+    rng = np.random.default_rng(404)
+    model = RD.Satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    nb, per, ntab = 40, 101, 20
+    n = RD.state_dim(model)
+    tables = []
+    for k in range(ntab):
+        Zs = [RD.PackedTrajectory(n, 6, H.rand_rigid(rng, per, 6), 0.1 * b + np.arange(per) * 0.05, np.full(per, 0.05)).to("cuda") for b in range(nb)]
+        Js = [RD.alloc_jacobians(dm, per, Zs[0].data).fill_(7.0) for _ in range(nb)]
+        Ys = [torch.full((per, n), 7.0, dtype=torch.float64, device="cuda") for _ in range(nb)]
+        tables.append((Zs, Js, Ys))
+    for Zs, Js, Ys in tables:                       # no synchronisation anywhere in this loop
+        for _ in range(3):
+            assert RD.jacobian_multi_(sig, AD, dm, Js, Ys, Zs) == 1
+    torch.cuda.synchronize()
+    for Zs, Js, Ys in tables:
+        for b in (0, 17, nb - 1):
+            Jr = RD.alloc_jacobians(dm, per, Zs[b].data)
+            Yr = torch.empty((per, n), dtype=torch.float64, device="cuda")
+            RD.jacobian_(sig, AD, dm, Jr, Yr, Zs[b])
+            assert torch.equal(Js[b], Jr) and torch.equal(Ys[b], Yr)

@@ -357,6 +357,13 @@ def main():
         multi_case("16 x 4096 cartpole RK4 jacobian ForwardAD (C2 x 16)", cart, lambda N: rng.random((N, 5)), 16, 4096, RD.RK4, f64, a.reps)
         if a.only == "multi":
             return
+    if a.only == "multiprobe":     # what does the batch descriptor cost: fixed per launch or per tile?  (inline table <= 32 batches, device table beyond)
+        for nbatch, per in ((1, 65536), (16, 4096), (32, 2048), (64, 1024), (1, 131072), (32, 4096), (64, 2048), (128, 1024), (1, 262144), (32, 8192), (256, 1024)):
+            if nbatch == 1:
+                jac_case(f"single {per}", sat, rigid_inputs(per, 6, rng), RD.RK4, AD, f64, a.reps)
+            else:
+                multi_case(f"{nbatch} x {per} satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), nbatch, per, RD.RK4, f64, a.reps, singles=False)
+        return
     if a.only == "implicit":
         Zs = rigid_inputs(65536, 6, rng)
         dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
