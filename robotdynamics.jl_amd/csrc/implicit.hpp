@@ -790,6 +790,7 @@ template <class Fn, class T, class Plan> struct IftBody {
         const bool need = R::lu(a, piv) || bad;
         if (fr.g == 0 && fn.flag) {                                  // every compute wave sees the same knot points: one of them reports (unconditionally: nothing is ever cleared)
             const bool any = __any(need);
+            fr.epi = fr.epi || any;
             if ((threadIdx.x & 63) == 0 && (fn.solve || any)) fn.flag[1 + fr.tile] = any ? 1 : 0;      // (solve == 0: the Newton kernel wrote the word, this one only raises it)
         }
         waves<0>(fn, fr, xm, a, piv);

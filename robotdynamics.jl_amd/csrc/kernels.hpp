@@ -298,6 +298,16 @@ template <class T, class BT> RD_DEV TileRef<T> at_uniform(const BT& bt, long lon
 }
 
 
+// tuning (tune/tune_ift.hip, tune/tune_jac.hip): wall-clock stamps (100 MHz) of the split-role loop's phases, [workgroup][iteration < 8][slot < 16]:
+// 0 compute wave 0 enters the iteration, 4 + g compute wave g is done with its columns, 2 / 3 compute wave 0 behind barrier A / B, 8 / 9 / 10 copy
+// wave 0 behind barrier A / has the tile in registers / has issued its stores, 11 / 12 helper wave starts / ends the next tile's chain
+#if defined(RD_SPLIT_STAMP)
+__device__ long long* g_split_stamp = nullptr;
+#define RD_STAMP(it, slot) do { const long long c_ = (long long)wall_clock64(); long long* sp_ = g_split_stamp; if ((threadIdx.x & 63) == 0 && (it) < 8 && sp_) sp_[((long long)blockIdx.x * 8 + (it)) * 16 + (slot)] = c_; } while (0)
+#else
+#define RD_STAMP(it, slot) do {} while (0)
+#endif
+
 // Default plan: one chunk, contiguous column ranges per wave, f(z) emitted by wave 0.
 template <int NZ, int NG_> struct ContiguousPlan {
     static constexpr int NG = NG_, NCHUNK = 1;
@@ -366,6 +376,7 @@ template <class Fn, class T> struct JacFrame {
     T* row;          // this lane's row of the LDS output tile
     T* yrow;         // this lane's row of a separate LDS f(z) tile, or nullptr: f(z) goes behind the chunk's columns
     bool want_y;
+    bool epi = false;   // split-role loop, bodies with EPILOGUE: set (wave-uniformly, by compute wave 0) when some tile of the workgroup needs the epilogue
     // position inside the row: columns of the current chunk first
     RD_DEV void put_at(int pos, const T (&col)[NY]) {
 #pragma unroll
@@ -678,7 +689,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // NPASS = 2 (two copy waves, fp32): the copy waves take the tile out of LDS in two halves -- the first half's stores are issued in front of
     // barrier B, the second half's behind it -- and hold half a tile in registers at a time: 64 data registers instead of 128, which is what lets
     // a six-wave workgroup stay under the 168 registers of three waves per SIMD, i.e. TWO workgroups per compute unit (see UnrollPolicy / F32_NC)
+#if defined(RD_NPASS_ANY)                        // tuning (tune/tune_ng.hip): the two-pass copy for fp64 tiles too (six compute waves + two copy waves)
+    constexpr int NPASS = (NCC == 2 && !GATHER) ? 2 : 1;
+#else
     constexpr int NPASS = (sizeof(T) == 4 && NCC == 2 && !GATHER) ? 2 : 1;
+#endif
     constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,6 +729,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     } else { tile = t_begin + wg; tend = ntiles; tstep = nwg; }
     if (tile >= tend) return;
     const long long tile0 = tile;
+    bool epi_any = false;
+    __shared__ int epi_word;
+    if (wave == 0) RD_STAMP(0, 13);                        // (slots 13 / 15 of iteration 0: the workgroup's first and last instruction)
 
     if (wave < NG) {
         // =========================== compute waves ===========================
@@ -768,6 +786,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         __syncthreads();                                   // barrier 0
         for (int it = 0; tile < tend; tile += tstep, ++it) {
             const int nk = (int)((cur.N - cur.k0) < TILE ? (cur.N - cur.k0) : TILE);
+            if (wave == 0) RD_STAMP(it, 0);
             fr.want_y = (cur.Y != nullptr);
             const long long nxt = tile + tstep;
             const bool more = nxt < tend;
@@ -817,18 +836,22 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             fr.tile = tile;
             fr.helper = hbuf + (size_t)(it & 1) * HelperOf<Body>::BYTES;
             Body::template run<0>(fn, fr);
+            RD_STAMP(it, 4 + wave);
             fr.first = false;
             if constexpr (NA > 0) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) fr.aux[i] = apre[i];
             }
             __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
+            if (wave == 0) RD_STAMP(it, 2);
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
             __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
+            if (wave == 0) RD_STAMP(it, 3);
             cur = nx;
         }
+        epi_any = fr.epi;
     } else if (HELPER && wave == NG + NC - 1) {
         // =========================== helper wave =============================
         if constexpr (HELPER) {
@@ -836,9 +859,16 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             __syncthreads();                                   // barrier 0
             bool first = ES > 0;
             for (int it = 0; tile < tend; tile += tstep, ++it) {
+#if !defined(RD_HELPER_CHAIN_FIRST)
                 if (first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
+#endif
                 const long long nxt = tile + tstep;
+                RD_STAMP(it, 11);
                 if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
+                RD_STAMP(it, 12);
+#if defined(RD_HELPER_CHAIN_FIRST)             // tuning: the next tile's chain in front of barrier E
+                if (first) { __syncthreads(); first = false; }
+#endif
                 __syncthreads();                               // barrier A
                 __syncthreads();                               // barrier B
             }
@@ -929,6 +959,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 }
             }
             __syncthreads();                               // barrier A
+            if (ct < TILE) RD_STAMP(it, 8);
             // number of valid bytes of a ragged last tile is nk*OW*sizeof(T), a multiple of sizeof(T) only
             const int jbytes = nk * OW * (int)sizeof(T), ybytes = nk * NVAL * (int)sizeof(T);
             V4* jdst = reinterpret_cast<V4*>(J + k0 * OW);
@@ -944,6 +975,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this part of the tile is in registers
                 if (ps == NPASS - 1) {
+                    if (ct < TILE) RD_STAMP(it, 9);
                     __syncthreads();                       // barrier B
                     // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
                     // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
@@ -979,16 +1011,24 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     }
                 }
             }
+            if (ct < TILE) RD_STAMP(it, 10);
             cur = nxt;
         }
     }
     // a body may have work behind the tile loop (the implicit-function-theorem kernel redoes the tiles that asked for the exact solve): every wave of
     // the workgroup has passed the same barriers, the copy waves' stores are acknowledged, and the whole dynamic LDS is free again
+    // -- but only a workgroup that has such a tile waits for its stores (in front of the epilogue's own loads that wait is the launch's drain plus one
+    // dependent round trip per tile for the flag words, 2 us at the end of EVERY workgroup of a 30 us launch): compute wave 0 saw every tile's verdict
     if constexpr (EpilogueOf<Body>::value) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        if (threadIdx.x == 0) epi_word = epi_any ? 1 : 0;
         __syncthreads();
-        Body::epilogue(fn, bt, tile0, tend, tstep, smem, (size_t)L::BYTES);
+        if (epi_word != 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+            __syncthreads();
+            Body::epilogue(fn, bt, tile0, tend, tstep, smem, (size_t)L::BYTES);
+        }
     }
+    if (wave == 0) RD_STAMP(0, 15);
 }
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) { jac_split_loop<Fn, T, Plan, NC, Body, BT>(fn, bt, blockIdx.x, gridDim.x); }

@@ -391,4 +391,6 @@ def test_batch_table_slots_are_reused_safely_without_an_event_per_launch():
             Jr = RD.alloc_jacobians(dm, per, Zs[b].data)
             Yr = torch.empty((per, n), dtype=torch.float64, device="cuda")
             RD.jacobian_(sig, AD, dm, Jr, Yr, Zs[b])
-            assert torch.equal(Js[b], Jr) and torch.equal(Ys[b], Yr)
+            # (101 knots alone take the column-split kernel: same columns, another order of operations -- not bit-equal)
+            np.testing.assert_allclose(host(Js[b]), host(Jr), rtol=0, atol=1e-13)
+            np.testing.assert_allclose(host(Ys[b]), host(Yr), rtol=0, atol=1e-13)
