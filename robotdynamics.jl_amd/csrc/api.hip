@@ -42,6 +42,12 @@ struct rdhip_ctx {
     // the upper half, so nothing is cleared between calls
     unsigned long long* d_progress = nullptr;
     unsigned long long roll_epoch = 0;
+    // dynamic tile schedule of the split-role Jacobian kernels (kernels.hpp jac_split_loop): a launch gets two counter words {next, done}, both zero
+    // between launches (the launch's last workgroup resets them).  One ring of words per stream of the context: launches of one stream run in order,
+    // so a slot comes round again only behind the launch that used it.
+    static constexpr int NSCHED = 32;
+    unsigned* d_sched = nullptr;          // 2 streams x NSCHED slots x 2 words, allocated on first use (never inside a capture)
+    unsigned sched_next[2] = {0, 0};
     int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
     bool allow_fused = true;              // rdhip_rollout_jacobian_multi lets ONE model of a call take the fused (spin-waiting) launch
     // Launch overlap (rdhip_ctx_set_overlap): consecutive rdhip_jacobian calls on device arrays alternate between the context's stream and one
@@ -165,6 +171,7 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_progress) (void)hipFree(c->d_progress);
+    if (c->d_sched) (void)hipFree(c->d_sched);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (hipEvent_t e : {c->side_done, c->main_mark, c->main_done}) if (e) (void)hipEventDestroy(e);
     for (auto& ch : c->child) if (ch) { (void)rdhip_ctx_destroy(ch); ch = nullptr; }
@@ -658,6 +665,20 @@ int rdhip_model_wrench_sparsity(const rdhip_model* M, int js[10]) {
     return RDHIP_OK;
 }
 
+static bool stream_is_capturing(rdhip_ctx* c);
+// the counter words of this launch's dynamic tile schedule on stream `me` (0: the context's, 1: the internal one), or NULL: static schedule (a capturing
+// stream -- a graph would bake one slot into every replay --, RDHIP_DYNAMIC_TILES=0, or no memory for the words)
+static unsigned* take_sched(rdhip_ctx* c, int me) {
+    static const bool off = [] { const char* e = getenv("RDHIP_DYNAMIC_TILES"); return e && e[0] == '0'; }();
+    if (off || stream_is_capturing(c)) return nullptr;
+    if (!c->d_sched) {
+        const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * 2 * sizeof(unsigned);
+        if (hipMalloc(&c->d_sched, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_sched = nullptr; return nullptr; }
+        if (hipMemset(c->d_sched, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c->d_sched); c->d_sched = nullptr; return nullptr; }
+    }
+    const unsigned slot = c->sched_next[me]++ % rdhip_ctx::NSCHED;
+    return c->d_sched + ((size_t)me * rdhip_ctx::NSCHED + slot) * 2;
+}
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";
@@ -712,6 +733,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
             c->pend[other].clear();
         }
         a.stream = mine;
+        a.sched = take_sched(c, (int)me);
         // (implicit rule: each stream has its own set of flag words, so the two launches in flight do not share any)
         const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a, (int)me) : family_jacobian(d, rule, diff, dtype, a), what);
         c->pend[me].push_back(fp);
@@ -719,6 +741,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
         ++c->flip;
         return k;
     }
+    if (N > 0) a.sched = take_sched(c, 0);
     const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
@@ -920,6 +943,7 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
         if (s.rc) return s.rc;
     }
     int k;
+    if (P > 0) a.sched = take_sched(c, 0);
     if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
     else if (lie_fused && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) k = fam_lie_errexp(d, rule, dtype, a);
     else if (quat && d.kind == RDHIP_MODEL_CUSTOM && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) {

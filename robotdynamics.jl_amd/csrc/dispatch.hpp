@@ -129,7 +129,7 @@ template <class Fn, class T, class Plan, int NC, class K> int launch_split_kerne
     if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y);
+    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
     return hip_status(hipGetLastError());
 }
 

@@ -550,7 +550,8 @@ static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const L
     JitKernel* k; int rc = jit_get(M, op, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* J = a.J; void* Y = a.Y;
-    void* args[] = {fn.data(), &N, &Z, &t, &dt, &J, &Y};
+    unsigned* sched = a.sched;                           // (read by the split-role kernels only; the others have no such parameter and ignore the entry)
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &J, &Y, &sched};
     const long long ntiles = (N + 63) / 64;
     unsigned grid;
     if (k->small) { const int w = k->block / 64; grid = tile_grid(k->lds, k->block, (ntiles + w - 1) / w); }      // persistent: one tile per wave and pass
@@ -566,7 +567,8 @@ int jit_errexp(void* h, int rule, int dtype, const LaunchArgs& a) {
     JitKernel* k; int rc = jit_get(M, JOP_ERREXP, rule, dtype, &k); if (rc) return rc;
     std::vector<unsigned char> fn; pack_params(M, dtype, fn);
     long long N = a.N; const void* Z = a.Z; const double* t = a.t; const double* dt = a.dt; void* E = a.J; void* Y = a.Y;
-    void* args[] = {fn.data(), &N, &Z, &t, &dt, &E, &Y};
+    unsigned* sched = a.sched;
+    void* args[] = {fn.data(), &N, &Z, &t, &dt, &E, &Y, &sched};
     const long long ntiles = (N + 63) / 64;
     return launch(M, k, tile_grid(k->lds, k->block, ntiles), a.stream, args);
 }
@@ -608,7 +610,8 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
                 one.resize(o + 32, 0);
                 const int solve1 = (lds_ift + 2 * (((size_t)64 * M.n * ts + 16 + 15) / 16 * 16) <= 160 * 1024) ? 2 : 1;       // IftBody::HELPER: the helper wave's double buffer fits next to the tile
                 std::memcpy(one.data() + o, &tol, 8); std::memcpy(one.data() + o + 8, &flag, 8); std::memcpy(one.data() + o + 16, &iters, 4); std::memcpy(one.data() + o + 20, &solve1, 4);
-                void* ar[] = {one.data(), &N, &Z, &t, &dt, &J, &Y};
+                unsigned* sched = nullptr;
+                void* ar[] = {one.data(), &N, &Z, &t, &dt, &J, &Y, &sched};
                 return launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar);
             }
             rc = jit_get(M, JOP_IMPLICIT_X_REG, RDHIP_IMPLICIT_MIDPOINT, dtype, &kr); if (rc) return rc;
@@ -624,7 +627,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
             int* iflag = tile_flags ? flag : nullptr;        // (per-tile words only)
             std::memcpy(ifn.data() + off, &tol, 8); std::memcpy(ifn.data() + off + 8, &iflag, 8); std::memcpy(ifn.data() + off + 16, &iters, 4);
             std::memcpy(ifn.data() + off + 20, &solve0, 4); std::memcpy(ifn.data() + off + 24, &xn, 8);
-            { void* ar[] = {ifn.data(), &N, &Z, &t, &dt, &J, (void*)&nul}; rc = launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar); if (rc) return rc; }
+            { unsigned* sched = nullptr; void* ar[] = {ifn.data(), &N, &Z, &t, &dt, &J, (void*)&nul, &sched}; rc = launch(M, ki, tile_grid(ki->lds, ki->block, (N + 63) / 64), a.stream, ar); if (rc) return rc; }
             const int* gate2 = flag;
             void* args[] = {fn.data(), &N, &Z, &t, &dt, &Y, (void*)&J, &iters, &tol, &gate2, &tile_flags};
             return launch(M, k, tile_grid(k->lds, 64, nblk), a.stream, args);

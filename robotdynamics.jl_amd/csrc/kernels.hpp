@@ -213,9 +213,12 @@ template <class BT> struct GatherOf<BT, decltype((void)BT::GATHER)> { static con
 template <class T> struct SingleBatch {
     static constexpr bool RING = false;    // at() is arithmetic
     long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
+    unsigned* sched = nullptr;             // split-role loop: {next, done} words of the dynamic tile schedule (zero between launches), or NULL: static schedule
     RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
     RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
 };
+template <class BT, class = void> struct SchedOf { static RD_DEV unsigned* get(const BT&) { return nullptr; } };
+template <class BT> struct SchedOf<BT, decltype((void)&BT::sched)> { static RD_DEV unsigned* get(const BT& bt) { return bt.sched; } };
 constexpr int MULTI_MAXB = 32;
 template <class T> struct MultiRec { const T* Z; const double* t; const double* dt; T* J; T* Y; long long N; long long pad[2]; };   // 64 bytes: one scalar load
 template <class T> struct MultiBatch {
@@ -727,8 +730,32 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         tile = xcd * ntx + (wg >> 3);
         tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
     } else { tile = t_begin + wg; tend = ntiles; tstep = nwg; }
-    if (tile >= tend) return;
+    // DYNAMIC schedule (descriptors that carry the two counter words; launches of >= 8 tiles per workgroup): a workgroup's first three tiles are wg,
+    // wg + nwg, wg + 2 nwg, every further one comes from a device-wide counter, fetched by one lane THREE iterations ahead (the next tile's inputs are
+    // requested a whole iteration early, so its number must be known two iterations early) in the quiet window between barriers A and B, where the
+    // atomic does not queue behind a tile's stores.  Why: the XCDs do not run at the same rate (stamps, tune/tune_stamp.hip: last store issued 37 ..
+    // 47 us after launch, by XCD, at 131 072 satellite knots) and with equal shares a launch ends with its slowest workgroup -- the longer the launch
+    // the further apart: 262 144 knots 100.8 -> 94.8 us, 524 288 202.8 -> 181.1, 1 M 398 (XCD ranges) -> 367, 4 M 1 857 -> 1 584 (tune/tune_dyn.hip,
+    // same binary, alternating passes, identical outputs).  Below 8 tiles per workgroup the counter costs more than it returns (65 536 knots: +0.6 us),
+    // and handing out ALL tiles from it puts 256 atomics on one address in front of every workgroup's first tile (+1.5 us).  The plain order plus the
+    // counter also beats the static XCD ranges above, which it replaces when the words are there.  sched = {next, done}: both zero between launches
+    // -- the last workgroup to leave resets them.
+    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
+    constexpr int DYN_STATIC = 3;
+    __shared__ long long sched_ring[4];
+    unsigned* sched = nullptr;
+    if constexpr (DYN_OK) sched = SchedOf<BT>::get(bt);
+    const bool dyn = DYN_OK && sched != nullptr && t_begin == 0 && t_end < 0 && ntiles >= 8 * (long long)nwg;
+    if (dyn) { tile = wg; tend = ntiles; tstep = nwg; }        // (plain order, whatever the static map would have been)
+    auto leave = [&]() {                                       // (one thread per workgroup)
+        if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (tile >= tend) { if (dyn && threadIdx.x == 0) leave(); return; }
     const long long tile0 = tile;
+#define RD_NEXT_TILE(it) (dyn ? sched_ring[((it) + 1) & 3] : tile + tstep)
     bool epi_any = false;
     __shared__ int epi_word;
     if (wave == 0) RD_STAMP(0, 13);                        // (slots 13 / 15 of iteration 0: the workgroup's first and last instruction)
@@ -783,12 +810,14 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = z0[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
         }
+        long long sched_pend = tile + 2 * tstep;           // thread 0: the tile fetched last (tile it + 2 while iteration it runs)
+        if (dyn && threadIdx.x == 0) sched_ring[1] = tile + tstep;
         __syncthreads();                                   // barrier 0
-        for (int it = 0; tile < tend; tile += tstep, ++it) {
+        for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
             const int nk = (int)((cur.N - cur.k0) < TILE ? (cur.N - cur.k0) : TILE);
             if (wave == 0) RD_STAMP(it, 0);
             fr.want_y = (cur.Y != nullptr);
-            const long long nxt = tile + tstep;
+            const long long nxt = RD_NEXT_TILE(it);
             const bool more = nxt < tend;
             // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
             TileRef<T> nx;
@@ -844,6 +873,10 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             }
             __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
             if (wave == 0) RD_STAMP(it, 2);
+            if (dyn && threadIdx.x == 0) {                 // tile it + 2 becomes visible behind barrier B; tile it + 3 is requested
+                sched_ring[(it + 2) & 3] = sched_pend;
+                sched_pend = (long long)DYN_STATIC * nwg + __hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
@@ -852,17 +885,18 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             cur = nx;
         }
         epi_any = fr.epi;
+        if (dyn && threadIdx.x == 0) leave();
     } else if (HELPER && wave == NG + NC - 1) {
         // =========================== helper wave =============================
         if constexpr (HELPER) {
             Body::helper_tile(fn, at_uniform<T>(bt, tile), hbuf);
             __syncthreads();                                   // barrier 0
             bool first = ES > 0;
-            for (int it = 0; tile < tend; tile += tstep, ++it) {
+            for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
 #if !defined(RD_HELPER_CHAIN_FIRST)
                 if (first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
 #endif
-                const long long nxt = tile + tstep;
+                const long long nxt = RD_NEXT_TILE(it);
                 RD_STAMP(it, 11);
                 if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
                 RD_STAMP(it, 12);
@@ -934,7 +968,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 cur = nxt;
             }
         } else
-        for (int it = 0; tile < tend; tile += tstep, ++it) {
+        for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
             const long long k0 = cur.k0;
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
@@ -979,7 +1013,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     __syncthreads();                       // barrier B
                     // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
                     // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
-                    const long long nxt_tile = tile + tstep;
+                    const long long nxt_tile = RD_NEXT_TILE(it);
                     if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
                     else nxt = at_uniform<T>(bt, nxt_tile < tend ? nxt_tile : tile);
                 }
@@ -1030,12 +1064,13 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     }
     if (wave == 0) RD_STAMP(0, 15);
 }
+#undef RD_NEXT_TILE
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) { jac_split_loop<Fn, T, Plan, NC, Body, BT>(fn, bt, blockIdx.x, gridDim.x); }
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? RD_F32_MINB : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                               const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+                                                                               const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
 }
 // the same loops over several independent packed trajectories (rdhip_jacobian_multi), for ANY body: ForwardAD with compile-time or run-time columns,
 // FiniteDifference (plain or along the cascade), the UserDefined chain rule, the implicit-function-theorem columns.  MINB: minimum workgroups per
@@ -1243,8 +1278,8 @@ template <class Fn, class T, class Plan> struct ErrUnrolledBody {
 };
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_errexp_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                                   const double* __restrict__ dtt, T* __restrict__ E, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, E, Y});
+                                                                                   const double* __restrict__ dtt, T* __restrict__ E, T* __restrict__ Y, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, E, Y, sched});
 }
 
 // ---- small models (n + m <= 10): ONE wave owns 64 knot points and ALL Jacobian columns ---------------------------------
@@ -1408,8 +1443,8 @@ template <class Fn, class T, class Plan> struct AdLoopBody {
 };
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_loop_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                                    const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+                                                                                    const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
@@ -1605,8 +1640,8 @@ template <class Fn, class T, class Plan> struct ChainUnrolledBody {
 };
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_chain_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                                  const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+                                                                                  const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
 }
 
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
@@ -1649,8 +1684,8 @@ template <class Fn, class T, class Plan> struct FdBody {
 };
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
-                                                                               const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y) {
-    jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
+                                                                               const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,

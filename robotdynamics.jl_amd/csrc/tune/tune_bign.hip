@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
         for (int mp : maps) {
             CK(hipMemcpyToSymbol(HIP_SYMBOL(rd::g_tile_map), &mp, sizeof(int)));
             const int reps = (int)((8LL << 20) / N) + 4;
-            auto launch = [&](int i) { const bool o = rot_in && (i & 1); hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, o ? Z2 : Z, o ? t2 : t, o ? dt2 : dt, J[i & 1], Y[i & 1]); };
+            auto launch = [&](int i) { const bool o = rot_in && (i & 1); hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, o ? Z2 : Z, o ? t2 : t, o ? dt2 : dt, J[i & 1], Y[i & 1], (unsigned*)nullptr); };
             for (int i = 0; i < reps; ++i) launch(i);
             CK(hipStreamSynchronize(s));
             CK(hipEventRecord(e0, s));

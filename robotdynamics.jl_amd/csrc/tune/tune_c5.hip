@@ -56,8 +56,8 @@ int main(int argc, char** argv) {
         printf("%-44s %8.2f us  (%.3f of 8 TB/s on the judge's bytes)\n", name, ms * 1e3 / reps, alg / (ms * 1e-3 / reps) / 8e12);
     };
     timeit("rollout alone (fused kernel, grid = G)", [&]() { hipLaunchKernelGGL(kf, dim3(G), dim3(512), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, (TT*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL); });
-    timeit("Jacobians alone (256 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr); });
-    timeit("Jacobians alone (192 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(192), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr); });
+    timeit("Jacobians alone (256 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr, (unsigned*)nullptr); });
+    timeit("Jacobians alone (192 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(192), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr, (unsigned*)nullptr); });
     for (double split_frac : {0.0, 0.3, 0.35, 0.4, 0.45, 0.5, 0.55})
     for (int nj : {256 - G}) {
         if (nj <= 0) continue;

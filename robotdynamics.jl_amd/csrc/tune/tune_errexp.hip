@@ -34,7 +34,7 @@ template <class Plan> void run(const char* name, const Fn& fn, long long N, cons
     auto k = jac_errexp_split_kernel<Fn, double, Plan, 4>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, E[i % 4], Y[i % 4]); };
+    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, E[i % 4], Y[i % 4], (unsigned*)nullptr); };
     for (int i = 0; i < 3000; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     double best = 1e30, sum = 0;

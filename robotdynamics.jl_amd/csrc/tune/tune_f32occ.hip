@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
         for (int per_cu : {1, 2, 3}) {
             if (per_cu > occ) continue;
             const int grid = 256 * per_cu, reps = N > 500000 ? 20 : 200;
-            auto launch = [&](int i) { hipLaunchKernelGGL(kj, dim3(grid), dim3(threads), ldsj, s, fn, N, Z, t, dt, J[i % nb], Y[i % nb]); };
+            auto launch = [&](int i) { hipLaunchKernelGGL(kj, dim3(grid), dim3(threads), ldsj, s, fn, N, Z, t, dt, J[i % nb], Y[i % nb], (unsigned*)nullptr); };
             for (int i = 0; i < reps; ++i) launch(i);
             CK(hipStreamSynchronize(s));
             CK(hipEventRecord(e0, s));

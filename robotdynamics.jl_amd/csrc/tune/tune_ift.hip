@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     auto k = implicit_ift_split_kernel<Fn, double, Plan, 4>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4]); };
+    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
     for (int i = 0; i < 3000; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     for (int r = 0; r < 4; ++r) {

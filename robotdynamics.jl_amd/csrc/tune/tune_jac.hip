@@ -33,7 +33,7 @@ template <class Plan, int NC> void launch_split(const Fn& fn, long long N, const
     static bool init = false;
     if (!init) { CK(hipFuncSetAttribute((const void*)jac_ad_split_kernel<Fn, double, Plan, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); init = true; }
     const long long ntiles = (N + TILE - 1) / TILE;
-    hipLaunchKernelGGL((jac_ad_split_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y);
+    hipLaunchKernelGGL((jac_ad_split_kernel<Fn, double, Plan, NC>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3((Plan::NG + NC) * TILE), lds, s, fn, N, Z, t, dt, J, Y, (unsigned*)nullptr);
 }
 
 template <class Plan, int NC> void launch_split2(const Fn& fn, long long N, const double* Z, const double* t, const double* dt, double* J, double* Y, hipStream_t s) {

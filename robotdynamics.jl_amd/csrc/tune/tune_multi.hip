@@ -47,8 +47,8 @@ int main(int argc, char** argv) {
         }
         printf("%-52s %8.2f us (best %8.2f)  frac %.3f\n", name, sum / 5, best, knots * 2248.0 / (sum / 5 * 1e-6) / 8e12);
     };
-    timeit("single 65536", 65536, [&](int i) { hipLaunchKernelGGL(ks, dim3(256), dim3(512), lds, s, fn, 65536LL, Z, t, dt, J[i % NBUF], Y[i % NBUF]); });
-    timeit("single 103424", 103424, [&](int i) { hipLaunchKernelGGL(ks, dim3(256), dim3(512), lds, s, fn, 103424LL, Z, t, dt, J[i % NBUF], Y[i % NBUF]); });
+    timeit("single 65536", 65536, [&](int i) { hipLaunchKernelGGL(ks, dim3(256), dim3(512), lds, s, fn, 65536LL, Z, t, dt, J[i % NBUF], Y[i % NBUF], (unsigned*)nullptr); });
+    timeit("single 103424", 103424, [&](int i) { hipLaunchKernelGGL(ks, dim3(256), dim3(512), lds, s, fn, 103424LL, Z, t, dt, J[i % NBUF], Y[i % NBUF], (unsigned*)nullptr); });
     struct Case { const char* name; int nb; long long per; bool table; };
     const Case cases[] = {{"multi inline 16 x 4096", 16, 4096, false}, {"multi inline 32 x 2048", 32, 2048, false}, {"multi table uniform 64 x 1024", 64, 1024, true},
                           {"multi table uniform 1024 x 101", 1024, 101, true}, {"multi table ragged 1024 x 101(+-)", 1024, -101, true}, {"multi inline 32 x 101", 32, 101, false}};

@@ -29,7 +29,7 @@ template <class Plan, int NC> double run(const char* name, const Fn& fn, long lo
     auto k = jac_ad_split_kernel<Fn, double, Plan, NC>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3((Plan::NG + NC) * 64), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4]); };
+    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3((Plan::NG + NC) * 64), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
     for (int i = 0; i < 2000; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     double sum = 0;

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
     constexpr size_t lds = SplitLds<Fn, double, Plan, 4>::BYTES;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(NWG), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4]); };
+    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(NWG), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
     for (int i = 0; i < 2000; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     float ms;

@@ -394,3 +394,57 @@ def test_batch_table_slots_are_reused_safely_without_an_event_per_launch():
             # (101 knots alone take the column-split kernel: same columns, another order of operations -- not bit-equal)
             np.testing.assert_allclose(host(Js[b]), host(Jr), rtol=0, atol=1e-13)
             np.testing.assert_allclose(host(Ys[b]), host(Yr), rtol=0, atol=1e-13)
+
+
+def test_dynamic_tile_schedule_gives_what_the_static_one_gives():
+    """From 8 tiles per workgroup on (131 072 knots on a whole MI355X) the split-role Jacobian kernels take a workgroup's fourth and later tiles from a
+    device-wide counter (kernels.hpp jac_split_loop; two counter words per launch from a ring of the context, reset by the launch's last workgroup).
+    Knot points are independent, so a big batch must give bit for bit what its two halves give in separate calls (64-knot tiles fall on the same
+    knots; the halves are below the threshold: static schedule) -- for every kernel that goes through that loop, with a ragged last tile, in
+    overlap mode (two streams, a ring each), and after more launches than the ring has slots (a counter that was not reset would skip tiles)."""
+    rng = np.random.default_rng(808)
+    sig, AD, FD, UD = RD.StaticReturn(), RD.ForwardAD(), RD.FiniteDifference(), RD.UserDefined()
+    half = 8 * 256 * 64 // 2
+    N = 2 * half + 37
+    custom = RD.CustomModel(13, 6, H.SATELLITE_SRC, params=(2.0, 2.0, 3.0, 1.0), liestate=(RD.QuatRotation, (3, 6)))
+    cases = [(RD.Satellite(), 6, AD, np.float64), (RD.Satellite(), 6, FD, np.float64), (RD.Satellite(), 6, UD, np.float64), (RD.Quadrotor(), 4, AD, np.float64),
+             (RD.Satellite(bodyframe=True), 6, AD, np.float32), (custom, 6, AD, np.float64)]
+    for model, m, diff, dtype in cases:
+        n = RD.state_dim(model)
+        dm = RD.DiscretizedDynamics(model, RD.RK4)
+        Zn = np.ascontiguousarray(H.rand_rigid(rng, N, m), dtype=dtype)
+        t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+        whole = RD.PackedTrajectory(n, m, Zn, t, dt).to("cuda")
+        J = [RD.alloc_jacobians(dm, N, whole.data) for _ in range(2)]
+        Y = [torch.empty((N, n), dtype=whole.data.dtype, device="cuda") for _ in range(2)]
+        for i in range(70):                                   # (more than twice the 32 slots of the context's ring)
+            RD.jacobian_(sig, diff, dm, J[i & 1], Y[i & 1], whole)
+        parts = []
+        for lo, hi in ((0, half), (half, N)):
+            Zp = RD.PackedTrajectory(n, m, Zn[lo:hi], t[lo:hi], dt[lo:hi]).to("cuda")
+            Jp = RD.alloc_jacobians(dm, hi - lo, Zp.data)
+            Yp = torch.empty((hi - lo, n), dtype=Zp.data.dtype, device="cuda")
+            RD.jacobian_(sig, diff, dm, Jp, Yp, Zp)
+            parts.append((Jp, Yp))
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(J[k], torch.cat([parts[0][0], parts[1][0]])), (type(model).__name__, type(diff).__name__, dtype.__name__)
+            assert torch.equal(Y[k], torch.cat([parts[0][1], parts[1][1]]))
+    # overlap mode: launches alternate between two streams, each with its own ring of counter words
+    model, dm = RD.Satellite(), RD.DiscretizedDynamics(RD.Satellite(), RD.RK4)
+    Zn = H.rand_rigid(rng, N, 6)
+    whole = RD.PackedTrajectory(13, 6, Zn, np.arange(N) * 0.05, np.full(N, 0.05)).to("cuda")
+    from rdhip import _lib as L
+    ctx = L.Context(0)
+    ctx.set_overlap(True)
+    if True:
+        Js = [RD.alloc_jacobians(dm, N, whole.data) for _ in range(4)]
+        calls = [RD.prepare_jacobian(sig, AD, dm, Js[b], None, whole, ctx=ctx) for b in range(4)]
+        for i in range(80):
+            calls[i & 3]()
+        ctx.synchronize()
+        ref = RD.alloc_jacobians(dm, N, whole.data)
+        RD.jacobian_(sig, AD, dm, ref, None, whole)
+        torch.cuda.synchronize()
+        for b in range(4):
+            assert torch.equal(Js[b], ref)
