@@ -158,6 +158,21 @@ def secondary_metrics(dev, reps):
         out[key] = {"knot_points": N, "value": N / (us * 1e-6), "unit": "knot-point Jacobians/s", "us_per_launch": us, "bytes_per_knot": BYTES_PER_KNOT,
                     "frac_of_hbm_peak": N * BYTES_PER_KNOT / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     del Jx
+    # the headline operator on a LARGE batch (1 M knot points, 16 tiles per workgroup and more: the tile loop's dynamic schedule); inputs and
+    # outputs rotate over two sets (2 x 2.2 GB)
+    try:
+        Nl = 1 << 20
+        Zl = [RD.PackedTrajectory(NX, NU, *synthetic_inputs(Nl, 21 + k)).to(dev) for k in range(2)]
+        Jl = [RD.alloc_jacobians(dm, Nl, Zl[0].data) for _ in range(2)]
+        Yl = [torch.empty((Nl, NX), dtype=torch.float64, device=dev) for _ in range(2)]
+        calls = [RD.prepare_jacobian(RD.StaticReturn(), RD.ForwardAD(), dm, Jl[k], Yl[k], Zl[k]) for k in range(2)]
+        us = _timed_us(lambda i: calls[i & 1](), 20, warm=3)
+        out["jacobian_rk4_satellite_1M_knots"] = {"knot_points": Nl, "value": Nl / (us * 1e-6), "unit": "knot-point Jacobians/s", "us_per_launch": us,
+                                                  "bytes_per_knot": BYTES_PER_KNOT, "frac_of_hbm_peak": Nl * BYTES_PER_KNOT / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                  "kernel": L.last_kernel_name()[:60], "input_buffers": 2, "output_buffers": 2}
+        del Zl, Jl, Yl, calls
+    except Exception as e:
+        out["jacobian_rk4_satellite_1M_knots"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # rollout!: one GPU's share of C5's satellite half, 512 trajectories x 256 knot points, fp32 -- a latency chain, not a stream
     Mr, Kr = 512, 256
     zr, _, _ = synthetic_inputs(Mr * Kr, 12)
