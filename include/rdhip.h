@@ -201,7 +201,7 @@ int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, 
  * J: n x (n+m) x N, fully overwritten.  Y: n x N or NULL; receives f(z) (what InPlace leaves in `y`).
  * rule = RDHIP_IMPLICIT_MIDPOINT: diff = RDHIP_FORWARD_AD stands for ImplicitFunctionTheorem(ForwardAD()) (the only DiffMethod the reference
  * accepts for implicit models, src/discretized_dynamics.jl:243-249): the next state is solved for, then J = -J2[:,1:n] \ J1.
- * Batches of 8 or more 64-knot tiles per workgroup (131 072 knot points on a whole MI355X) are scheduled dynamically (a device-wide counter hands
+ * fp64 batches of 8 or more 64-knot tiles per workgroup (131 072 knot points on a whole MI355X) are scheduled dynamically (a device-wide counter hands
  * out the tiles; same results, bit for bit); RDHIP_DYNAMIC_TILES=0 in the environment keeps the static order, and so does a capturing stream. */
 int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                    const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);

@@ -740,7 +740,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // and handing out ALL tiles from it puts 256 atomics on one address in front of every workgroup's first tile (+1.5 us).  The plain order plus the
     // counter also beats the static XCD ranges above, which it replaces when the words are there.  sched = {next, done}: both zero between launches
     // -- the last workgroup to leave resets them.
-    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
+    // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
+    // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
+    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
     constexpr int DYN_STATIC = 3;
     __shared__ long long sched_ring[4];
     unsigned* sched = nullptr;
