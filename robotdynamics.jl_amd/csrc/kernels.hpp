@@ -742,7 +742,14 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // -- the last workgroup to leave resets them.
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
     // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
+#if defined(RD_DYN_F32)                          // tuning (tune/tune_dyn.hip -DTT=float): the counter for fp32 tiles too, RD_DYN_CHUNK tiles per atomic
+    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
+#else
     constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
+#endif
+#ifndef RD_DYN_CHUNK
+#define RD_DYN_CHUNK 1
+#endif
     constexpr int DYN_STATIC = 3;
     __shared__ long long sched_ring[4];
     unsigned* sched = nullptr;
@@ -813,6 +820,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = t0;
         }
         long long sched_pend = tile + 2 * tstep;           // thread 0: the tile fetched last (tile it + 2 while iteration it runs)
+        int sched_have = 1;                                // (RD_DYN_CHUNK > 1: how many consecutive tiles from sched_pend on are this workgroup's)
         if (dyn && threadIdx.x == 0) sched_ring[1] = tile + tstep;
         __syncthreads();                                   // barrier 0
         for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
@@ -877,7 +885,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             if (wave == 0) RD_STAMP(it, 2);
             if (dyn && threadIdx.x == 0) {                 // tile it + 2 becomes visible behind barrier B; tile it + 3 is requested
                 sched_ring[(it + 2) & 3] = sched_pend;
-                sched_pend = (long long)DYN_STATIC * nwg + __hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (RD_DYN_CHUNK > 1 && sched_have > 1) { ++sched_pend; --sched_have; }
+                else {
+                    sched_pend = (long long)DYN_STATIC * nwg + __hip_atomic_fetch_add(sched, (unsigned)RD_DYN_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sched_have = RD_DYN_CHUNK;
+                }
             }
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }

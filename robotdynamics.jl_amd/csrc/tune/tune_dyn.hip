@@ -9,7 +9,10 @@ using namespace rd;
 #ifndef KIND
 #define KIND 0
 #endif
-using Mdl = RigidBody<double, WRENCH_SATELLITE, false, true>;
+#ifndef TT
+#define TT double
+#endif
+using Mdl = RigidBody<TT, WRENCH_SATELLITE, false, true>;
 #if KIND == 1
 using Fn = IftFun<Mdl>;
 using Plan = typename IftPlanOf<Mdl>::Plan;
@@ -22,32 +25,33 @@ int main(int argc, char** argv) {
     const long long N = argc > 1 ? atoll(argv[1]) : 65536;
     const int reps = argc > 2 ? atoi(argv[2]) : 400;
     constexpr int NZ = 19, OW = 13 * NZ;
-    std::vector<double> hz((size_t)N * NZ), ht(N), hdt(N, 0.1);
+    std::vector<TT> hz((size_t)N * NZ); std::vector<double> ht(N), hdt(N, 0.1);
     for (long long k = 0; k < N; ++k) {
-        for (int i = 0; i < NZ; ++i) hz[k * NZ + i] = 0.1 + 0.8 * ((k * NZ + i) * 2654435761u % 1000) / 1000.0;
+        for (int i = 0; i < NZ; ++i) hz[k * NZ + i] = (TT)(0.1 + 0.8 * ((k * NZ + i) * 2654435761u % 1000) / 1000.0);
         double q2 = 0; for (int i = 3; i < 7; ++i) q2 += hz[k * NZ + i] * hz[k * NZ + i];
-        for (int i = 3; i < 7; ++i) hz[k * NZ + i] /= std::sqrt(q2);
+        for (int i = 3; i < 7; ++i) hz[k * NZ + i] /= (TT)std::sqrt(q2);
         ht[k] = 0.1 * k;
     }
     const int NB = N <= 262144 ? 4 : 2;
-    double *Z, *t, *dt, *J[4], *Y[4]; int* flag; unsigned* sc;
-    CK(hipMalloc(&Z, N * NZ * 8)); CK(hipMalloc(&t, N * 8)); CK(hipMalloc(&dt, N * 8)); CK(hipMalloc(&flag, (2 + N / 64) * 4)); CK(hipMemset(flag, 0, (2 + N / 64) * 4));
+    TT *Z, *J[4], *Y[4]; double *t, *dt; int* flag; unsigned* sc; constexpr size_t TS = sizeof(TT);
+    CK(hipMalloc(&Z, N * NZ * TS)); CK(hipMalloc(&t, N * 8)); CK(hipMalloc(&dt, N * 8)); CK(hipMalloc(&flag, (2 + N / 64) * 4)); CK(hipMemset(flag, 0, (2 + N / 64) * 4));
     CK(hipMalloc(&sc, 8)); CK(hipMemset(sc, 0, 8));
-    for (int b = 0; b < NB; ++b) { CK(hipMalloc(&J[b], N * OW * 8)); CK(hipMalloc(&Y[b], N * 13 * 8)); }
-    CK(hipMemcpy(Z, hz.data(), hz.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(t, ht.data(), ht.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dt, hdt.data(), hdt.size() * 8, hipMemcpyHostToDevice));
+    for (int b = 0; b < NB; ++b) { CK(hipMalloc(&J[b], N * OW * TS)); CK(hipMalloc(&Y[b], N * 13 * TS)); }
+    CK(hipMemcpy(Z, hz.data(), hz.size() * TS, hipMemcpyHostToDevice)); CK(hipMemcpy(t, ht.data(), ht.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dt, hdt.data(), hdt.size() * 8, hipMemcpyHostToDevice));
     double prm[10] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 1};
 #if KIND == 1
     Fn fn{Mdl::make(prm), 1e-12, flag, 10, 2, nullptr};
-    auto k = implicit_ift_split_kernel<Fn, double, Plan, 4>;
+    auto k = implicit_ift_split_kernel<Fn, TT, Plan, 4>;
 #else
     Fn fn{Mdl::make(prm)};
-    auto k = jac_ad_split_kernel<Fn, double, Plan, 4>;
+    auto k = jac_ad_split_kernel<Fn, TT, Plan, 4>;
 #endif
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    constexpr size_t lds = SplitLds<Fn, double, Plan, 4>::BYTES;
+    constexpr size_t lds = SplitLds<Fn, TT, Plan, 4>::BYTES;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int grid = (int)((N / 64) < 256 ? (N / 64) : 256);
+    const int ngrid = sizeof(TT) == 4 ? 512 : 256;     // (fp32: two workgroups per CU)
+    const int grid = (int)((N / 64) < ngrid ? (N / 64) : ngrid);
     unsigned* cur = nullptr;                           // the launch's counter words (NULL: static schedule)
     auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, fn, N, Z, t, dt, J[i % NB], Y[i % NB], cur); };
     for (int i = 0; i < 500; ++i) launch(i);
@@ -63,13 +67,13 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("KIND %d  N %lld  %s: %.2f us per launch\n", KIND, N, v ? "first 3 static + counter (>= 8 tiles per workgroup)" : "static                                              ", ms * 1e3 / reps);
     }
-    CK(hipMemset(Y[0], 0, N * 13 * 8)); CK(hipMemset(Y[1], 0, N * 13 * 8)); CK(hipMemset(J[0], 0, N * OW * 8)); CK(hipMemset(J[1], 0, N * OW * 8));
+    CK(hipMemset(Y[0], 0, N * 13 * TS)); CK(hipMemset(Y[1], 0, N * 13 * TS)); CK(hipMemset(J[0], 0, N * OW * TS)); CK(hipMemset(J[1], 0, N * OW * TS));
     CK(hipDeviceSynchronize());                        // (the stream is non-blocking: the memsets of the null stream must be over before the launches)
     cur = nullptr; launch(0); CK(hipStreamSynchronize(s));
     cur = sc; launch(1); launch(1); CK(hipStreamSynchronize(s));
-    std::vector<double> ja((size_t)N * OW), jb((size_t)N * OW), a((size_t)N * 13), b((size_t)N * 13);
-    CK(hipMemcpy(ja.data(), J[0], ja.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(jb.data(), J[1], jb.size() * 8, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(a.data(), Y[0], a.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), Y[1], b.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<TT> ja((size_t)N * OW), jb((size_t)N * OW), a((size_t)N * 13), b((size_t)N * 13);
+    CK(hipMemcpy(ja.data(), J[0], ja.size() * TS, hipMemcpyDeviceToHost)); CK(hipMemcpy(jb.data(), J[1], jb.size() * TS, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(a.data(), Y[0], a.size() * TS, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), Y[1], b.size() * TS, hipMemcpyDeviceToHost));
     size_t bad = 0; for (size_t i = 0; i < ja.size(); ++i) bad += ja[i] != jb[i]; for (size_t i = 0; i < a.size(); ++i) bad += a[i] != b[i];
     unsigned hc[2]; CK(hipMemcpy(hc, sc, 8, hipMemcpyDeviceToHost));
     printf("counter vs static outputs: %zu values differ; counters after the launches: %u %u\n", bad, hc[0], hc[1]);
