@@ -854,6 +854,11 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
             }
             p.total = acc;
             LaunchArgs a{}; a.stream = c->stream; a.multi = &md;
+            // dynamic tile schedule (kernels.hpp jac_split_loop) only for LONG trajectories: it gives up the resolved-tile ring, so every tile's descriptor is
+            // looked up in front of the compute waves' input prefetch -- a scalar-cache hit while consecutive tiles share a batch record, a memory round trip
+            // per tile when batches are one or two tiles long (1 024 x 101 knots: 40.7 -> 47.8 us with the counter, 4 096 x 101: 151 -> 166; 256 x 4 096:
+            // 374-387 -> 353 us)
+            a.sched = (acc >= 16LL * ng) ? take_sched(c, 0) : nullptr;
             const int k = family_jacobian(d, rule, diff, dtype, a);
             if (k == RDHIP_ERR_UNSUPPORTED && g0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff): decided before anything was launched
             if (k) return kernel_status(c, k, what);

@@ -159,7 +159,7 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
     auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
     return hip_status(hipGetLastError());
 }
 template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {

@@ -542,7 +542,8 @@ static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const L
         JitKernel* km; int rcm = jit_get(M, JOP_MULTI + mop, rule, dtype, &km); if (rcm) return rcm;
         std::vector<unsigned char> fnm; pack_params(M, dtype, fnm);
         MultiPod pod = a.multi->pod;
-        void* margs[] = {fnm.data(), &pod};
+        unsigned* msched = a.sched;                    // (the split-role multi kernel's last parameter; the tile multi kernel has none and ignores the entry)
+        void* margs[] = {fnm.data(), &pod, &msched};
         const int wm = km->block / 64;
         const unsigned gridm = km->small ? tile_grid(km->lds, km->block, (pod.total + wm - 1) / wm) : tile_grid(km->lds, km->block, pod.total);
         return launch(M, km, gridm, a.stream, margs);

@@ -288,8 +288,17 @@ RD_DEV long long uniform64(long long v) {
     const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
     return ((long long)hi << 32) | (unsigned int)lo;
 }
+// a batch table together with the launch's counter words of the dynamic tile schedule (jac_split_loop); the table stays where the kernel argument is
+template <class T> struct MultiBatchSched {
+    static constexpr bool RING = MultiBatch<T>::RING;
+    const MultiBatch<T>& m;
+    unsigned* sched;
+    RD_DEV long long ntiles() const { return m.ntiles(); }
+    RD_DEV TileRef<T> at(long long tile) const { return m.at(tile); }
+};
 template <class BT> struct LooksUp { static constexpr bool value = false; };
 template <class T> struct LooksUp<MultiBatch<T>> { static constexpr bool value = true; };
+template <class T> struct LooksUp<MultiBatchSched<T>> { static constexpr bool value = true; };
 // bt.at(tile) for a tile number that is the same in every lane of the wavefront: a descriptor with a table counts and subtracts in vector registers
 // (the compiler vectorises the branch-free search), so without this the tile's pointers and first knot point stay in VGPRs -- 14 registers across the
 // column code of a kernel at the 256-register limit, and a waterfall loop around every buffer store of the copy waves, whose resource must be scalar
@@ -743,9 +752,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
     // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
 #if defined(RD_DYN_F32)                          // tuning (tune/tune_dyn.hip -DTT=float): the counter for fp32 tiles too, RD_DYN_CHUNK tiles per atomic
-    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
+    constexpr bool DYN_OK = !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
 #else
-    constexpr bool DYN_OK = !GATHER && !BT::RING && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
+    constexpr bool DYN_OK = !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
 #endif
 #ifndef RD_DYN_CHUNK
 #define RD_DYN_CHUNK 1
@@ -831,7 +840,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const bool more = nxt < tend;
             // (the last iteration re-reads element 0 of its own batch: the loads stay unconditional)
             TileRef<T> nx;
-            if (RING_N > 0 && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
+            if (RING_N > 0 && !dyn && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
             else nx = at_uniform<T>(bt, more ? nxt : tile);
             if constexpr (WaitsOf<BT>::value) { if (more) bt.wait(nxt); }
             const long long k1 = nx.k0;
@@ -1028,7 +1037,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
                     // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
                     const long long nxt_tile = RD_NEXT_TILE(it);
-                    if (RING_N > 0 && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
+                    if (RING_N > 0 && !dyn && it + 1 < RING_N) nxt = nxt_tile < tend ? ring_get<T>(ring[it + 1]) : cur;
                     else nxt = at_uniform<T>(bt, nxt_tile < tend ? nxt_tile : tile);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1090,8 +1099,8 @@ __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? RD_F
 // FiniteDifference (plain or along the cascade), the UserDefined chain rule, the implicit-function-theorem columns.  MINB: minimum workgroups per
 // CU the register allocation must allow (the ForwardAD flagship keeps the occupancy of its single-batch kernel)
 template <class Fn, class T, class Plan, int NC, class Body, int MINB>
-__global__ void __launch_bounds__((Plan::NG + NC) * TILE, MINB) jac_split_multi_kernel(Fn fn, MultiBatch<T> mb) {
-    jac_split_loop<Fn, T, Plan, NC, Body>(fn, mb);
+__global__ void __launch_bounds__((Plan::NG + NC) * TILE, MINB) jac_split_multi_kernel(Fn fn, MultiBatch<T> mb, unsigned* sched) {
+    jac_split_loop<Fn, T, Plan, NC, Body>(fn, MultiBatchSched<T>{mb, sched});
 }
 template <class Fn, class T, class Plan, class Body>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_tile_multi_kernel(Fn fn, MultiBatch<T> mb) {

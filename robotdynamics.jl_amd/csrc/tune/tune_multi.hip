@@ -81,8 +81,8 @@ int main(int argc, char** argv) {
             }
         }
         const unsigned grid = (unsigned)(mb[0].total < 256 ? mb[0].total : 256);
-        timeit(c.name, knots, [&](int i) { hipLaunchKernelGGL(km, dim3(grid), dim3(512), lds, s, fn, mb[i % NBUF]); });
-        if (c.nb == 1024) { char nm[100]; snprintf(nm, sizeof nm, "%s grid 255", c.name); timeit(nm, knots, [&](int i) { hipLaunchKernelGGL(km, dim3(255), dim3(512), lds, s, fn, mb[i % NBUF]); }); }
+        timeit(c.name, knots, [&](int i) { hipLaunchKernelGGL(km, dim3(grid), dim3(512), lds, s, fn, mb[i % NBUF], (unsigned*)nullptr); });
+        if (c.nb == 1024) { char nm[100]; snprintf(nm, sizeof nm, "%s grid 255", c.name); timeit(nm, knots, [&](int i) { hipLaunchKernelGGL(km, dim3(255), dim3(512), lds, s, fn, mb[i % NBUF], (unsigned*)nullptr); }); }
     }
     // correctness spot check: single vs multi(16 x 4096) on buffer 0 / 1
     CK(hipStreamSynchronize(s));

@@ -448,3 +448,29 @@ def test_dynamic_tile_schedule_gives_what_the_static_one_gives():
         torch.cuda.synchronize()
         for b in range(4):
             assert torch.equal(Js[b], ref)
+
+
+def test_dynamic_tile_schedule_with_a_batch_table():
+    """rdhip_jacobian_multi on enough tiles for the dynamic schedule (>= 8 per workgroup, trajectories of >= 16 tiles on average): 70 equal
+    trajectories (one look-up per tile) and 72 ragged ones (two), the table on the device.  Every launch of a run of 40 (the context's ring of counter
+    words wraps) must leave the same bits, and sampled trajectories must agree with one rdhip_jacobian call each."""
+    rng = np.random.default_rng(909)
+    model = RD.Satellite()
+    dm = RD.DiscretizedDynamics(model, RD.RK4)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    n = RD.state_dim(model)
+    for sizes in ([4096] * 70, [4096, 2000, 3001] * 24):
+        Zs = [RD.PackedTrajectory(n, 6, H.rand_rigid(rng, N, 6), 0.1 * (b % 7) + np.arange(N) * 0.05, np.full(N, 0.05)).to("cuda") for b, N in enumerate(sizes)]
+        Js = [[RD.alloc_jacobians(dm, N, Zs[0].data) for N in sizes] for _ in range(2)]
+        Ys = [[torch.empty((N, n), dtype=torch.float64, device="cuda") for N in sizes] for _ in range(2)]
+        for i in range(40):
+            assert RD.jacobian_multi_(sig, AD, dm, Js[i & 1], Ys[i & 1], Zs) == 1
+        torch.cuda.synchronize()
+        for b in range(len(sizes)):
+            assert torch.equal(Js[0][b], Js[1][b]) and torch.equal(Ys[0][b], Ys[1][b]), b
+        for b in list(range(0, len(sizes), 9)) + [len(sizes) - 1]:
+            Jr = RD.alloc_jacobians(dm, sizes[b], Zs[b].data)
+            Yr = torch.empty((sizes[b], n), dtype=torch.float64, device="cuda")
+            RD.jacobian_(sig, AD, dm, Jr, Yr, Zs[b])
+            np.testing.assert_allclose(host(Js[0][b]), host(Jr), rtol=0, atol=1e-13)
+            np.testing.assert_allclose(host(Ys[0][b]), host(Yr), rtol=0, atol=1e-13)

@@ -352,6 +352,8 @@ def main():
         multi_case("64 x 1024 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 64, 1024, RD.RK4, f64, a.reps)
         multi_case("32 x 101 satellite RK4 jacobian ForwardAD", sat, lambda N: rigid_inputs(N, 6, rng), 32, 101, RD.RK4, f64, a.reps)
         multi_case("1024 x 101 satellite RK4 jacobian ForwardAD (the reference's unit at scale)", sat, lambda N: rigid_inputs(N, 6, rng), 1024, 101, RD.RK4, f64, a.reps, singles=False)
+        multi_case("4096 x 101 satellite RK4 jacobian ForwardAD (32 tiles per workgroup)", sat, lambda N: rigid_inputs(N, 6, rng), 4096, 101, RD.RK4, f64, a.reps, singles=False)
+        multi_case("256 x 4096 satellite RK4 jacobian ForwardAD (64 tiles per workgroup)", sat, lambda N: rigid_inputs(N, 6, rng), 256, 4096, RD.RK4, f64, a.reps, singles=False)
         multi_case("1024 x 101 satellite RK4 jacobian FiniteDifference", sat, lambda N: rigid_inputs(N, 6, rng), 1024, 101, RD.RK4, f64, a.reps, singles=False, diff=FD)
         multi_case("1024 x 101 cartpole RK4 jacobian ForwardAD", cart, lambda N: rng.random((N, 5)), 1024, 101, RD.RK4, f64, a.reps, singles=False)
         multi_case("16 x 4096 cartpole RK4 jacobian ForwardAD (C2 x 16)", cart, lambda N: rng.random((N, 5)), 16, 4096, RD.RK4, f64, a.reps)
