@@ -42,11 +42,11 @@ struct rdhip_ctx {
     // the upper half, so nothing is cleared between calls
     unsigned long long* d_progress = nullptr;
     unsigned long long roll_epoch = 0;
-    // dynamic tile schedule of the split-role Jacobian kernels (kernels.hpp jac_split_loop): a launch gets two counter words {next, done}, both zero
+    // dynamic tile schedule of the split-role Jacobian kernels (kernels.hpp jac_split_loop): a launch gets a slot of counter words {next, done, eight per-XCD-range counters}, all zero
     // between launches (the launch's last workgroup resets them).  One ring of words per stream of the context: launches of one stream run in order,
     // so a slot comes round again only behind the launch that used it.
-    static constexpr int NSCHED = 32;
-    unsigned* d_sched = nullptr;          // 2 streams x NSCHED slots x 2 words, allocated on first use (never inside a capture)
+    static constexpr int NSCHED = 32, SCHED_WORDS = 16;      // (a slot: next, done, eight per-XCD-range counters; 64 bytes)
+    unsigned* d_sched = nullptr;          // 2 streams x NSCHED slots x SCHED_WORDS words, allocated on first use (never inside a capture)
     unsigned sched_next[2] = {0, 0};
     int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
     bool allow_fused = true;              // rdhip_rollout_jacobian_multi lets ONE model of a call take the fused (spin-waiting) launch
@@ -672,12 +672,12 @@ static unsigned* take_sched(rdhip_ctx* c, int me) {
     static const bool off = [] { const char* e = getenv("RDHIP_DYNAMIC_TILES"); return e && e[0] == '0'; }();
     if (off || stream_is_capturing(c)) return nullptr;
     if (!c->d_sched) {
-        const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * 2 * sizeof(unsigned);
+        const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS * sizeof(unsigned);
         if (hipMalloc(&c->d_sched, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_sched = nullptr; return nullptr; }
         if (hipMemset(c->d_sched, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c->d_sched); c->d_sched = nullptr; return nullptr; }
     }
     const unsigned slot = c->sched_next[me]++ % rdhip_ctx::NSCHED;
-    return c->d_sched + ((size_t)me * rdhip_ctx::NSCHED + slot) * 2;
+    return c->d_sched + ((size_t)me * rdhip_ctx::NSCHED + slot) * rdhip_ctx::SCHED_WORDS;
 }
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {

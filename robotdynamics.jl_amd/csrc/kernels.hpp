@@ -213,7 +213,7 @@ template <class BT> struct GatherOf<BT, decltype((void)BT::GATHER)> { static con
 template <class T> struct SingleBatch {
     static constexpr bool RING = false;    // at() is arithmetic
     long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
-    unsigned* sched = nullptr;             // split-role loop: {next, done} words of the dynamic tile schedule (zero between launches), or NULL: static schedule
+    unsigned* sched = nullptr;             // split-role loop: the launch's counter words of the dynamic tile schedule (next, done, eight per-XCD-range counters; zero between launches), or NULL: static schedule
     RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
     RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
 };
@@ -739,7 +739,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         tile = xcd * ntx + (wg >> 3);
         tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
     } else { tile = t_begin + wg; tend = ntiles; tstep = nwg; }
-    // DYNAMIC schedule (descriptors that carry the two counter words; launches of >= 8 tiles per workgroup): a workgroup's first three tiles are wg,
+    // DYNAMIC schedule (descriptors that carry the launch's counter words; launches of >= 8 tiles per workgroup): a workgroup's first three tiles are wg,
     // wg + nwg, wg + 2 nwg, every further one comes from a device-wide counter, fetched by one lane THREE iterations ahead (the next tile's inputs are
     // requested a whole iteration early, so its number must be known two iterations early) in the quiet window between barriers A and B, where the
     // atomic does not queue behind a tile's stores.  Why: the XCDs do not run at the same rate (stamps, tune/tune_stamp.hip: last store issued 37 ..
@@ -747,8 +747,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // the further apart: 262 144 knots 100.8 -> 94.8 us, 524 288 202.8 -> 181.1, 1 M 398 (XCD ranges) -> 367, 4 M 1 857 -> 1 584 (tune/tune_dyn.hip,
     // same binary, alternating passes, identical outputs).  Below 8 tiles per workgroup the counter costs more than it returns (65 536 knots: +0.6 us),
     // and handing out ALL tiles from it puts 256 atomics on one address in front of every workgroup's first tile (+1.5 us).  The plain order plus the
-    // counter also beats the static XCD ranges above, which it replaces when the words are there.  sched = {next, done}: both zero between launches
-    // -- the last workgroup to leave resets them.
+    // counter also beats the static XCD ranges above, which it replaces when the words are there.  sched = {next, done, eight range counters (XR below)}:
+    // all zero between launches -- the last workgroup to leave resets them.
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
     // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
 #if defined(RD_DYN_F32)                          // tuning (tune/tune_dyn.hip -DTT=float): the counter for fp32 tiles too, RD_DYN_CHUNK tiles per atomic
@@ -764,11 +764,37 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     unsigned* sched = nullptr;
     if constexpr (DYN_OK) sched = SchedOf<BT>::get(bt);
     const bool dyn = DYN_OK && sched != nullptr && t_begin == 0 && t_end < 0 && ntiles >= 8 * (long long)nwg;
+    // XR: the counter per XCD RANGE.  Every XCD walks its own contiguous eighth of the tiles (what the static ranges did: one sequential stream per L2
+    // and translation cache), its 32 workgroups taking the range's tiles from the range's counter (words 2 .. 9 of the slot); a workgroup whose range
+    // is used up moves on to the next XCD's range, so a fast XCD finishes a slow one's work.
+    // Measured against the one counter over the plain order (tune/tune_dyn.hip -DRD_DYN_XR=..., two boxes): 2 M knots 792 -> 766 and 791 -> 716 us, 4 M
+    // 1 581 -> 1 518 and 1 567 -> 1 426 us (0.78-0.83 of the roofline), but 1 M 317 -> 328 and 322 -> 336 us: from 128 tiles per workgroup on.
+#ifndef RD_DYN_XR
+#define RD_DYN_XR 128
+#endif
+    const bool xr = dyn && (nwg & 7) == 0 && ntiles >= RD_DYN_XR * (long long)nwg;
+    const long long xr_ntx = (ntiles + 7) / 8;
+    const int xr_nxw = (int)(nwg >> 3), xr_own = (int)(wg & 7);
     if (dyn) { tile = wg; tend = ntiles; tstep = nwg; }        // (plain order, whatever the static map would have been)
+    if (xr) { tile = xr_own * xr_ntx + (wg >> 3); tstep = xr_nxw; }   // the first DYN_STATIC tiles: the head of the own range, strided over the XCD's workgroups
     auto leave = [&]() {                                       // (one thread per workgroup)
         if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
             __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (xr) for (int x = 0; x < 8; ++x) __hip_atomic_store(sched + 2 + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // XR, thread 0: the counter value `a` drawn from range `v` as a tile number; if that range is used up, draw from the following ranges (waiting for each
+    // answer: at most seven times per workgroup and launch, at its end); ntiles = nothing left anywhere
+    int xr_victim = xr_own;
+    auto xr_resolve = [&](unsigned a) -> long long {
+        for (;;) {
+            const long long rend = (xr_victim + 1) * xr_ntx < ntiles ? (xr_victim + 1) * xr_ntx : ntiles;
+            const long long t = xr_victim * xr_ntx + (long long)DYN_STATIC * xr_nxw + a;
+            if (t < rend) return t;
+            xr_victim = (xr_victim + 1) & 7;
+            if (xr_victim == xr_own) { xr_victim = -1; return ntiles; }
+            a = __hip_atomic_fetch_add(sched + 2 + xr_victim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     if (tile >= tend) { if (dyn && threadIdx.x == 0) leave(); return; }
@@ -830,6 +856,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         }
         long long sched_pend = tile + 2 * tstep;           // thread 0: the tile fetched last (tile it + 2 while iteration it runs)
         int sched_have = 1;                                // (RD_DYN_CHUNK > 1: how many consecutive tiles from sched_pend on are this workgroup's)
+        unsigned xr_raw = 0; bool xr_pending = false;      // XR: a counter value that has not been turned into a tile number yet
         if (dyn && threadIdx.x == 0) sched_ring[1] = tile + tstep;
         __syncthreads();                                   // barrier 0
         for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
@@ -893,11 +920,18 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             __syncthreads();                               // barrier A: tile complete; all compute waves are done with zs/ts
             if (wave == 0) RD_STAMP(it, 2);
             if (dyn && threadIdx.x == 0) {                 // tile it + 2 becomes visible behind barrier B; tile it + 3 is requested
+                if (xr) {
+                    if (xr_pending) sched_pend = xr_resolve(xr_raw);
+                    sched_ring[(it + 2) & 3] = sched_pend;
+                    if (xr_victim >= 0) { xr_raw = __hip_atomic_fetch_add(sched + 2 + xr_victim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); xr_pending = true; }
+                    else { sched_pend = ntiles; xr_pending = false; }
+                } else {
                 sched_ring[(it + 2) & 3] = sched_pend;
                 if (RD_DYN_CHUNK > 1 && sched_have > 1) { ++sched_pend; --sched_have; }
                 else {
                     sched_pend = (long long)DYN_STATIC * nwg + __hip_atomic_fetch_add(sched, (unsigned)RD_DYN_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sched_have = RD_DYN_CHUNK;
+                }
                 }
             }
 #pragma unroll

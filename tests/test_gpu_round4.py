@@ -474,3 +474,31 @@ def test_dynamic_tile_schedule_with_a_batch_table():
             RD.jacobian_(sig, AD, dm, Jr, Yr, Zs[b])
             np.testing.assert_allclose(host(Js[0][b]), host(Jr), rtol=0, atol=1e-13)
             np.testing.assert_allclose(host(Ys[0][b]), host(Yr), rtol=0, atol=1e-13)
+
+
+def test_tile_counters_per_xcd_range_with_stealing():
+    """From 128 tiles per workgroup on (2 M knot points on a whole chip) every XCD walks its own eighth of the tiles with a counter of its own, and a
+    workgroup whose range is used up takes tiles from the next XCD's range (kernels.hpp jac_split_loop, XR).  2 097 189 satellite knots (a ragged
+    last tile) must give bit for bit what the two halves give in separate calls (64 tiles per workgroup: one counter over the plain order), three
+    launches in a row (all ten counter words are reset by the last workgroup of a launch)."""
+    rng = np.random.default_rng(1212)
+    model, dm = RD.Satellite(), RD.DiscretizedDynamics(RD.Satellite(), RD.RK4)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    half = 128 * 256 * 64 // 2
+    N = 2 * half + 37
+    Zn = H.rand_rigid(rng, N, 6)
+    t, dt = np.arange(N) * 0.05, np.full(N, 0.05)
+    whole = RD.PackedTrajectory(13, 6, Zn, t, dt).to("cuda")
+    J = RD.alloc_jacobians(dm, N, whole.data)
+    Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        RD.jacobian_(sig, AD, dm, J, Y, whole)
+    assert "jac_ad_split_kernel" in RD.last_kernel_name()
+    for lo, hi in ((0, half), (half, N)):
+        Zp = RD.PackedTrajectory(13, 6, Zn[lo:hi], t[lo:hi], dt[lo:hi]).to("cuda")
+        Jp = RD.alloc_jacobians(dm, hi - lo, Zp.data)
+        Yp = torch.empty((hi - lo, 13), dtype=torch.float64, device="cuda")
+        RD.jacobian_(sig, AD, dm, Jp, Yp, Zp)
+        torch.cuda.synchronize()
+        assert torch.equal(J[lo:hi], Jp) and torch.equal(Y[lo:hi], Yp)
+        del Jp, Yp, Zp
