@@ -157,6 +157,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));          // word 0 = epoch of the last call that raised a tile word (0: none yet)
     if (e == hipSuccess) e = hipMalloc(&c->d_progress, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_progress, 0, (size_t)PROGRESS_WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);          // (the memsets above run on the null stream, which a non-blocking stream's launches are not ordered behind)
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
@@ -674,7 +675,10 @@ static unsigned* take_sched(rdhip_ctx* c, int me) {
     if (!c->d_sched) {
         const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS * sizeof(unsigned);
         if (hipMalloc(&c->d_sched, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_sched = nullptr; return nullptr; }
-        if (hipMemset(c->d_sched, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c->d_sched); c->d_sched = nullptr; return nullptr; }
+        // zeroed ON the context's stream and waited for (once per context): a memset of the null stream is not ordered against a non-blocking stream's launches
+        if (hipMemsetAsync(c->d_sched, 0, bytes, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(c->d_sched); c->d_sched = nullptr; return nullptr;
+        }
     }
     const unsigned slot = c->sched_next[me]++ % rdhip_ctx::NSCHED;
     return c->d_sched + ((size_t)me * rdhip_ctx::NSCHED + slot) * rdhip_ctx::SCHED_WORDS;
