@@ -314,7 +314,9 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * latency chain -- for the RigidBody{QuatRotation} models (satellite, quadrotor), explicit rules, RDHIP_FORWARD_AD, RDHIP_TIME_MAJOR data with
  * 16-byte aligned J and M * n * (n+m) * sizeof(T) a multiple of 16 (M even in fp64, a multiple of 4 in fp32) and at most half as many 64-trajectory
  * groups as the device has compute units; every other combination runs the two launches back to back.  rdhip_ctx_last_rollout_jacobian_launches
- * says which (1 = overlapped).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
+ * says which (1 = overlapped).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are
+ * latency-sized; from 262 144 knot points on they run the two launches, which is faster there (4 096 x 101 fp64 knots: 204 vs 250 us;
+ * RDHIP_FUSED_TJ_MAX_KNOTS in the environment moves the limit).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
  * The Jacobian workgroups of the overlapped launch hold their compute unit while they wait for the rollout workgroups of the SAME launch; the
  * library therefore keeps at most one such launch in flight per device and process (a second one, from any context, is ordered behind the first by
  * an event edge).  Outside its reach: launches replayed from captured graphs side by side, and other processes sharing the GPU -- do not run two of

@@ -1077,7 +1077,13 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
     c->last_rolljac_launches = 0;
     LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1;
-    if (!implicit && c->allow_fused && family_rolljac(d, rule, diff, dtype, f) == RDHIP_OK) {      // (probe: nothing is launched)
+    // A TRAJECTORY-major stack of bandwidth size goes the two-launch way: its fused form gathers tiles of 4 trajectories x 16 knots (ragged when K is not a
+    // multiple of 16, short runs of output) and was measured SLOWER than rollout + Jacobians in two launches from a few hundred thousand knot points
+    // on (4 096 x 101 fp64: 252 vs 221 us; 16 384 x 64: 365 vs 365; the latency-sized 512 x 256 fp32: 138 vs 148, so small stacks stay fused); the
+    // Jacobian launch over the contiguous stack then also gets the dynamic tile schedule.  Time-major stacks are faster fused at every size measured.
+    static const long long tj_max = [] { const char* e = getenv("RDHIP_FUSED_TJ_MAX_KNOTS"); return e ? atoll(e) : 262144LL; }();
+    const bool tj_two_launches = layout != RDHIP_TIME_MAJOR && N >= tj_max;
+    if (!implicit && c->allow_fused && !tj_two_launches && family_rolljac(d, rule, diff, dtype, f) == RDHIP_OK) {      // (probe: nothing is launched)
         // ONE launch: rollout workgroups + Jacobian workgroups that consume finished chunks through progress words (fused.hpp)
         f.probe = 0;
         const bool capturing = stream_is_capturing(c);
@@ -1089,7 +1095,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
         if (kf != RDHIP_ERR_UNSUPPORTED) { c->last_rolljac_launches = 1; const int k = kernel_status(c, kf, what); return memspace == RDHIP_HOST ? s.finish(k) : k; }
     }
     int k = kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
-    if (!k) k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what);
+    if (!k) { j.sched = take_sched(c, 0); k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what); }
     c->last_rolljac_launches = 2;
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
