@@ -485,10 +485,11 @@ template <class Fn, class T, class Plan, class Cas> struct FdCascadeBody {
         waves<0>(fn, fr, f0, S);
     }
 };
-template <class Fn, class T, class Plan, class Cas, int NC>
+template <class Fn, class T, class Plan, class Cas, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_cascade_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                  const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, FdCascadeBody<Fn, T, Plan, Cas>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, FdCascadeBody<Fn, T, Plan, Cas>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, J, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, FdCascadeBody<Fn, T, Plan, Cas>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 template <class Fn, class T, class Cas, int R, int B, bool PUB = false> struct CascadeWaves {

@@ -122,15 +122,29 @@ template <class Fn, class T, class Plan, class K> int launch_jac_kernel(K kernel
     return hip_status(hipGetLastError());
 }
 
-template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
+template <class Fn, class T, class Plan, int NC, class K, class KD> int launch_split_kernel(K kernel, KD kernel_dyn, const Fn& fn, const LaunchArgs& a) {
     constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
-    if (e != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
-    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
+    // the instantiation with the dynamic tile schedule (kernels.hpp jac_split_loop) when the launch has counter words and 8 or more tiles per workgroup
+    if constexpr (!std::is_same<K, KD>::value) {
+        if (a.sched) {
+            const unsigned gd = tile_grid_occ(reinterpret_cast<const void*>(kernel_dyn), lds, threads, ntiles);
+            if (ntiles >= 8LL * gd) {
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_dyn), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                RD_LAUNCH(kernel_dyn, dim3(gd), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
+                return hip_status(hipGetLastError());
+            }
+        }
+    }
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (e != hipSuccess) return RDHIP_ERR_HIP;
+    RD_LAUNCH(kernel, dim3(tile_grid_occ(reinterpret_cast<const void*>(kernel), lds, threads, ntiles)), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, (unsigned*)nullptr);
     return hip_status(hipGetLastError());
+}
+template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
+    return launch_split_kernel<Fn, T, Plan, NC>(kernel, kernel, fn, a);
 }
 
 // the same loop for kernels without a separate f(z) output (signature ..., J)
@@ -156,10 +170,21 @@ template <class T> MultiBatch<T> to_multi_batch(const MultiDesc& md) {
 template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int launch_split_multi(const Fn& fn, const LaunchArgs& a) {
     constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    constexpr int threads = (Plan::NG + NC) * TILE;
+    if constexpr (sizeof(T) == 8) {                      // the instantiation with the dynamic tile schedule (see launch_split_kernel)
+        if (a.sched) {
+            auto kd = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB, true>;
+            const unsigned gd = tile_grid_occ(reinterpret_cast<const void*>(kd), lds, threads, a.multi->pod.total);
+            if (a.multi->pod.total >= 8LL * gd) {
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kd), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                RD_LAUNCH(kd, dim3(gd), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
+                return hip_status(hipGetLastError());
+            }
+        }
+    }
     auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-    constexpr int threads = (Plan::NG + NC) * TILE;
-    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
+    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), (unsigned*)nullptr);
     return hip_status(hipGetLastError());
 }
 template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {
@@ -261,22 +286,26 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             if constexpr (NC > 0) {
                 // compute/copy split-role kernel: needs 16-byte aligned output slabs (a tile is copied as 16-byte units)
                 if (aligned16(a.J) && aligned16(a.Y))
-                    return launch_split_kernel<Fn, T, Plan, NC>(jac_ad_split_kernel<Fn, T, Plan, NC>, fn, a);
+                    { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, NC>(jac_ad_split_kernel<Fn, T, Plan, NC>, jac_ad_split_kernel<Fn, T, Plan, NC, true>, fn, a);
+                      else return launch_split_kernel<Fn, T, Plan, NC>(jac_ad_split_kernel<Fn, T, Plan, NC>, fn, a); }
             }
             return launch_jac_kernel<Fn, T, Plan>(jac_ad_unrolled_kernel<Fn, T, Plan>, fn, a);
         } else {
             if constexpr (split_fits)
-                if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, fn, a);
+                if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, jac_ad_loop_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
+                  else return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, fn, a); }
             return launch_jac_kernel<Fn, T, DefPlan>(jac_ad_loop_kernel<Fn, T, DefPlan>, fn, a);
         }
     } else if (diff == RDHIP_FINITE_DIFF) {
         // models with a cascade structure and a column plan: perturbed evaluations integrate only the blocks a column can change (cascade.hpp)
         if constexpr (RULE != RULE_CONTINUOUS && Cascade<Mdl>::NB > 1 && FdPlanOf<Mdl>::value) {
             using Plan = typename FdPlanOf<Mdl>::Plan;
-            if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, fn, a);
+            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4, true>, fn, a);
+              else return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, fn, a); }
         }
         if constexpr (split_fits)
-            if (aligned16(a.J) && aligned16(a.Y)) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, fn, a);
+            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, jac_fd_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
+              else return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, fn, a); }
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
     } else if (diff == RDHIP_USER_DEFINED) {
         if constexpr (Mdl::HAS_USER_JACOBIAN) {
@@ -284,7 +313,8 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
                 using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
                 constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
                 if (aligned16(a.J) && aligned16(a.Y))
-                    return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, fn, a);
+                    { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, jac_chain_split_kernel<Fn, T, Plan, NC, true>, fn, a);
+                      else return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, fn, a); }
             }
             return launch_jac_kernel<Fn, T, DefPlan>(jac_chain_kernel<Fn, T, DefPlan>, fn, a);
         }
@@ -377,7 +407,8 @@ template <class Mdl, int RULE> int launch_errexp(const Mdl& m, const LaunchArgs&
     if (a.N == 0) return RDHIP_OK;
     if (!aligned16(a.J) || !aligned16(a.Y)) return RDHIP_ERR_INVALID_ARG;
     Fn fn{{m}};
-    return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, fn, a);
+    { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, jac_errexp_split_kernel<Fn, T, Plan, NC, true>, fn, a);
+      else return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, fn, a); }
 }
 template <class Mdl> int dispatch_errexp_rule(const Mdl& m, int rule, const LaunchArgs& a) {
     switch (rule) {

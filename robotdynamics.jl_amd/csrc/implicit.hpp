@@ -847,7 +847,8 @@ template <class Fn, class T, class Plan> struct IftBody {
 template <class Fn, class T, class Plan, int NC>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) implicit_ift_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                      const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Xn, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, IftBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Xn, sched});
+    (void)sched;                                           // (helper wave + epilogue: static schedule)
+    jac_split_loop<Fn, T, Plan, NC, IftBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Xn});
 }
 
 template <class Mdl, class T>

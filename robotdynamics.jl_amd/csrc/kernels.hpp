@@ -213,12 +213,15 @@ template <class BT> struct GatherOf<BT, decltype((void)BT::GATHER)> { static con
 template <class T> struct SingleBatch {
     static constexpr bool RING = false;    // at() is arithmetic
     long long N; const T* Z; const double* t; const double* dt; T* J; T* Y;
-    unsigned* sched = nullptr;             // split-role loop: the launch's counter words of the dynamic tile schedule (next, done, eight per-XCD-range counters; zero between launches), or NULL: static schedule
     RD_DEV long long ntiles() const { return (N + TILE - 1) / TILE; }
     RD_DEV TileRef<T> at(long long tile) const { return TileRef<T>{Z, t, dt, J, Y, N, tile * TILE}; }
 };
-template <class BT, class = void> struct SchedOf { static RD_DEV unsigned* get(const BT&) { return nullptr; } };
-template <class BT> struct SchedOf<BT, decltype((void)&BT::sched)> { static RD_DEV unsigned* get(const BT& bt) { return bt.sched; } };
+// the same with the launch's counter words of the dynamic tile schedule (next, done, eight per-XCD-range counters; zero between launches).  A type of its
+// own, and the kernels that take it instantiations of their own (template parameter DYN): compiled into the one kernel, the dormant schedule cost the
+// 65 536-knot launch -- four tiles per workgroup, static -- 0.3-0.5 us of 27 (five registers, an LDS word read per iteration and role)
+template <class T> struct SingleBatchDyn : SingleBatch<T> { unsigned* sched; };
+template <class BT, class = void> struct SchedOf { static constexpr bool HAS = false; static RD_DEV unsigned* get(const BT&) { return nullptr; } };
+template <class BT> struct SchedOf<BT, decltype((void)&BT::sched)> { static constexpr bool HAS = true; static RD_DEV unsigned* get(const BT& bt) { return bt.sched; } };
 constexpr int MULTI_MAXB = 32;
 template <class T> struct MultiRec { const T* Z; const double* t; const double* dt; T* J; T* Y; long long N; long long pad[2]; };   // 64 bytes: one scalar load
 template <class T> struct MultiBatch {
@@ -752,9 +755,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
     // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
 #if defined(RD_DYN_F32)                          // tuning (tune/tune_dyn.hip -DTT=float): the counter for fp32 tiles too, RD_DYN_CHUNK tiles per atomic
-    constexpr bool DYN_OK = !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
+    constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
 #else
-    constexpr bool DYN_OK = !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
+    constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
 #endif
 #ifndef RD_DYN_CHUNK
 #define RD_DYN_CHUNK 1
@@ -1124,17 +1127,19 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
 #undef RD_NEXT_TILE
 template <class Fn, class T, class Plan, int NC, class Body, class BT>
 RD_DEV void jac_split_loop(const Fn& fn, const BT& bt) { jac_split_loop<Fn, T, Plan, NC, Body, BT>(fn, bt, blockIdx.x, gridDim.x); }
-template <class Fn, class T, class Plan, int NC>
+template <class Fn, class T, class Plan, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE, (sizeof(T) == 4 ? RD_F32_MINB : 1)) jac_ad_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, J, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 // the same loops over several independent packed trajectories (rdhip_jacobian_multi), for ANY body: ForwardAD with compile-time or run-time columns,
 // FiniteDifference (plain or along the cascade), the UserDefined chain rule, the implicit-function-theorem columns.  MINB: minimum workgroups per
 // CU the register allocation must allow (the ForwardAD flagship keeps the occupancy of its single-batch kernel)
-template <class Fn, class T, class Plan, int NC, class Body, int MINB>
+template <class Fn, class T, class Plan, int NC, class Body, int MINB, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE, MINB) jac_split_multi_kernel(Fn fn, MultiBatch<T> mb, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, Body>(fn, MultiBatchSched<T>{mb, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, Body>(fn, MultiBatchSched<T>{mb, sched});
+    else jac_split_loop<Fn, T, Plan, NC, Body>(fn, mb);
 }
 template <class Fn, class T, class Plan, class Body>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_tile_multi_kernel(Fn fn, MultiBatch<T> mb) {
@@ -1333,10 +1338,11 @@ template <class Fn, class T, class Plan> struct ErrUnrolledBody {
         waves<CH, 0>(fn, fr, qc, qn);
     }
 };
-template <class Fn, class T, class Plan, int NC>
+template <class Fn, class T, class Plan, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_errexp_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                    const double* __restrict__ dtt, T* __restrict__ E, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, E, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, E, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, ErrUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, E, Y});
 }
 
 // ---- small models (n + m <= 10): ONE wave owns 64 knot points and ALL Jacobian columns ---------------------------------
@@ -1498,10 +1504,11 @@ template <class Fn, class T, class Plan> struct AdLoopBody {
         }
     }
 };
-template <class Fn, class T, class Plan, int NC>
+template <class Fn, class T, class Plan, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_ad_loop_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                     const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, J, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, AdLoopBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_ad_loop_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
@@ -1695,10 +1702,11 @@ template <class Fn, class T, class Plan> struct ChainUnrolledBody {
         waves<CH, 0>(fn, fr, x2, x3, x4);
     }
 };
-template <class Fn, class T, class Plan, int NC>
+template <class Fn, class T, class Plan, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_chain_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                   const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, J, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 
 // ---- FiniteDifference: forward differences, eps_j = max(sqrt(eps)|z_j|, sqrt(eps)) (FiniteDiff.jl default) -----
@@ -1739,10 +1747,11 @@ template <class Fn, class T, class Plan> struct FdBody {
         }
     }
 };
-template <class Fn, class T, class Plan, int NC>
+template <class Fn, class T, class Plan, int NC, bool DYN = false>
 __global__ void __launch_bounds__((Plan::NG + NC) * TILE) jac_fd_split_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
                                                                                const double* __restrict__ dtt, T* __restrict__ J, T* __restrict__ Y, unsigned* sched) {
-    jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y, sched});
+    if constexpr (DYN) jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatchDyn<T>{{N, Z, tt, dtt, J, Y}, sched});
+    else jac_split_loop<Fn, T, Plan, NC, FdBody<Fn, T, Plan>>(fn, SingleBatch<T>{N, Z, tt, dtt, J, Y});
 }
 template <class Fn, class T, class Plan>
 __global__ void __launch_bounds__(Plan::NG * TILE) jac_fd_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,

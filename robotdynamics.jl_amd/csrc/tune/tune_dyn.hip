@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
 #else
     Fn fn{Mdl::make(prm)};
     auto k = jac_ad_split_kernel<Fn, TT, Plan, 4>;
+    auto kd = jac_ad_split_kernel<Fn, TT, Plan, 4, true>;          // the instantiation with the dynamic schedule
 #endif
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     constexpr size_t lds = SplitLds<Fn, TT, Plan, 4>::BYTES;
@@ -53,7 +54,12 @@ int main(int argc, char** argv) {
     const int ngrid = sizeof(TT) == 4 ? 512 : 256;     // (fp32: two workgroups per CU)
     const int grid = (int)((N / 64) < ngrid ? (N / 64) : ngrid);
     unsigned* cur = nullptr;                           // the launch's counter words (NULL: static schedule)
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, fn, N, Z, t, dt, J[i % NB], Y[i % NB], cur); };
+#if KIND == 1
+    auto kd = k;
+#endif
+    CK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto launch = [&](int i) { if (cur) hipLaunchKernelGGL(kd, dim3(grid), dim3(512), lds, s, fn, N, Z, t, dt, J[i % NB], Y[i % NB], cur);
+                               else hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, fn, N, Z, t, dt, J[i % NB], Y[i % NB], cur); };
     for (int i = 0; i < 500; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     float ms;
