@@ -128,8 +128,8 @@ template <class Fn, class T, class Plan, int NC, class K, class KD> int launch_s
     const long long ntiles = (a.N + TILE - 1) / TILE;
     constexpr int threads = (Plan::NG + NC) * TILE;
     // the instantiation with the dynamic tile schedule (kernels.hpp jac_split_loop) when the launch has counter words and 8 or more tiles per workgroup
-    if constexpr (!std::is_same<K, KD>::value) {
-        if (a.sched) {
+    {   // (the two are pointers of one type: the same pointer twice means "no such instantiation")
+        if (a.sched && reinterpret_cast<const void*>(kernel_dyn) != reinterpret_cast<const void*>(kernel)) {
             const unsigned gd = tile_grid_occ(reinterpret_cast<const void*>(kernel_dyn), lds, threads, ntiles);
             if (ntiles >= 8LL * gd) {
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_dyn), lds) != hipSuccess) return RDHIP_ERR_HIP;
