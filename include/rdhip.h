@@ -64,7 +64,8 @@ typedef enum { RDHIP_FRAME_WORLD = 0, RDHIP_FRAME_BODY = 1 } rdhip_velocity_fram
 /* QuadratureRule (src/integration.jl:69,109,258; RK2 = v0.3 explicit midpoint); RDHIP_CONTINUOUS = no discretisation */
 /* RDHIP_IMPLICIT_MIDPOINT (src/integration.jl:620-729): x1 + h f((x1+x2)/2, u1) - x2 = 0 solved by Newton's method (src/integration.jl:422-463);
  * accepted by rdhip_discrete_dynamics, rdhip_jacobian (implicit function theorem, src/integration.jl:517-538), rdhip_dynamics_error[_jacobian] */
-typedef enum { RDHIP_CONTINUOUS = -1, RDHIP_EULER = 0, RDHIP_RK2 = 1, RDHIP_RK3 = 2, RDHIP_RK4 = 3, RDHIP_IMPLICIT_MIDPOINT = 4 } rdhip_rule;
+/* RDHIP_DISCRETE: the model's OWN step -- the only rule of a user-defined DiscreteDynamics model (rdhip_model_create_custom_discrete), and of no other model */
+typedef enum { RDHIP_CONTINUOUS = -1, RDHIP_EULER = 0, RDHIP_RK2 = 1, RDHIP_RK3 = 2, RDHIP_RK4 = 3, RDHIP_IMPLICIT_MIDPOINT = 4, RDHIP_DISCRETE = 5 } rdhip_rule;
 typedef enum { RDHIP_FORWARD_AD = 0, RDHIP_FINITE_DIFF = 1, RDHIP_USER_DEFINED = 2 } rdhip_diffmethod; /* src/functionbase.jl:109-120 */
 typedef enum { RDHIP_F64 = 0, RDHIP_F32 = 1 } rdhip_dtype;
 typedef enum { RDHIP_DEVICE = 0, RDHIP_HOST = 1 } rdhip_memspace;
@@ -144,6 +145,29 @@ int rdhip_model_destroy(rdhip_model* model);
  * processes load them instead of compiling. */
 int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const char* preamble, const double* params, int nparams,
                               int rotation, const int* P, int nP, rdhip_model** out);
+/* The user's OWN Jacobian of a custom continuous model -- `jacobian!(model, J, xdot, x, u, t)`, src/dynamics.jl:115-116 (test/cartpole_model.jl:57-96 is the
+ * cartpole's) -- as the body of
+ *       __device__ void jac(const T* x, const T* u, T t, T* J) const        J: n x (n+m), column-major (J[i + n * j]), ZERO on entry
+ * in plain T arithmetic (sin, cos, sqrt ... are the HIP device functions; p[i] the parameters).  RDHIP_USER_DEFINED then evaluates THESE formulas:
+ * directly for rule RDHIP_CONTINUOUS, and through the integrators' chain rule on the stage Jacobians (src/integration.jl:85-93, :149-177, :302-337:
+ * the reference's literal recipe) for Euler / RK2 / RK3 / RK4 of models with n + m <= 10.  Bigger discretized models keep what every custom model
+ * without a Jacobian body gets: the same chain rule taken matrix-free on forward duals of the dynamics (equal in exact arithmetic; the user's
+ * formulas are then not consulted).  NULL or "" removes the body.  Compiled kernels of the model are discarded. */
+int rdhip_model_set_user_jacobian(rdhip_model* model, const char* jacobian_body);
+/* A user-defined DiscreteDynamics model -- `discrete_dynamics(model, x, u, t, dt)` on a DiscreteDynamics subtype, src/discrete_dynamics.jl:1-108
+ * (test/discrete_dynamics_test.jl:5-63 is the reference's discrete double integrator) -- given as the body of
+ *       template <class S> __device__ void step(const S* x, const S* u, T t, T h, S* xn) const
+ * (S as for rdhip_model_create_custom; t and h = the knot point's time and time step, plain T) and, optionally (NULL: none), the body of its own
+ *       __device__ void jac(const T* x, const T* u, T t, T h, T* J) const   -- `jacobian!(model, J, xn, x, u, t, dt)`, src/discrete_dynamics.jl:111-113
+ * with J as above.  Every call on such a model takes rule = RDHIP_DISCRETE and nothing else (it has no quadrature rule and no continuous
+ * dynamics: rdhip_dynamics and the implicit rule answer RDHIP_ERR_INVALID_ARG): rdhip_discrete_dynamics, rdhip_jacobian[_multi] with RDHIP_FORWARD_AD (the
+ * reference's default for a DiscreteDynamics model, what `@autodiff` generates) / RDHIP_FINITE_DIFF / RDHIP_USER_DEFINED (the jac body;
+ * RDHIP_ERR_NOT_IMPLEMENTED without one, "User-defined discrete dynamics Jacobian not defined."), rdhip_rollout[_layout], rdhip_rollout_jacobian[_multi],
+ * rdhip_dynamics_error[_jacobian] (J2 = [-I 0], src/discrete_dynamics.jl:186-201) and, with a LieState partition, the error-state operators and
+ * rdhip_error_expansion.  No cascade declaration, no column balancing (rdhip_model_set_cascade / _balance_columns: continuous models). */
+int rdhip_model_create_custom_discrete(int n, int m, const char* step_body, const char* jacobian_body, const char* preamble, const double* params, int nparams,
+                                       int rotation, const int* P, int nP, rdhip_model** out);
+int rdhip_model_is_discrete(const rdhip_model* model, int* discrete);
 /* setnewtoniters / setnewtontolerance of an ImplicitDynamicsModel (src/discretized_dynamics.jl:225-228); defaults 10 and 1e-12
  * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol. */
 int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_tol);
@@ -183,6 +207,20 @@ int rdhip_model_gen_inds(const rdhip_model* model, int first[5], int len[5]);
 int rdhip_liestate_query(int rotation, const int* P, int nP, int* length, int* errstate_dim, int* rot_first, int* vec_first);
 
 /* ---------------------------------------------------------------- batched hot path ------------------- */
+/* NaN / Inf CONTRACT of every batched entry point.  The reference creates trajectories filled with NaN (src/trajectories.jl:83) and stores dt = Inf on
+ * a last knot point that carries a control (:104-108), so both reach these calls.
+ *   - A knot point (or trajectory) that holds a NaN or an Inf changes NOTHING about the others: knot points are independent, and a poisoned one's
+ *     neighbours in its 64-knot tile get the bits they get without it.  One exception, to rounding (1e-13), not to the bit: ImplicitMidpoint
+ *     Jacobians, where a tile with a knot point whose Newton iteration does not converge is redone by the exact LDS kernel, whose operation order
+ *     differs from the register kernel's.
+ *   - Every call returns: Newton stops at its iteration limit (a NaN residual never passes the convergence test), no loop waits for a value.
+ *   - Function values (dynamics, discrete dynamics, x_next, errors, rollouts from that knot on) are NaN in every component whose formula reads the
+ *     poisoned input; `dt === 0` is tested on the bit pattern, so dt = NaN / Inf is "not terminal".
+ *   - Jacobian entries of a poisoned knot point are NaN wherever the entry's formula reads the poisoned input, and may be FINITE elsewhere: tangent
+ *     seeds are compile-time constants here, so the `0 * NaN` products by which ForwardDiff spreads a NaN into every entry do not exist (a NaN force
+ *     control of the satellite leaves d x_next / d u finite: the step is linear in u).  Structural zeros stay exact zeros.
+ * (The library is built with -ffinite-math-only -- it is what lets the compiler fold those seeds; comparisons whose operand may be NaN are done on
+ * bit patterns.  tests/test_gpu_round5.py holds the contract to the kernels.) */
 /* dynamics(model, z) for every knot point: src/dynamics.jl:81-83 (RigidBody: src/rigidbody.jl:213-236).
  * Xdot: n x N. */
 int rdhip_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
@@ -313,8 +351,11 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * word, Jacobian workgroups on the rest of the chip consume the chunks a few steps behind, so the Jacobian store stream runs under the rollout's
  * latency chain -- for the RigidBody{QuatRotation} models (satellite, quadrotor), explicit rules, RDHIP_FORWARD_AD, RDHIP_TIME_MAJOR data with
  * 16-byte aligned J and M * n * (n+m) * sizeof(T) a multiple of 16 (M even in fp64, a multiple of 4 in fp32) and at most half as many 64-trajectory
- * groups as the device has compute units; every other combination runs the two launches back to back.  rdhip_ctx_last_rollout_jacobian_launches
- * says which (1 = overlapped).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are
+ * groups as the device has compute units; every other combination runs rollout and Jacobians as launches of their own -- back to back, or, for
+ * RDHIP_TIME_MAJOR stacks of 262 144 knot points and more with at least 64 knots per trajectory (small models, custom models, the models of a
+ * mixed-model call that did not get the overlapped launch), in four pieces of consecutive knots with the Jacobians of a finished piece on an
+ * internal stream beside the rollout of the next (RDHIP_ROLLJAC_PIPE_MIN_KNOTS in the environment moves the limit, 0 = never; results are those of
+ * the two plain launches).  rdhip_ctx_last_rollout_jacobian_launches says which (1 = overlapped in one launch, 2 = back to back, more = in pieces).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are
  * latency-sized; from 262 144 knot points on they run the two launches, which is faster there (4 096 x 101 fp64 knots: 204 vs 250 us;
  * RDHIP_FUSED_TJ_MAX_KNOTS in the environment moves the limit).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
  * The Jacobian workgroups of the overlapped launch hold their compute unit while they wait for the rollout workgroups of the SAME launch; the

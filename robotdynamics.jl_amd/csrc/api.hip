@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "jit_api.hpp"
 
 using namespace rd;
 
@@ -65,6 +66,10 @@ struct rdhip_ctx {
     // rdhip_rollout_jacobian_multi: one child context (own stream, own progress words) per additional model, created on first use
     rdhip_ctx* child[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+    // rdhip_rollout_jacobian, models without the fused launch, time-major stacks: the Jacobians of a finished piece of the rollout run on this stream
+    // while the rollout goes on (created on first use)
+    hipStream_t pipe = nullptr;
+    hipEvent_t pipe_ev = nullptr, pipe_done = nullptr;
 };
 static constexpr int PROGRESS_WORDS = 4096;
 struct rdhip_model {
@@ -178,6 +183,8 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     for (auto& ch : c->child) if (ch) { (void)rdhip_ctx_destroy(ch); ch = nullptr; }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     for (auto& e : c->join_ev) if (e) (void)hipEventDestroy(e);
+    if (c->pipe) { (void)hipStreamSynchronize(c->pipe); (void)hipStreamDestroy(c->pipe); }
+    for (hipEvent_t e : {c->pipe_ev, c->pipe_done}) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c; return RDHIP_OK;
@@ -350,10 +357,11 @@ int rdhip_model_create(int kind, int rot, int frame, const double* params, int n
 }
 int rdhip_model_destroy(rdhip_model* M) { if (M && M->d.jit) jit_model_destroy(M->d.jit); delete M; return RDHIP_OK; }
 
-int rdhip_model_create_custom(int n, int m, const char* body, const char* preamble, const double* params, int nparams, int rot, const int* P, int nP, rdhip_model** out) {
+// shared by the two custom-model constructors: argument checks, the ModelDesc, the LieState partition; `discrete` picks the plug-in object
+static int create_custom(int n, int m, const char* body, const char* jac_body, const char* preamble, const double* params, int nparams, int rot, const int* P, int nP, bool discrete, rdhip_model** out) {
     if (!out) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
-    if (!body || !*body) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "dynamics_body is empty");
+    if (!body || !*body) return fail(nullptr, RDHIP_ERR_INVALID_ARG, discrete ? "step_body is empty" : "dynamics_body is empty");
     if (n <= 0 || m <= 0 || n > 16 || m > 8) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "unsupported dimensions n=%d m=%d (n <= 16, m <= 8)", n, m);
     if (nparams < 0 || nparams > 64 || (nparams > 0 && !params)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad params (nparams=%d)", nparams);
     if (nP < 0 || nP > 8 || (nP > 0 && !P)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "bad LieState partition (nP=%d)", nP);
@@ -371,10 +379,35 @@ int rdhip_model_create_custom(int n, int m, const char* body, const char* preamb
         if (len != n) { delete M; return fail(nullptr, RDHIP_ERR_DIM_MISMATCH, "LieState partition has length %d but n = %d", len, n); }
         d.e = 3 * (nP - 1) + sp;
     } else d.e = n;
-    d.jit = jit_model_create(n, m, body, preamble, d.params, nparams, d.rot == RDHIP_ROT_QUAT, d.lie_P, nP);
+    d.jit = discrete ? jit_model_create_discrete(n, m, body, jac_body, preamble, d.params, nparams, d.rot == RDHIP_ROT_QUAT, d.lie_P, nP)
+                     : jit_model_create(n, m, body, preamble, d.params, nparams, d.rot == RDHIP_ROT_QUAT, d.lie_P, nP);
     d.newton_iters = 10; d.newton_tol = 1e-12;
     build_lie(M);
     *out = M; return RDHIP_OK;
+}
+int rdhip_model_create_custom(int n, int m, const char* body, const char* preamble, const double* params, int nparams, int rot, const int* P, int nP, rdhip_model** out) {
+    return create_custom(n, m, body, nullptr, preamble, params, nparams, rot, P, nP, false, out);
+}
+int rdhip_model_create_custom_discrete(int n, int m, const char* step_body, const char* jac_body, const char* preamble, const double* params, int nparams, int rot, const int* P, int nP,
+                                       rdhip_model** out) {
+    return create_custom(n, m, step_body, jac_body, preamble, params, nparams, rot, P, nP, true, out);
+}
+int rdhip_model_set_user_jacobian(rdhip_model* M, const char* jac_body) {
+    if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_set_user_jacobian: not a custom model");
+    return jit_set_user_jacobian(M->d.jit, jac_body);
+}
+int rdhip_model_is_discrete(const rdhip_model* M, int* discrete) {
+    if (!M || !discrete) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "NULL argument");
+    *discrete = (M->d.kind == RDHIP_MODEL_CUSTOM && jit_is_discrete(M->d.jit)) ? 1 : 0; return RDHIP_OK;
+}
+// the rule argument of a call against the model: a user-defined DiscreteDynamics model IS its own rule (RDHIP_DISCRETE, nothing else); every other model
+// takes lo .. hi of the quadrature rules
+static int rule_ok(rdhip_ctx* c, const rdhip_model* M, int rule, int lo, int hi, const char* what) {
+    const bool discrete = M && M->d.kind == RDHIP_MODEL_CUSTOM && jit_is_discrete(M->d.jit);
+    if (discrete) return rule == RDHIP_DISCRETE ? RDHIP_OK : fail(c, RDHIP_ERR_INVALID_ARG, "%s: a DiscreteDynamics model has no quadrature rule and no continuous dynamics: pass RDHIP_DISCRETE (got %d)", what, rule);
+    if (rule == RDHIP_DISCRETE) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: RDHIP_DISCRETE is the rule of user-defined discrete models (rdhip_model_create_custom_discrete)", what);
+    if (rule < lo || rule > hi) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    return RDHIP_OK;
 }
 int rdhip_model_set_newton(rdhip_model* M, int iters, double tol) {
     if (!M) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "model is NULL");
@@ -383,17 +416,19 @@ int rdhip_model_set_newton(rdhip_model* M, int iters, double tol) {
 }
 int rdhip_model_balance_columns(rdhip_model* M) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_balance_columns: not a custom model");
+    if (jit_is_discrete(M->d.jit)) return fail(nullptr, RDHIP_ERR_UNSUPPORTED, "rdhip_model_balance_columns: continuous custom models only");
     const int rc = jit_balance(M->d.jit);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
 int rdhip_model_set_cascade(rdhip_model* M, int nblocks, const int* state_block, const int* control_block) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_set_cascade: not a custom model");
+    if (jit_is_discrete(M->d.jit)) return fail(nullptr, RDHIP_ERR_UNSUPPORTED, "rdhip_model_set_cascade: continuous custom models only (a discrete step has no stage points to share)");
     const int rc = jit_set_cascade(M->d.jit, nblocks, state_block, control_block);
     return rc ? fail(nullptr, rc, "rdhip_model_set_cascade: %s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
 int rdhip_model_precompile(rdhip_model* M, int op, int rule, int dtype) {
     if (!M || !M->d.jit) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: not a custom model");
-    if (op < 0 || (op > 18 && !(op >= 32 && (op - 32 == 11 || (op - 32 >= 2 && op - 32 <= 6)))) || rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
+    if (op < 0 || (op > 20 && !(op >= 32 && (op - 32 == 11 || op - 32 == 19 || op - 32 == 20 || (op - 32 >= 2 && op - 32 <= 6)))) || rule < RDHIP_CONTINUOUS || rule > RDHIP_DISCRETE || (dtype != RDHIP_F64 && dtype != RDHIP_F32)) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_model_precompile: bad op / rule / dtype");
     const int rc = jit_precompile(M->d.jit, op, rule, dtype);
     return rc ? fail(nullptr, rc, "%s", jit_last_error(M->d.jit)) : RDHIP_OK;
 }
@@ -606,7 +641,7 @@ static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype
 static int eval_common(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long N, const void* Z, const double* t, const double* dt,
                        void* Y, int memspace, const char* what) {
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_CONTINUOUS, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (N > 0 && (!Z || !t || !dt || !Y)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M, 0); if (rc) return rc;
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
@@ -669,9 +704,15 @@ int rdhip_model_wrench_sparsity(const rdhip_model* M, int js[10]) {
 static bool stream_is_capturing(rdhip_ctx* c);
 // the counter words of this launch's dynamic tile schedule on stream `me` (0: the context's, 1: the internal one), or NULL: static schedule (a capturing
 // stream -- a graph would bake one slot into every replay --, RDHIP_DYNAMIC_TILES=0, or no memory for the words)
-static unsigned* take_sched(rdhip_ctx* c, int me) {
+// `ntiles`, `dtype`: of the launch -- only launches that can take the schedule at all (fp64, 8 tiles per workgroup of the reduced grid: dispatch.hpp
+// dyn_grid) use up a slot.
+// A slot is handed out on the promise that its words are zero: the launch that used it before leaves them so (its last workgroup resets them).  A
+// launch that never finished -- a fault, an aborted process sharing the context's memory -- would break that promise for good, and every later launch on
+// the slot would silently skip tiles.  So each time a stream's ring comes round, the whole ring is zeroed again ON that stream (every launch that used
+// it is then complete by stream order): a 2 KB fill per 32 big launches, and a poisoned slot heals within one turn of the ring.
+static unsigned* take_sched(rdhip_ctx* c, int me, long long ntiles, int dtype) {
     static const bool off = [] { const char* e = getenv("RDHIP_DYNAMIC_TILES"); return e && e[0] == '0'; }();
-    if (off || stream_is_capturing(c)) return nullptr;
+    if (off || dtype != RDHIP_F64 || ntiles < 8LL * (long long)dyn_grid((unsigned)dev_info().cus) || stream_is_capturing(c)) return nullptr;
     if (!c->d_sched) {
         const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS * sizeof(unsigned);
         if (hipMalloc(&c->d_sched, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_sched = nullptr; return nullptr; }
@@ -680,8 +721,14 @@ static unsigned* take_sched(rdhip_ctx* c, int me) {
             (void)hipGetLastError(); (void)hipFree(c->d_sched); c->d_sched = nullptr; return nullptr;
         }
     }
-    const unsigned slot = c->sched_next[me]++ % rdhip_ctx::NSCHED;
-    return c->d_sched + ((size_t)me * rdhip_ctx::NSCHED + slot) * rdhip_ctx::SCHED_WORDS;
+    const unsigned turn = c->sched_next[me]++;
+    const unsigned slot = turn % rdhip_ctx::NSCHED;
+    unsigned* ring = c->d_sched + (size_t)me * rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS;
+    if (slot == 0 && turn > 0) {
+        hipStream_t st = me == 0 ? c->stream : c->side;
+        if (hipMemsetAsync(ring, 0, (size_t)rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS * sizeof(unsigned), st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return ring + (size_t)slot * rdhip_ctx::SCHED_WORDS;
 }
 int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                    void* J, void* Y, int memspace) {
@@ -691,7 +738,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
     int rc = check_common(c, M, dtype, N, memspace);
     if (c) c->in_overlapped_call = false;
     if (rc) return rc;
-    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_CONTINUOUS, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     if (N > 0 && (!Z || !t || !dt || !J)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M, 0); if (rc) return rc;
@@ -737,7 +784,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
             c->pend[other].clear();
         }
         a.stream = mine;
-        a.sched = take_sched(c, (int)me);
+        a.sched = take_sched(c, (int)me, (N + 63) / 64, dtype);
         // (implicit rule: each stream has its own set of flag words, so the two launches in flight do not share any)
         const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a, (int)me) : family_jacobian(d, rule, diff, dtype, a), what);
         c->pend[me].push_back(fp);
@@ -745,7 +792,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
         ++c->flip;
         return k;
     }
-    if (N > 0) a.sched = take_sched(c, 0);
+    if (N > 0) a.sched = take_sched(c, 0, (N + 63) / 64, dtype);
     const int k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, a) : family_jacobian(d, rule, diff, dtype, a), what);
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }
@@ -797,7 +844,7 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     if (nbatch < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative nbatch", what);
     if (nbatch == 0) return RDHIP_OK;
     if (!N || !Z || !t || !dt || !J) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL table", what);
-    if (rule < RDHIP_CONTINUOUS || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_CONTINUOUS, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     std::vector<int> live;
     bool aligned = true, equal = true;
@@ -862,7 +909,7 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
             // looked up in front of the compute waves' input prefetch -- a scalar-cache hit while consecutive tiles share a batch record, a memory round trip
             // per tile when batches are one or two tiles long (1 024 x 101 knots: 40.7 -> 47.8 us with the counter, 4 096 x 101: 151 -> 166; 256 x 4 096:
             // 374-387 -> 353 us)
-            a.sched = (acc >= 16LL * ng) ? take_sched(c, 0) : nullptr;
+            a.sched = (acc >= 16LL * ng) ? take_sched(c, 0, acc, dtype) : nullptr;
             const int k = family_jacobian(d, rule, diff, dtype, a);
             if (k == RDHIP_ERR_UNSUPPORTED && g0 == 0) { fused = false; break; }      // no fused kernel for this (model, rule, diff): decided before anything was launched
             if (k) return kernel_status(c, k, what);
@@ -893,7 +940,8 @@ int rdhip_ctx_last_multi_launches(rdhip_ctx* c, int* launches) {
 static int dynerr_common(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, long long N, const void* Z, const double* t, const double* dt,
                          void* J2, void* J1, void* E, bool want_jac, int memspace, const char* what) {
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: a quadrature rule is required (got %d)", what, rule);
+    if (rule == RDHIP_CONTINUOUS) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: a quadrature rule is required (got %d)", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_EULER, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (want_jac && (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
@@ -934,7 +982,8 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
                           void* Ebar, void* Y, int memspace) {
     const char* what = "rdhip_error_expansion";
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
-    if (rule < RDHIP_EULER || rule > RDHIP_RK4) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: an explicit quadrature rule is required (got %d)", what, rule);
+    if (rule == RDHIP_CONTINUOUS || rule == RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: an explicit quadrature rule is required (got %d)", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_EULER, RDHIP_RK4, what); if (rc) return rc;
     const long long P = N - 1;
     if (P <= 0) return RDHIP_OK;
     if (!Z || !t || !dt || !Ebar) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
@@ -952,7 +1001,7 @@ int rdhip_error_expansion(rdhip_ctx* c, const rdhip_model* M, int rule, int dtyp
         if (s.rc) return s.rc;
     }
     int k;
-    if (P > 0) a.sched = take_sched(c, 0);
+    if (P > 0) a.sched = take_sched(c, 0, (P + 63) / 64, dtype);
     if (d.lie_nP == 0) k = family_jacobian(d, rule, RDHIP_FORWARD_AD, dtype, a);   // EuclideanState: G = I
     else if (lie_fused && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) k = fam_lie_errexp(d, rule, dtype, a);
     else if (quat && d.kind == RDHIP_MODEL_CUSTOM && !(reinterpret_cast<uintptr_t>(a.J) & 15) && !(reinterpret_cast<uintptr_t>(a.Y) & 15)) {
@@ -1024,7 +1073,7 @@ int rdhip_rollout_layout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype
     const char* what = "rdhip_rollout";
     int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
     if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
-    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_EULER, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (layout != RDHIP_TRAJECTORY_MAJOR && layout != RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad layout %d", what, layout);
     if (K * Mt > 0 && (!Z || !t || !dt)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     rc = check_rotation(c, M, 0); if (rc) return rc;
@@ -1054,7 +1103,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     const char* what = "rdhip_rollout_jacobian";
     int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
     if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
-    if (rule < RDHIP_EULER || rule > RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad rule %d", what, rule);
+    rc = rule_ok(c, M, rule, RDHIP_EULER, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
     if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad diff method %d", what, diff);
     if (layout != RDHIP_TRAJECTORY_MAJOR && layout != RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad layout %d", what, layout);
     const long long N = K * Mt;
@@ -1094,8 +1143,47 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
         const int kf = fused_launch(c, d, rule, diff, dtype, f, capturing);
         if (kf != RDHIP_ERR_UNSUPPORTED) { c->last_rolljac_launches = 1; const int k = kernel_status(c, kf, what); return memspace == RDHIP_HOST ? s.finish(k) : k; }
     }
+    // Models without the fused launch (small models, custom models, the models of a mixed-model call that did not get it): a TIME-major stack of
+    // bandwidth size is rolled out in a few pieces of consecutive knots, and the Jacobians of a finished piece -- one contiguous range of the stack --
+    // run on a second stream while the next piece is rolled out.  Nothing spins: every launch waits for nobody, so any number of these may be in
+    // flight beside a fused launch.  A piece starts from the last knot of the one before it (read back from Z, the same bits the one-piece rollout
+    // carries in registers), so states and Jacobians are those of the two plain launches.  BASELINE config 5's cartpole half (4 096 x 256 fp32):
+    // rollout 124 us + Jacobians 19 us one after the other; inside the mixed-model call the Jacobians started at 173 us and took 98 us beside
+    // the satellite's fused launch -- they were the end of the call.
+    static const long long pipe_min = [] { const char* e = getenv("RDHIP_ROLLJAC_PIPE_MIN_KNOTS"); return e ? atoll(e) : 262144LL; }();     // tuning switch (0 = never)
+    constexpr long long PIECES = 4;
+    if (!implicit && layout == RDHIP_TIME_MAJOR && pipe_min > 0 && N >= pipe_min && K >= 16 * PIECES && !stream_is_capturing(c)) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!c->pipe) HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe, hipStreamNonBlocking));
+        if (!c->pipe_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->pipe_ev, hipEventDisableTiming));
+        if (!c->pipe_done) HIP_TRY(c, hipEventCreateWithFlags(&c->pipe_done, hipEventDisableTiming));
+        const long long len = (K + PIECES - 1) / PIECES;
+        const size_t zb = (size_t)Mt * nz * ts, jb = (size_t)Mt * d.n * nz * ts;      // bytes of one knot of the whole stack
+        int k = RDHIP_OK, launches = 0;
+        for (long long k0 = 0; k0 < K && !k; k0 += len) {
+            const long long nk = K - k0 < len ? K - k0 : len;                  // knots k0 .. k0 + nk - 1 get their Jacobians from this piece
+            const bool last = k0 + nk >= K;
+            LaunchArgs rc = r;
+            rc.Z = (const char*)r.Z + (size_t)k0 * zb; rc.t = r.t + k0 * Mt; rc.dt = r.dt + k0 * Mt;
+            rc.K = last ? nk : nk + 1;                                         // ... and the piece simulates up to the first knot of the next one
+            if (k0 > 0) rc.X0 = nullptr;
+            if (rc.K >= 2 || k0 == 0) { k = kernel_status(c, family_rollout(d, rule, dtype, rc), what); ++launches; }
+            if (k) break;
+            // what the Jacobians of this piece read is complete once the piece's rollout is -- except its last knot's successor, which they do not need
+            HIP_TRY(c, hipEventRecord(c->pipe_ev, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->pipe, c->pipe_ev, 0));
+            LaunchArgs jc = j;
+            jc.stream = c->pipe; jc.N = nk * Mt; jc.Z = rc.Z; jc.t = rc.t; jc.dt = rc.dt; jc.J = (char*)dJ + (size_t)k0 * jb; jc.sched = nullptr;
+            k = kernel_status(c, family_jacobian(d, rule, diff, dtype, jc), what); ++launches;
+        }
+        // (the context's stream is ordered behind the Jacobians whatever happened above)
+        HIP_TRY(c, hipEventRecord(c->pipe_done, c->pipe));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipe_done, 0));
+        c->last_rolljac_launches = launches;
+        return memspace == RDHIP_HOST ? s.finish(k) : k;
+    }
     int k = kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, r) : family_rollout(d, rule, dtype, r), what);
-    if (!k) { j.sched = take_sched(c, 0); k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what); }
+    if (!k) { j.sched = take_sched(c, 0, (N + 63) / 64, dtype); k = kernel_status(c, implicit ? family_implicit(c, d, 1, dtype, j) : family_jacobian(d, rule, diff, dtype, j), what); }
     c->last_rolljac_launches = 2;
     return memspace == RDHIP_HOST ? s.finish(k) : k;
 }

@@ -1,6 +1,7 @@
 // common.hpp -- host-side descriptors shared by the C-ABI layer (api.hip) and the per-family kernel TUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include "../../include/rdhip.h"
@@ -94,9 +95,28 @@ inline unsigned tile_grid_occ(const void* kernel, size_t lds_bytes, int threads,
         per_cu_of[dev & 63][kernel] = per_cu;
     }
     const unsigned lds_bound = tile_grid(lds_bytes, threads, ntiles);
+    // RDHIP_STATIC_GRID (tuning): workgroups per launch of the one-per-CU persistent kernels instead of one per compute unit (tune/tune_grid.hip)
+    static const long long grid_env = [] { const char* e = getenv("RDHIP_STATIC_GRID"); return e ? atoll(e) : 0LL; }();
+    if (grid_env > 0 && per_cu == 1) { const long long r0 = ntiles < grid_env ? ntiles : grid_env; return (unsigned)(r0 < (long long)lds_bound ? r0 : (long long)lds_bound); }
     const long long g = (long long)dev_info().cus * per_cu;
     const long long r = ntiles < g ? ntiles : g;
     return (unsigned)(r < (long long)lds_bound ? r : (long long)lds_bound);
+}
+
+// Persistent grid of the split-role launches WITH the dynamic tile schedule: three quarters of the chip, not all of it.  Round 5 (tune/tune_grid.hip, two
+// boxes, satellite RK4 ForwardAD fp64, us per launch on 256 / 224 / 208 / 192 / 176 / 160 workgroups): 131 072 knots 52.6 / 52.0 / 49.6 / 47.7 / 50.0 /
+// 53.5, 262 144: 97.9 / 95.6 / 87.7 / 89.7 / 93.0 / 99.2, 1 M: 404 / 396 / 387 / 370 / 370 / 391 -- 192 workgroups move 9-10 % more bytes per second
+// than 256.  Every workgroup streams its own 126 KB slab; fewer concurrent streams meet fewer open DRAM rows per bank (a streaming fill shows the same
+// preference), and the counter keeps the smaller grid balanced.  Static launches of a few tiles per workgroup (the 65 536-knot headline: 4 per
+// workgroup) lose to tile quantisation what they gain (27.15 us on 256, 26.85 on 160, 27.4 on 176, 28.6 on 192) and keep the whole chip; fp32
+// tiles are half the size and want all 256 (1 M knots: 205 us on 256, 217-222 on 192).  RDHIP_DYN_GRID overrides (tuning).
+inline unsigned dyn_grid(unsigned full) {
+    static const long long env = [] { const char* e = getenv("RDHIP_DYN_GRID"); return e ? atoll(e) : 0LL; }();
+    const unsigned cus = (unsigned)dev_info().cus;
+    if (env > 0) return (unsigned)(env < (long long)full ? env : (long long)full);
+    if (full < cus) return full;
+    const unsigned g = (cus * 3 / 4) & ~7u;
+    return g >= 8 ? g : full;
 }
 
 // implicit kernels: flag words of a context (word 0: whole batch; words 1 .. : one per 64-knot tile)

@@ -130,7 +130,7 @@ template <class Fn, class T, class Plan, int NC, class K, class KD> int launch_s
     // the instantiation with the dynamic tile schedule (kernels.hpp jac_split_loop) when the launch has counter words and 8 or more tiles per workgroup
     {   // (the two are pointers of one type: the same pointer twice means "no such instantiation")
         if (a.sched && reinterpret_cast<const void*>(kernel_dyn) != reinterpret_cast<const void*>(kernel)) {
-            const unsigned gd = tile_grid_occ(reinterpret_cast<const void*>(kernel_dyn), lds, threads, ntiles);
+            const unsigned gd = dyn_grid(tile_grid_occ(reinterpret_cast<const void*>(kernel_dyn), lds, threads, ntiles));
             if (ntiles >= 8LL * gd) {
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_dyn), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 RD_LAUNCH(kernel_dyn, dim3(gd), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
@@ -174,7 +174,7 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
     if constexpr (sizeof(T) == 8) {                      // the instantiation with the dynamic tile schedule (see launch_split_kernel)
         if (a.sched) {
             auto kd = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB, true>;
-            const unsigned gd = tile_grid_occ(reinterpret_cast<const void*>(kd), lds, threads, a.multi->pod.total);
+            const unsigned gd = dyn_grid(tile_grid_occ(reinterpret_cast<const void*>(kd), lds, threads, a.multi->pod.total));
             if (a.multi->pod.total >= 8LL * gd) {
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kd), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 RD_LAUNCH(kd, dim3(gd), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
@@ -346,15 +346,23 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             static_assert(lds <= 160 * 1024, "fused kernel: LDS");
             const long long cus = dev_info().cus;
             // the rollout workgroups must leave most of the chip to the Jacobians (and all of them must be resident together with consumers)
-            if (G > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
+            if (G * FUSED_PROGRESS_STRIDE > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
             if (a.probe) return RDHIP_OK;
-            // Two-phase split (fused.hpp): the rollout workgroups produce G tiles per step, the nj Jacobian workgroups consume nj tiles per tile time;
-            // while the rollout runs, the consumers get through  A = nj (K - 1) step / tile_time  tiles.  If that is (nearly) everything the
-            // consumers keep up and there is no second phase; otherwise the tiles behind A are shared by ALL workgroups, the former rollout
-            // workgroups included.  tile_time / step, measured (tune/tune_c5.hip, satellite RK4): 3.4 us / 0.47 us in fp32, 6.9 / 0.62 in fp64.
+            // The walk's second part (fused.hpp FusedWalk): the rollout workgroups produce G tiles per step, the nj Jacobian workgroups consume nj tiles per
+            // tile time; while the rollout runs, the consumers get through  A = nj (K - 1) step / tile_time  tiles.  If that is (nearly) everything the
+            // consumers keep up and there is no second part; otherwise the tiles behind A are shared by ALL workgroups, the former rollout workgroups
+            // included.  fp32, satellite RK4 (tune/tune_c5.hip, 4 096 x 256, round 5's consumers: 2.9 us per tile against 0.46 us per step): the best
+            // split of a sweep sits at 0.6-0.7 K, ratio 4.6 (it was 7.2, 0.40 K, while every tile paid a poll); calibrated on the satellite only.
+            // fp64 takes NO second part: its 126 KB tiles are bandwidth-bound on three quarters of the chip already (the plain kernel is faster on
+            // 192 workgroups than on 256, launch_split_kernel above) -- 4 096 x 101 knots 162-166 us without, 173-181 us with a split anywhere
+            // between 0.3 and 0.55 K.  RDHIP_FUSED_RATIO (tuning) forces a ratio for either type.
+            static const double ratio_env = [] { const char* e = getenv("RDHIP_FUSED_RATIO"); return e ? atof(e) : 0.0; }();
+            // test switch: fewer Jacobian workgroups (read per call -- tests/test_gpu_round4.py toggles it inside one process; a look-up in the environment
+            // costs a fraction of a microsecond in front of a launch of 100 us and more)
+            const long long nj_env = [] { const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS"); return e ? atoll(e) : 0LL; }();
             auto split_of = [&](long long ntiles, long long nj) -> long long {
-                double ratio = sizeof(T) == 4 ? 7.2 : 11.0 * 4.0 / rule_stages<RULE>();
-                if (const char* e = getenv("RDHIP_FUSED_RATIO")) { const double v = atof(e); if (v > 0) ratio = v; }      // tuning switch
+                if (sizeof(T) == 8 && !(ratio_env > 0)) return 0;
+                const double ratio = ratio_env > 0 ? ratio_env : 4.6;
                 const double A = (double)nj * (double)(K - 1) / ratio;
                 if (G < 8 || A >= 0.85 * (double)ntiles) return 0;
                 long long sp = (long long)A; sp -= sp % G;
@@ -365,7 +373,7 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 const long long ntiles = K * G;
                 long long nj = cus - G; if (nj > ntiles) nj = ntiles;
-                if (const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS")) { const long long v = atoll(e); if (v >= 1 && v < nj) nj = v; }     // test / tuning switch: fewer Jacobian workgroups
+                if (nj_env >= 1 && nj_env < nj) nj = nj_env;
                 RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
                                    a.progress, a.pbase, split_of(ntiles, nj));
             } else {
@@ -373,7 +381,7 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 const long long ntiles = ((K + GATHER_RUN - 1) / GATHER_RUN) * ((M + GATHER_NRUN - 1) / GATHER_NRUN);
                 long long nj = cus - G; if (nj > ntiles) nj = ntiles;
-                if (const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS")) { const long long v = atoll(e); if (v >= 1 && v < nj) nj = v; }
+                if (nj_env >= 1 && nj_env < nj) nj = nj_env;
                 RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), lds, a.stream, Fn{m}, K, M, (int)G, K, 1LL, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
                                    a.progress, a.pbase, split_of(ntiles, nj));
             }

@@ -533,15 +533,13 @@ template <class Mdl, class T> struct ImplicitRegOps {
     // one Newton solve from x1 (src/integration.jl:422-463): xn = solution, xl = last tested iterate; true if a row exchange was needed
     // (*unconv = the lane left the loop at the iteration limit, i.e. xn is one update past the last tested iterate xl)
     static RD_DEV bool newton(const Mdl& m, const T (&x1)[NX], const T (&u)[NU], T tj, T h, int iters, double tol, T (&xn)[NX], T (&xl)[NX], bool* unconv = nullptr) {
-#if !defined(RD_NO_CASCADE_NEWTON)
-        if constexpr (Cascade<Mdl>::NB > 1) {          // block by block (CascadeNewton above); a lane it cannot vouch for goes to the exact kernel
+        if constexpr (Cascade<Mdl>::NB > 1 && !Tune::NO_CASCADE_NEWTON) {          // block by block (CascadeNewton above); a lane it cannot vouch for goes to the exact kernel
             const bool hand_over = CascadeNewton<Mdl, T, Cascade<Mdl>>::newton(m, x1, u, tj, h, iters, tol, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xl[i] = xn[i];
             if (unconv) *unconv = false;
             return hand_over;
         }
-#endif
         const T tm = tj + h * T(0.5);
         T xm[NX], f[NX], r[NX];
 #pragma unroll
@@ -756,13 +754,10 @@ template <class Fn, class T, class Plan> struct IftBody {
         // front cost its launch, 7 us with nothing to overlap, and a round trip of x_next through memory.
         T xn[NX], xl[NX];
         bool bad = false;
-#if defined(RD_IFT_ABL) && RD_IFT_ABL == 2     // tuning only: no Newton solve at all (x_next = x): what bounds the kernel besides the helper wave's chain?
-        if (true) {
+        if (Tune::IFT_ABL == 2) {                                    // tuning only: no Newton solve at all (x_next = x): what bounds the kernel besides the helper wave's chain?
 #pragma unroll
             for (int i = 0; i < NX; ++i) xn[i] = fr.x[i];
-        } else
-#endif
-        if (fn.solve == 2) {                                         // the helper wave solved this tile while the previous one was being computed
+        } else if (fn.solve == 2) {                                         // the helper wave solved this tile while the previous one was being computed
             const T* hx = reinterpret_cast<const T*>(fr.helper);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xn[i] = hx[fr.kl * NX + i];
@@ -779,14 +774,12 @@ template <class Fn, class T, class Plan> struct IftBody {
         if (fr.g == Plan::value_wave && fr.want_y) fr.put_value(NX + NU, xn);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xm[i] = (fr.x[i] + xn[i]) * T(0.5);
-#if defined(RD_IFT_ABL) && RD_IFT_ABL == 1     // tuning only: what would the kernel cost if (h/2) A - I came for free?  (a = -I: fill and factorisation fold away)
+        if constexpr (Tune::IFT_ABL == 1) {                          // tuning only: what would the kernel cost if (h/2) A - I came for free?  (a = -I: fill and factorisation fold away)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { f[i] = T(0);
+            for (int i = 0; i < NX; ++i) { f[i] = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) a[i][j] = (i == j) ? T(-1) : T(0); }
-#else
-        R::template fill<0>(fn.m, xm, fr.u, fr.t, fr.t + fr.h * T(0.5), fr.h, a, f);
-#endif
+                for (int j = 0; j < NX; ++j) a[i][j] = (i == j) ? T(-1) : T(0); }
+        } else R::template fill<0>(fn.m, xm, fr.u, fr.t, fr.t + fr.h * T(0.5), fr.h, a, f);
         const bool need = R::lu(a, piv) || bad;
         if (fr.g == 0 && fn.flag) {                                  // every compute wave sees the same knot points: one of them reports (unconditionally: nothing is ever cleared)
             const bool any = __any(need);
@@ -802,10 +795,7 @@ template <class Fn, class T, class Plan> struct IftBody {
     static constexpr size_t HELPER_BYTES = ((size_t)TILE * NX * sizeof(T) + 16 + 15) / 16 * 16;
     static constexpr bool HELPER = SplitLds<Fn, T, Plan, 4>::BYTES + 2 * HELPER_BYTES <= 160 * 1024;
     template <class TR> static RD_DEV void helper_tile(const Fn& fn, const TR& r, unsigned char* dst) {
-        if (fn.solve != 2) return;
-#if defined(RD_IFT_ABL) && RD_IFT_ABL == 2
-        return;
-#endif
+        if (fn.solve != 2 || Tune::IFT_ABL == 2) return;
         constexpr int NZ = NX + NU;
         const int lane = threadIdx.x & 63;
         const int nk = (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE);

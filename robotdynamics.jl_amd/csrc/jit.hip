@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 #include "common.hpp"
+#include "jit_api.hpp"
 #include "embedded_headers.inc"
 
 namespace rd {
@@ -34,6 +35,11 @@ struct JitKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; size_t
 struct JitModel {
     int n = 0, m = 0, np = 0;
     std::string name, body, preamble;
+    // discrete: `body` is the body of step(x, u, t, h, xn) -- a user-defined DiscreteDynamics model (src/discrete_dynamics.jl:80-108); every call takes
+    // rule RDHIP_DISCRETE.  jac_body (may be empty): the user's own Jacobian, jac(x, u, t, J) / jac(x, u, t, h, J): what RDHIP_USER_DEFINED evaluates
+    // (src/dynamics.jl:115-116, src/discrete_dynamics.jl:111-113; user_model.hpp)
+    bool discrete = false;
+    std::string jac_body;
     std::vector<double> params;
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;        // key -> code object (device independent)
@@ -57,7 +63,7 @@ struct JitModel {
 enum { JOP_EVAL = 0, JOP_ROLLOUT = 1, JOP_JAC_AD = 2, JOP_JAC_FD = 3, JOP_JAC_CHAIN = 4, JOP_JAC_AD_LOOP = 5, JOP_JAC_CHAIN_LOOP = 6,
        JOP_IMPLICIT_X = 7, JOP_IMPLICIT_J = 8, JOP_IMPLICIT_ERR = 9, JOP_IMPLICIT_ROLLOUT = 10, JOP_JAC_FD_LOOP = 11, JOP_ERREXP = 12,
        JOP_IMPLICIT_X_REG = 13, JOP_IMPLICIT_J_REG = 14, JOP_IMPLICIT_ROLLOUT_REG = 15, JOP_IMPLICIT_IFT = 16, JOP_IMPLICIT_ROLLOUT_CAS = 17,
-       JOP_ROLLOUT_PLAIN = 18,
+       JOP_ROLLOUT_PLAIN = 18, JOP_JAC_USER = 19, JOP_JAC_USER_CHAIN = 20,
        JOP_MULTI = 32 };           // + JOP_MULTI: the same Jacobian operation over a MultiBatch (rdhip_jacobian_multi), ops 2 - 6 and 11   // 5, 6, 11: element-wise fallbacks for unaligned outputs; 18: one lane per trajectory whatever the model declares
 
 // CascadeLds<Fn, Cas, 4>::BYTES (cascade.hpp) of a declared block structure for a rule with `ns` stage points: ring of published stage points +
@@ -89,12 +95,19 @@ static std::string rot_start_expr(const JitModel& M) {
 }
 static std::string program_source(const JitModel& M) {
     std::ostringstream s;
-    s << "#include \"implicit.hpp\"\n#include \"cascade.hpp\"\nnamespace rd {\n" << M.preamble << "\n"
+    const bool user = M.discrete || !M.jac_body.empty();
+    s << "#include \"implicit.hpp\"\n#include \"cascade.hpp\"\n" << (user ? "#include \"user_model.hpp\"\n" : "") << "namespace rd {\n" << M.preamble << "\n"
       << "template <class T_> struct UserModel {\n    using T = T_;\n    static constexpr int NX = " << M.n << ", NU = " << M.m << ";\n"
-      << "    static constexpr bool HAS_USER_JACOBIAN = true;\n    static constexpr int NROT = " << M.rot_starts.size() << ";\n"
-      << "    static constexpr int rot_start(int r) { " << rot_start_expr(M) << " }\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n"
-      // the body sits in an inner block: a body written for the time-invariant signature may declare its own `t`
-      << "    template <class S> RD_DEV void f(const S* x, const S* u, T t, S* xdot) const {\n        (void)t;\n        {\n" << M.body << "\n        }\n    }\n};\n";
+      << "    static constexpr bool HAS_USER_JACOBIAN = " << ((M.discrete && M.jac_body.empty()) ? "false" : "true") << ";\n    static constexpr int NROT = " << M.rot_starts.size() << ";\n"
+      << "    static constexpr int rot_start(int r) { " << rot_start_expr(M) << " }\n    T p[" << (M.np > 0 ? M.np : 1) << "];\n";
+    // the bodies sit in an inner block: a body written for the time-invariant signature may declare its own `t`
+    if (M.discrete) s << "    template <class S> RD_DEV void step(const S* x, const S* u, T t, T h, S* xn) const {\n        (void)t; (void)h;\n        {\n" << M.body << "\n        }\n    }\n";
+    else s << "    template <class S> RD_DEV void f(const S* x, const S* u, T t, S* xdot) const {\n        (void)t;\n        {\n" << M.body << "\n        }\n    }\n";
+    if (!M.jac_body.empty()) {
+        if (M.discrete) s << "    RD_DEV void jac(const T* x, const T* u, T t, T h, T* J) const {\n        (void)t; (void)h;\n        {\n" << M.jac_body << "\n        }\n    }\n";
+        else s << "    RD_DEV void jac(const T* x, const T* u, T t, T* J) const {\n        (void)t;\n        {\n" << M.jac_body << "\n        }\n    }\n";
+    }
+    s << "};\n";
     if (M.cas_nb > 1) {            // the declared block structure: the cascade kernels (FiniteDifference, rollout, Newton) pick it up like a compiled-in model's
         s << "template <class T_> struct Cascade<UserModel<T_> > {\n    static constexpr int NB = " << M.cas_nb << ";\n"
           << "    static constexpr int block_of(int i) { constexpr int b[" << M.n << "] = {";
@@ -187,6 +200,11 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
                 break;
             case JOP_JAC_AD_LOOP: tile("AdLoopBody"); break;
             case JOP_JAC_FD_LOOP: tile("FdBody"); break;
+            case JOP_JAC_USER: case JOP_JAC_USER_CHAIN: {            // the user's own Jacobian: one wave per tile (user_model.hpp)
+                const std::string one = "rd::ContiguousPlan<" + std::to_string(nz) + ", 2>";
+                s << "rd::jac_tile_multi_kernel<" << F << ", " << T << ", " << one << ", rd::" << (base == JOP_JAC_USER ? "UserJacBody" : "UserChainBody") << "<" << F << ", " << T << ", " << one << "> >";
+                break;
+            }
             default: tile("ChainBody"); break;
         }
         return s.str();
@@ -213,6 +231,8 @@ static std::string kernel_expr(const JitModel& M, int op, int rule, int dtype) {
             if (nz <= 10) s << "rd::jac_chain_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">";
             else s << "rd::jac_chain_split_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ", 4>";
             break;
+        case JOP_JAC_USER: s << "rd::jac_user_kernel<" << fn.str() << ", " << T << ", rd::ContiguousPlan<" << nz << ", 2> >"; break;
+        case JOP_JAC_USER_CHAIN: s << "rd::jac_user_chain_kernel<" << fn.str() << ", " << T << ", rd::ContiguousPlan<" << nz << ", 2> >"; break;
         default: s << "rd::jac_chain_kernel<" << fn.str() << ", " << T << ", " << plan.str() << ">"; break;
     }
     return s.str();
@@ -331,6 +351,9 @@ static int jit_get(JitModel& M, int op_, int rule, int dtype, JitKernel** out) {
             const int waves = 4 * wave_bytes <= 160 * 1024 ? 4 : 2 * wave_bytes <= 160 * 1024 ? 2 : 1;
             jk.block = 64 * waves; jk.persistent = true; jk.lds = waves * wave_bytes;
         }
+        else if (op == JOP_JAC_USER || op == JOP_JAC_USER_CHAIN) {         // JacLds<Fn, T, ContiguousPlan<nz, 2>>::BYTES, two waves
+            jk.block = 128; jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8;
+        }
         else if (split) { jk.block = 512; jk.persistent = true; jk.lds = a16((size_t)64 * ny * nz * ts) + a16((size_t)64 * ny * ts) + a16((size_t)64 * nz * ts) + 2 * 64 * 8; }   // SplitLds<Fn,T,Plan,4>::BYTES
         else { jk.block = 64 * (nz >= 4 ? 4 : nz); jk.persistent = true; jk.lds = ((size_t)64 * ((nz * ny + ny) | 1) + (size_t)64 * nz) * ts + 2 * 64 * 8; }   // JacLds<Fn,T,ContiguousPlan>::BYTES
         if (jk.lds > 64 * 1024) {
@@ -430,6 +453,21 @@ void* jit_model_create(int n, int m, const char* body, const char* preamble, con
     M->params.assign(params, params + np);
     return M;
 }
+// a user-defined DiscreteDynamics model: `step_body` is the body of step(x, u, t, h, xn) (program_source)
+void* jit_model_create_discrete(int n, int m, const char* step_body, const char* jac_body, const char* preamble, const double* params, int np, int quat_rotations, const int* P, int nP) {
+    JitModel* M = static_cast<JitModel*>(jit_model_create(n, m, step_body, preamble, params, np, quat_rotations, P, nP));
+    M->discrete = true; M->jac_body = jac_body ? jac_body : "";
+    return M;
+}
+int jit_set_user_jacobian(void* h, const char* jac_body) {
+    JitModel& M = *static_cast<JitModel*>(h);
+    std::lock_guard<std::mutex> g(M.mu);
+    M.jac_body = jac_body ? jac_body : "";
+    retire_compiled(M);
+    return RDHIP_OK;
+}
+int jit_is_discrete(void* h) { return h && static_cast<JitModel*>(h)->discrete ? 1 : 0; }
+int jit_has_user_jacobian(void* h) { return h && !static_cast<JitModel*>(h)->jac_body.empty() ? 1 : 0; }
 void jit_model_destroy(void* h) {
     JitModel* M = static_cast<JitModel*>(h);
     if (!M) return;
@@ -437,9 +475,14 @@ void jit_model_destroy(void* h) {
     delete M;
 }
 const char* jit_last_error(void* h) { return static_cast<JitModel*>(h)->err.c_str(); }
+static int user_jac_op(const JitModel& M, int rule, int diff);
 int jit_precompile(void* h, int op, int rule, int dtype) {
     JitModel& M = *static_cast<JitModel*>(h);
     std::lock_guard<std::mutex> g(M.mu);
+    if (M.discrete != (rule == RDHIP_DISCRETE)) { M.err = "precompile: RDHIP_DISCRETE is the rule of discrete models, and their only one"; return RDHIP_ERR_INVALID_ARG; }
+    // "UserDefined" (the chain-rule op) of a model with a Jacobian body means the kernel that evaluates the body, where one exists (jit_jacobian_impl)
+    if (op == JOP_JAC_CHAIN || op == JOP_MULTI + JOP_JAC_CHAIN) { const int u = user_jac_op(M, rule, RDHIP_USER_DEFINED); if (u >= 0) op = (op >= JOP_MULTI ? JOP_MULTI : 0) + u; }
+    if ((op == JOP_JAC_USER || op == JOP_JAC_USER_CHAIN || op == JOP_MULTI + JOP_JAC_USER || op == JOP_MULTI + JOP_JAC_USER_CHAIN) && M.jac_body.empty()) { M.err = "precompile: the model has no Jacobian body"; return RDHIP_ERR_NOT_IMPLEMENTED; }
     std::ostringstream k; k << op << ":" << rule << ":" << dtype;
     return jit_compile(M, op, rule, dtype, k.str());
 }
@@ -531,14 +574,23 @@ int jit_jacobian(void* h, int rule, int diff, int dtype, const LaunchArgs& a) {
     if (M.cas_nb > 1) { const int vc = jit_verify_cascade(M, a.stream); if (vc) return vc; }
     return jit_jacobian_impl(M, rule, diff, dtype, a);
 }
+// RDHIP_USER_DEFINED with the user's own formulas (user_model.hpp), or -1: a discrete model's own jac; a continuous model's jac for rule CONTINUOUS and,
+// through the integrators' chain rule on stage Jacobians held in registers, for the explicit rules of models with n + m <= 10
+static int user_jac_op(const JitModel& M, int rule, int diff) {
+    if (diff != RDHIP_USER_DEFINED || M.jac_body.empty()) return -1;
+    if (M.discrete || rule == RDHIP_CONTINUOUS) return JOP_JAC_USER;
+    return (M.n + M.m <= 10 && rule >= RDHIP_EULER && rule <= RDHIP_RK4) ? JOP_JAC_USER_CHAIN : -1;
+}
 static int jit_jacobian_impl(JitModel& M, int rule, int diff, int dtype, const LaunchArgs& a) {
-    int op = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
+    if (M.discrete && diff == RDHIP_USER_DEFINED && M.jac_body.empty()) { M.err = "User-defined discrete dynamics Jacobian not defined."; return RDHIP_ERR_NOT_IMPLEMENTED; }      // src/discrete_dynamics.jl:112-113
+    const int uop = user_jac_op(M, rule, diff);
+    int op = uop >= 0 ? uop : diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.J) | reinterpret_cast<uintptr_t>(a.Y)) & 15) == 0;
-    if (M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);   // the split-role kernels copy 16-B units
+    if (uop < 0 && M.n + M.m > 10 && !aligned) op = (op == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (op == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);   // the split-role kernels copy 16-B units
     if (a.multi) {                    // rdhip_jacobian_multi: the same body over a MultiBatch (kernel argument = the MultiPod image)
         if (a.multi->pod.total == 0) return RDHIP_OK;
-        int mop = diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
-        if (M.n + M.m > 10 && !a.multi->aligned16) mop = (mop == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (mop == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);
+        int mop = uop >= 0 ? uop : diff == RDHIP_FORWARD_AD ? JOP_JAC_AD : diff == RDHIP_FINITE_DIFF ? JOP_JAC_FD : JOP_JAC_CHAIN;
+        if (uop < 0 && M.n + M.m > 10 && !a.multi->aligned16) mop = (mop == JOP_JAC_AD) ? JOP_JAC_AD_LOOP : (mop == JOP_JAC_CHAIN ? JOP_JAC_CHAIN_LOOP : JOP_JAC_FD_LOOP);
         JitKernel* km; int rcm = jit_get(M, JOP_MULTI + mop, rule, dtype, &km); if (rcm) return rcm;
         std::vector<unsigned char> fnm; pack_params(M, dtype, fnm);
         MultiPod pod = a.multi->pod;

@@ -6,15 +6,19 @@
 // Everything between load and store lives in registers.
 #pragma once
 #include "models.hpp"
+#include "tune_default.hpp"
+// the tuning policy (tune_default.hpp): the library never defines RD_TUNE; a harness under csrc/tune/ includes tune/harness_tune.hpp first
+#ifndef RD_TUNE
+#define RD_TUNE rd::DefaultTune
+#endif
 
 namespace rd {
 
+using Tune = RD_TUNE;
 // register budget of the fp32 ForwardAD tile kernels, in waves per SIMD: 2 = up to 256 registers (the kernels take 146 and do not spill; one
 // workgroup per CU).  Rounds 1-3 asked for 4 (128 registers, two workgroups per CU by LDS): 68 bytes of scratch per lane and 30.3 instead of
 // 26.9 us for 131 072 fp32 satellite knot points (tune/tune_plan.hip -DTT=float, same-box A/B)
-#ifndef RD_F32_MINB
-#define RD_F32_MINB 2
-#endif
+constexpr int RD_F32_MINB = Tune::F32_MINB;
 constexpr int TILE = 64;   // knot points per wave = wave width on gfx950
 constexpr int ROLLOUT_PREFETCH = 4;   // rollout kernels: inputs are requested this many steps ahead
 
@@ -26,14 +30,6 @@ template <> RD_DEV float sqrt_eps<float>() { return 3.4526698300124393e-04f; }  
 // floating-point compare against a NaN/Inf time step (the reference stores dt = Inf on a last knot point that
 // carries a control, src/trajectories.jl:104) would be undefined.
 RD_DEV bool is_terminal_dt(double h) { return (__double_as_longlong(h) << 1) == 0; }
-
-#ifdef RD_STAMP   // tuning only: per-wave phase time stamps (100 MHz wall clock) into a global buffer
-__device__ long long* g_stamps;
-RD_DEV void stamp(int slot, int ev) { if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[slot * 64 + ev] = wall_clock64(); }
-#define RD_STAMP_AT(slot, ev) stamp(slot, ev)
-#else
-#define RD_STAMP_AT(slot, ev) do {} while (0)
-#endif
 
 RD_DEV void wave_sync() {
     // LDS hand-off inside ONE wave: DS ops of a wave execute in order, we only need the compiler to keep them so.
@@ -205,6 +201,10 @@ template <class T> struct TileRef {
     // descriptors with GATHER: the tile's 64 slots are GATHER_NRUN runs of GATHER_RUN consecutive knot points, run r starting at knot k0 + r run_stride
     // (4 trajectories x 16 knots of a trajectory-major stack); the first nruns runs and the first run_knots knots of every run exist
     long long run_stride; int run_knots; int nruns;
+    // descriptors with WAITS: what the tile waits for -- its producer group and the progress word that makes it available (fused.hpp); at() fills them
+    // in, so that the wait in front of every tile does not repeat at()'s index arithmetic: a compute wave issues ~one instruction per 5 cycles whatever
+    // its kind, and ~40 scalar instructions per tile in front of the input requests measured 0.18 us of a 3.2 us iteration (tune/tune_c5.hip stamps)
+    long long wgroup; unsigned long long wneed;
 };
 constexpr int GATHER_RUN = 16, GATHER_NRUN = TILE / GATHER_RUN;      // (measured: runs of 4 / 8 / 16 knot points -> the one-launch call takes 0.97 / 0.955 / 0.905 of the two-launch time at 4 096 x 101)
 constexpr size_t SPLIT_GATHER_EXTRA = (size_t)GATHER_NRUN * 16;
@@ -228,11 +228,7 @@ template <class T> struct MultiBatch {
     // at() is two dependent memory round trips: the split-role loop resolves the tiles of a workgroup's first iterations IN PARALLEL before its
     // first barrier (one copy-wave lane per iteration) and hands them to everybody through an LDS table (jac_split_loop), so that no lookup sits
     // in front of a compute wave's input prefetch or between a copy wave's stores
-#if defined(RD_MULTI_NO_RING)     // tuning: every wave resolves its own tiles
-    static constexpr bool RING = false;
-#else
-    static constexpr bool RING = true;
-#endif
+    static constexpr bool RING = !Tune::MULTI_NO_RING;
     int nb;
     int uniform;                           // > 0: every batch has this many tiles (no search)
     long long total;                       // tiles of all batches (< 2^31)
@@ -313,15 +309,11 @@ template <class T, class BT> RD_DEV TileRef<T> at_uniform(const BT& bt, long lon
 }
 
 
-// tuning (tune/tune_ift.hip, tune/tune_jac.hip): wall-clock stamps (100 MHz) of the split-role loop's phases, [workgroup][iteration < 8][slot < 16]:
+// tuning (tune/tune_stamp.hip, tune/tune_c5.hip): wall-clock stamps (100 MHz) of the split-role loop's phases, [workgroup][iteration < 8][slot < 16]:
 // 0 compute wave 0 enters the iteration, 4 + g compute wave g is done with its columns, 2 / 3 compute wave 0 behind barrier A / B, 8 / 9 / 10 copy
-// wave 0 behind barrier A / has the tile in registers / has issued its stores, 11 / 12 helper wave starts / ends the next tile's chain
-#if defined(RD_SPLIT_STAMP)
-__device__ long long* g_split_stamp = nullptr;
-#define RD_STAMP(it, slot) do { const long long c_ = (long long)wall_clock64(); long long* sp_ = g_split_stamp; if ((threadIdx.x & 63) == 0 && (it) < 8 && sp_) sp_[((long long)blockIdx.x * 8 + (it)) * 16 + (slot)] = c_; } while (0)
-#else
-#define RD_STAMP(it, slot) do {} while (0)
-#endif
+// wave 0 behind barrier A / has the tile in registers / has issued its stores, 11 / 12 helper wave starts / ends the next tile's chain, 13 / 15 (iteration
+// 0) the workgroup's first / last instruction.  Tune::split_stamp is empty in the library.
+#define RD_STAMP(it, slot) Tune::split_stamp((it), (slot))
 
 // Default plan: one chunk, contiguous column ranges per wave, f(z) emitted by wave 0.
 template <int NZ, int NG_> struct ContiguousPlan {
@@ -537,12 +529,10 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
                 for (int i = 0; i < NX; ++i) { xd[i].v = fr.x[i]; xd[i].d[0] = (i == C) ? T(1) : T(0); }
 #pragma unroll
                 for (int i = 0; i < NU; ++i) { ud[i].v = fr.u[i]; ud[i].d[0] = (NX + i == C) ? T(1) : T(0); }
-#if defined(RD_ABLATE) && RD_ABLATE == 2   // tuning only: no arithmetic, same store pattern
+                if constexpr (Tune::ABLATE == 2) {            // tuning only: no arithmetic, same store pattern
 #pragma unroll
-                for (int i = 0; i < NY; ++i) { yd[i].v = fr.x[i]; yd[i].d[0] = fr.x[i] + T(C); }
-#else
-                fn.eval(xd, ud, fr.t, fr.h, yd);
-#endif
+                    for (int i = 0; i < NY; ++i) { yd[i].v = fr.x[i]; yd[i].d[0] = fr.x[i] + T(C); }
+                } else fn.eval(xd, ud, fr.t, fr.h, yd);
                 T col[NY];
                 if constexpr (VALUE_PENDING) {
                     if (fr.want_y) {
@@ -556,9 +546,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 #pragma unroll
                 for (int i = 0; i < NY; ++i) col[i] = yd[i].d[0] * sc;
                 fr.put_at(C - C0, col);
-#if defined(RD_COL_BARRIER)
-                __builtin_amdgcn_sched_barrier(0);          // finish this column before the scheduler starts interleaving the next one (register pressure)
-#endif
+                if constexpr (Tune::COL_BARRIER) __builtin_amdgcn_sched_barrier(0);      // (tuning) finish this column before the scheduler starts interleaving the next one
                 AdCols<Fn, T, Plan, CH, G, C + 1, false>::run(fn, fr);
             } else {
                 AdCols<Fn, T, Plan, CH, G, C + 1, VALUE_PENDING>::run(fn, fr);
@@ -609,25 +597,23 @@ __global__ void col_probe_kernel(Fn fn, const T* __restrict__ Z, T* __restrict__
 // so the HBM write stream of tile t runs under the arithmetic of tile t+1.  Requires 16-byte aligned J and Y (the
 // copy is a linear 16-byte sweep over the tile, which is one contiguous slab of global memory).
 // tile stores are streaming (written once, never re-read by this kernel): the non-temporal hint measured 3-5 % faster
-// than plain stores on MI355X (less dirty data left in L2 for the end-of-kernel write-back); -DRD_PLAIN_STORES reverts
-#if defined(RD_ABLATE) && RD_ABLATE == 3      // tuning only: no tile stores (what does the arithmetic alone cost?)
-#define RD_TILE_STORE(p, v) do { if (lane == 99) *(p) = (v); } while (0)
-#elif defined(RD_PLAIN_STORES)
-#define RD_TILE_STORE(p, v) (*(p) = (v))
-#else
-#define RD_TILE_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#endif
+// than plain stores on MI355X (less dirty data left in L2 for the end-of-kernel write-back); Tune::PLAIN_STORES reverts, Tune::ABLATE == 3 drops the stores
+template <class V> RD_DEV void tile_store(V* p, V v, int lane) {
+    if constexpr (Tune::ABLATE == 3) { if (lane == 99) *p = v; }
+    else if constexpr (Tune::PLAIN_STORES) *p = v;
+    else __builtin_nontemporal_store(v, p);
+}
+#define RD_TILE_STORE(p, v) tile_store((p), (v), lane)
 // Tile stores of the copy waves as BUFFER stores: the tile slab's base in a scalar resource descriptor, ONE vector register with the lane's byte offset
 // (16 ct) for the whole sweep and the unit's offset (r x 4 096 bytes for four copy waves) as the instruction's scalar offset.  As global stores every
 // unit carried its own 64-bit per-lane address: the compiler hoisted those 2 x 31 registers out of the tile loop, and in the batch-table kernels (256
 // registers, rdhip_jacobian_multi) spilled some of them and reloaded them INSIDE the store sweep, each reload behind a wait for every store issued so far.
-#if defined(RD_ABLATE) && RD_ABLATE == 3
-#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) do { if (lane == 99) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 2); } while (0)
-#elif defined(RD_PLAIN_STORES)
-#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 0)
-#else
-#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) __builtin_amdgcn_raw_buffer_store_b128((v), (rsrc), (lane_off), (unit_off), 2)      // aux 2 = nt (streaming: written once, never re-read here)
-#endif
+template <class V> RD_DEV void tile_store_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned unit_off, V v, int lane) {
+    if constexpr (Tune::ABLATE == 3) { if (lane == 99) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane_off, unit_off, 2); }
+    else if constexpr (Tune::PLAIN_STORES) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane_off, unit_off, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane_off, unit_off, 2);      // aux 2 = nt (streaming: written once, never re-read here)
+}
+#define RD_TILE_STORE_BUF(rsrc, lane_off, unit_off, v) tile_store_buf((rsrc), (lane_off), (unit_off), (v), lane)
 RD_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, (short)0, 0x7fffffff, 0x00020000); }
 template <class Fn, class T, class Plan, int NC> struct SplitLds {
     static constexpr int NZ = Fn::NX + Fn::NU, NY = Fn::NY, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT;
@@ -653,13 +639,15 @@ template <class T> RD_DEV TileRef<T> ring_get(const long long* slot) {
     return TileRef<T>{(const T*)v[0], (const double*)v[1], (const double*)v[2], (T*)v[3], (T*)v[4], v[5], v[6]};
 }
 
-// a descriptor with WAITS = true makes the compute waves call bt.wait(tile) before they request a tile's inputs (tiles produced by other
+// a descriptor with WAITS = true makes the compute waves call bt.wait(ref, seen) before they request a tile's inputs (tiles produced by other
 // workgroups of the same launch: the fused rollout -> Jacobians kernel, fused.hpp)
-template <class BT, class = void> struct WaitsOf { static constexpr bool value = false; };
-template <class BT> struct WaitsOf<BT, decltype((void)BT::WAITS)> { static constexpr bool value = BT::WAITS; };
+template <class BT, class = void> struct WaitsOf { static constexpr bool value = false; struct Seen {}; };
+template <class BT> struct WaitsOf<BT, decltype((void)BT::WAITS)> { static constexpr bool value = BT::WAITS; using Seen = typename BT::Seen; };
 // tile inputs of a descriptor with WAITS were written by other workgroups of the SAME launch (possibly on another XCD, i.e. behind another L2): they
 // are read with agent-scope loads, which bypass the non-coherent caches -- a plain load could be served from a line this compute unit cached
 // while it read a neighbouring tile, before this tile's part of the line was produced (tiles that do not start on 128-byte lines)
+template <class BT, class = void> struct CoherentOf { static constexpr bool value = WaitsOf<BT>::value; };
+template <class BT> struct CoherentOf<BT, decltype((void)BT::COHERENT)> { static constexpr bool value = BT::COHERENT; };      // (tuning: a waiting descriptor with plain loads)
 template <bool COHERENT, class T> RD_DEV T tile_load(const T* p) {
     if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
@@ -673,11 +661,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, OW = Fn::NY * Fn::NCOLS, NVAL = Fn::NVAL, TIN = TILE + Fn::NEXT, NG = Plan::NG, NTC = NG * TILE;
     constexpr int NA = AuxOf<Fn>::N;
     // early part of a workgroup's first tile: the leading ES columns (ES * NY values of every row), see TablePlanS
-#if defined(RD_NO_EARLY)
-    constexpr int ES = 0;
-#else
-    constexpr int ES = (EarlyOf<Body>::value && !GatherOf<BT>::value) ? FirstSplitOf<Plan>::N : 0;
-#endif
+    constexpr int ES = (EarlyOf<Body>::value && !GatherOf<BT>::value && !Tune::NO_EARLY) ? FirstSplitOf<Plan>::N : 0;
     static_assert(Plan::NCHUNK == 1, "the split-role kernel stages whole tiles");
     using L = SplitLds<Fn, T, Plan, NC>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -704,11 +688,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // NPASS = 2 (two copy waves, fp32): the copy waves take the tile out of LDS in two halves -- the first half's stores are issued in front of
     // barrier B, the second half's behind it -- and hold half a tile in registers at a time: 64 data registers instead of 128, which is what lets
     // a six-wave workgroup stay under the 168 registers of three waves per SIMD, i.e. TWO workgroups per compute unit (see UnrollPolicy / F32_NC)
-#if defined(RD_NPASS_ANY)                        // tuning (tune/tune_ng.hip): the two-pass copy for fp64 tiles too (six compute waves + two copy waves)
-    constexpr int NPASS = (NCC == 2 && !GATHER) ? 2 : 1;
-#else
-    constexpr int NPASS = (sizeof(T) == 4 && NCC == 2 && !GATHER) ? 2 : 1;
-#endif
+    constexpr int NPASS = ((sizeof(T) == 4 || Tune::NPASS_ANY) && NCC == 2 && !GATHER) ? 2 : 1;      // (Tune::NPASS_ANY: fp64 tiles too, tune/tune_ng.hip)
     constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -720,24 +700,16 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // points, +2 % at 1 M).  Short launches keep the plain order: with a handful of tiles per workgroup the XCD ranges cost 1-4 % (and 15 % for
     // 64 fused batches of 1 024 knot points); a contiguous range per WORKGROUP costs 5-9 % at every size.
     long long tile, tend, tstep;
-#if defined(RD_TILE_MAP_RUNTIME)                 // tuning (tune/tune_bign.hip): the order chosen at run time through a device global
-    // g_tile_map = 0: plain; 100 R + v (R = 1, 2, 4 ranges per XCD): every XCD walks R contiguous ranges of ntiles / (8 R) tiles, its workgroups split
-    // into R groups; v = 0: an XCD's ranges are adjacent (range xcd R + sub), v = 1: interleaved (range sub 8 + xcd)
-    const int mp_ = g_tile_map;
+    // (tuning, tune/tune_bign.hip: Tune::tile_map_runtime() = 100 R + v, R = 1, 2, 4 ranges per XCD: every XCD walks R contiguous ranges of ntiles / (8 R)
+    // tiles, its workgroups split into R groups; v = 0: an XCD's ranges are adjacent (range xcd R + sub), v = 1: interleaved (range sub 8 + xcd).
+    // Tune::TILE_MAP = 0 / 2: the plain order / the XCD ranges at every size.  The library's policy returns 0 and 1: both fold away.)
+    const int mp_ = Tune::tile_map_runtime();
     if (mp_ >= 100 && (nwg & 7) == 0) {
         const int R = mp_ / 100, v = mp_ % 100;
         const long long xcd = wg & 7, j = wg >> 3, sub = j % R, jj = j / R, nr = 8LL * R;
         const long long rid = v == 0 ? xcd * R + sub : sub * 8 + xcd, ntr = (ntiles + nr - 1) / nr;
         tile = rid * ntr + jj; tend = ((rid + 1) * ntr < ntiles) ? (rid + 1) * ntr : ntiles; tstep = (nwg >> 3) / R;
-    } else
-#endif
-#if defined(RD_TILE_MAP) && RD_TILE_MAP == 0     // tuning: the plain order
-    if (false) {
-#elif defined(RD_TILE_MAP) && RD_TILE_MAP == 2   // tuning: XCD ranges at every size
-    if ((nwg & 7) == 0 && !WaitsOf<BT>::value) {
-#else
-    if ((nwg & 7) == 0 && ntiles >= 64 * (long long)nwg && !WaitsOf<BT>::value) {     // (tiles that are waited for keep the order in which they become available)
-#endif
+    } else if (Tune::TILE_MAP != 0 && (nwg & 7) == 0 && (Tune::TILE_MAP == 2 || ntiles >= 64 * (long long)nwg) && !WaitsOf<BT>::value) {     // (tiles that are waited for keep the order in which they become available)
         const long long ntx = (ntiles + 7) / 8, xcd = wg & 7;
         tile = xcd * ntx + (wg >> 3);
         tend = ((xcd + 1) * ntx < ntiles) ? (xcd + 1) * ntx : ntiles; tstep = nwg >> 3;
@@ -754,14 +726,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // all zero between launches -- the last workgroup to leave resets them.
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
     // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
-#if defined(RD_DYN_F32)                          // tuning (tune/tune_dyn.hip -DTT=float): the counter for fp32 tiles too, RD_DYN_CHUNK tiles per atomic
-    constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value;
-#else
-    constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && sizeof(T) == 8;
-#endif
-#ifndef RD_DYN_CHUNK
-#define RD_DYN_CHUNK 1
-#endif
+    // (Tune::DYN_F32, tune/tune_dyn.hip -DTT=float: the counter for fp32 tiles too, Tune::DYN_CHUNK tiles per atomic)
+    constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && (sizeof(T) == 8 || Tune::DYN_F32);
+    constexpr int RD_DYN_CHUNK = Tune::DYN_CHUNK;
     constexpr int DYN_STATIC = 3;
     __shared__ long long sched_ring[4];
     unsigned* sched = nullptr;
@@ -772,15 +739,19 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // is used up moves on to the next XCD's range, so a fast XCD finishes a slow one's work.
     // Measured against the one counter over the plain order (tune/tune_dyn.hip -DRD_DYN_XR=..., two boxes): 2 M knots 792 -> 766 and 791 -> 716 us, 4 M
     // 1 581 -> 1 518 and 1 567 -> 1 426 us (0.78-0.83 of the roofline), but 1 M 317 -> 328 and 322 -> 336 us: from 128 tiles per workgroup on.
-#ifndef RD_DYN_XR
-#define RD_DYN_XR 128
-#endif
+    constexpr int RD_DYN_XR = Tune::DYN_XR;
     const bool xr = dyn && (nwg & 7) == 0 && ntiles >= RD_DYN_XR * (long long)nwg;
     const long long xr_ntx = (ntiles + 7) / 8;
     const int xr_nxw = (int)(nwg >> 3), xr_own = (int)(wg & 7);
     if (dyn) { tile = wg; tend = ntiles; tstep = nwg; }        // (plain order, whatever the static map would have been)
     if (xr) { tile = xr_own * xr_ntx + (wg >> 3); tstep = xr_nxw; }   // the first DYN_STATIC tiles: the head of the own range, strided over the XCD's workgroups
-    auto leave = [&]() {                                       // (one thread per workgroup)
+    // (one thread per workgroup, thread 0.)  Its counter fetch-adds must be PERFORMED before its done count is issued -- the workgroup that counts last
+    // stores zeros, and a fetch-add that arrives behind them would leave a counter non-zero for the slot's next launch, which would then silently skip
+    // tiles: the last three fetches of a workgroup return values nobody waits for, so the wait is explicit (vmcnt(0): this wave has no stores in flight,
+    // the copy waves do the storing).  All of these are agent-scope read-modify-writes of one 64-byte line, executed where the line lives; "performed,
+    // then issued" orders them there whatever the route.  (The host also re-zeroes a stream's ring every time it comes round: api.hip take_sched.)
+    auto leave = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
             __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -825,7 +796,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         fr.yrow = yt + lane * NVAL;
         fr.zs = zs;
         TileRef<T> cur = at_uniform<T>(bt, tile);
-        if constexpr (WaitsOf<BT>::value) bt.wait(tile);
+        typename WaitsOf<BT>::Seen wseen; (void)wseen;       // (what this wave knows about the producers' progress: see the descriptor's wait)
+        if constexpr (WaitsOf<BT>::value) bt.wait(cur, wseen);
         {   // first tile: all of a thread's loads are issued before any is waited for (a load -> wait -> LDS-write loop costs one memory
             // round trip per pass: five of them in front of the first arithmetic of the kernel)
             const long long k0 = cur.k0, N = cur.N, NIN = N + Fn::NEXT;
@@ -835,12 +807,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             T z0[ZPT]; double t0;
             if constexpr (GATHER) {
 #pragma unroll
-                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<WaitsOf<BT>::value>(Z + gather_z(cur, e < TILE * NZ ? e : 0)); }
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<CoherentOf<BT>::value>(Z + gather_z(cur, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 t0 = tp[gather_knot(cur, threadIdx.x & (TILE - 1))];
             } else {
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<WaitsOf<BT>::value>(Z + ((e < nin * NZ) ? k0 * NZ + e : 0)); }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; z0[r] = tile_load<CoherentOf<BT>::value>(Z + ((e < nin * NZ) ? k0 * NZ + e : 0)); }
             {
                 const double* tp = (threadIdx.x < TILE) ? cur.t : cur.dt;
                 const int idx = threadIdx.x & (TILE - 1);
@@ -872,7 +844,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             TileRef<T> nx;
             if (RING_N > 0 && !dyn && it + 1 < RING_N) nx = more ? ring_get<T>(ring[it + 1]) : cur;
             else nx = at_uniform<T>(bt, more ? nxt : tile);
-            if constexpr (WaitsOf<BT>::value) { if (more) bt.wait(nxt); }
+            if constexpr (WaitsOf<BT>::value) { if (more) bt.wait(nx, wseen); }
             const long long k1 = nx.k0;
             const T* __restrict__ Z = nx.Z;
             const int nk1 = more ? (int)((nx.N - k1) < TILE ? (nx.N - k1) : TILE) : 0;
@@ -880,12 +852,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             T zpre[ZPT]; double tpre;                       // unconditional prefetch of the next tile's inputs
             if constexpr (GATHER) {
 #pragma unroll
-                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<WaitsOf<BT>::value>(Z + gather_z(nx, e < TILE * NZ ? e : 0)); }
+                for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + gather_z(nx, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 tpre = tp[gather_knot(nx, threadIdx.x & (TILE - 1))];
             } else {
 #pragma unroll
-            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<WaitsOf<BT>::value>(Z + ((e < nin1 * NZ) ? k1 * NZ + e : 0)); }
+            for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + ((e < nin1 * NZ) ? k1 * NZ + e : 0)); }
             {
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 const int idx = threadIdx.x & (TILE - 1);
@@ -953,16 +925,12 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             __syncthreads();                                   // barrier 0
             bool first = ES > 0;
             for (int it = 0; tile < tend; tile = RD_NEXT_TILE(it), ++it) {
-#if !defined(RD_HELPER_CHAIN_FIRST)
-                if (first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
-#endif
+                if (!Tune::HELPER_CHAIN_FIRST && first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
                 const long long nxt = RD_NEXT_TILE(it);
                 RD_STAMP(it, 11);
                 if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
                 RD_STAMP(it, 12);
-#if defined(RD_HELPER_CHAIN_FIRST)             // tuning: the next tile's chain in front of barrier E
-                if (first) { __syncthreads(); first = false; }
-#endif
+                if (Tune::HELPER_CHAIN_FIRST && first) { __syncthreads(); first = false; }  // (tuning: the next tile's chain in front of barrier E)
                 __syncthreads();                               // barrier A
                 __syncthreads();                               // barrier B
             }

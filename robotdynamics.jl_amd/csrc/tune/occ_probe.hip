@@ -1,4 +1,5 @@
 #include <cstdio>
+#include "harness_tune.hpp"
 #include "../fam_lie.hpp"
 using namespace rd;
 int main() {

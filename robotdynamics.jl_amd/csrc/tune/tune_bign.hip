@@ -5,7 +5,8 @@
 #include <cstdlib>
 #include <vector>
 #define RD_TILE_MAP_RUNTIME 1
-namespace rd { __device__ int g_tile_map; }
+// (rd::g_tile_map: harness_tune.hpp)
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 using TT = double;

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 #ifndef KIND

@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 using Mdl = RigidBody<double, WRENCH_SATELLITE, false, true>;

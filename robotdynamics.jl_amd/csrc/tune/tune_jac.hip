@@ -5,6 +5,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include "harness_tune.hpp"
 #include "experimental_kernels.hpp"
 
 using namespace rd;

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 using Mdl = RigidBody<double, WRENCH_SATELLITE, false, true>;

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 #if defined(QUAD)

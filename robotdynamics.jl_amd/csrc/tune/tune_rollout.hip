@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "harness_tune.hpp"
 #include "../dispatch.hpp"
 using namespace rd;
 #ifndef TUNE_T

@@ -6,6 +6,7 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#include "harness_tune.hpp"
 #include "../fam_rigid.hpp"
 using namespace rd;
 #ifndef KIND

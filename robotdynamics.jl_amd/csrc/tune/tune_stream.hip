@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include "harness_tune.hpp"
 #include "../dispatch.hpp"
 #include "../rollout_stream.hpp"
 using namespace rd;

@@ -38,7 +38,7 @@ const librdhip = get(ENV, "RDHIP_LIB", joinpath(@__DIR__, "..", "lib", "librdhip
 const MODEL_CARTPOLE, MODEL_DOUBLE_INTEGRATOR, MODEL_LINEAR, MODEL_SATELLITE, MODEL_QUADROTOR, MODEL_SATELLITE_PAIR, MODEL_LIE_SATELLITE, MODEL_CUSTOM = 0:7
 const ROT_QUAT, ROT_MRP, ROT_RP = 0:2
 const FRAME_WORLD, FRAME_BODY = 0:1
-const CONTINUOUS, EULER, RULE_RK2, RULE_RK3, RULE_RK4, IMPLICIT_MIDPOINT = -1:4
+const CONTINUOUS, EULER, RULE_RK2, RULE_RK3, RULE_RK4, IMPLICIT_MIDPOINT, DISCRETE = -1:5
 const FORWARD_AD, FINITE_DIFF, USER_DEFINED = 0:2
 const F64, F32 = 0:1
 const DEVICE, HOST = 0:1
@@ -261,6 +261,18 @@ mutable struct Handle
         finalizer(x -> ccall((:rdhip_model_destroy, librdhip), Cint, (Ptr{Cvoid},), x.ptr), h)
         return h
     end
+    # a user-defined DISCRETE model: `step_source` is the body of  template <class S> __device__ void step(const S* x, const S* u, T t, T h, S* xn) const,
+    # `jac_source` (or nothing) the body of its own jacobian!:  __device__ void jac(const T* x, const T* u, T t, T h, T* J) const
+    function Handle(::Val{:discrete}, n::Integer, m::Integer, step_source::AbstractString, jac_source::Union{Nothing,AbstractString}, preamble::AbstractString,
+                    params::Vector{Float64}, rot::Integer, P::Vector{Cint})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:rdhip_model_create_custom_discrete, librdhip), Cint, (Cint, Cint, Cstring, Cstring, Cstring, Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}),
+                   n, m, step_source, jac_source === nothing ? C_NULL : jac_source, preamble, params, length(params), rot, P, length(P), out)
+        check(nothing, rc)
+        h = new(out[])
+        finalizer(x -> ccall((:rdhip_model_destroy, librdhip), Cint, (Ptr{Cvoid},), x.ptr), h)
+        return h
+    end
 end
 
 rotcode(::Type{<:QuatRotation}) = ROT_QUAT
@@ -445,8 +457,11 @@ struct CustomModel{F} <: RobotDynamics.ContinuousDynamics
     f::F
     handle::Handle
 end
-CustomModel(n::Integer, m::Integer, f, hip_source::AbstractString; params=Float64[], preamble::AbstractString="") =
-    CustomModel(Int(n), Int(m), f, Handle(n, m, hip_source, preamble, collect(Float64, params), ROT_QUAT, Cint[]))
+function CustomModel(n::Integer, m::Integer, f, hip_source::AbstractString; params=Float64[], preamble::AbstractString="", jacobian::Union{Nothing,AbstractString}=nothing)
+    model = CustomModel(Int(n), Int(m), f, Handle(n, m, hip_source, preamble, collect(Float64, params), ROT_QUAT, Cint[]))
+    jacobian === nothing || set_user_jacobian!(model, jacobian)
+    return model
+end
 struct CustomLieModel{R,F} <: RobotDynamics.LieGroupModel
     P::Tuple{Vararg{Int}}
     m::Int
@@ -456,6 +471,43 @@ end
 function CustomLieModel(::Type{R}, P::Tuple{Vararg{Int}}, m::Integer, f, hip_source::AbstractString; params=Float64[], preamble::AbstractString="") where {R}
     n = length(RD.LieState(R, P))
     CustomLieModel{R,typeof(f)}(P, Int(m), f, Handle(n, m, hip_source, preamble, collect(Float64, params), rotcode(R), collect(Cint, P)))
+end
+"""
+    set_user_jacobian!(model, hip_source)
+
+The model's OWN `jacobian!(model, J, xdot, x, u, t)` (src/dynamics.jl:115-116) as the body of `__device__ void jac(const T* x, const T* u, T t, T* J) const`
+(J: n x (n+m) column-major, zero on entry).  `UserDefined()` then evaluates these formulas: directly for the continuous model, through the integrators'
+chain rule on the stage Jacobians (src/integration.jl:85-93, :149-177, :302-337) for `DiscretizedDynamics` of models with n + m <= 10
+(rdhip_model_set_user_jacobian).  Without it `UserDefined()` is the matrix-free chain rule on forward duals of the dynamics.
+"""
+set_user_jacobian!(model, hip_source::AbstractString) = (check(nothing, ccall((:rdhip_model_set_user_jacobian, librdhip), Cint, (Ptr{Cvoid}, Cstring), handle(model), hip_source)); model)
+
+"""
+    CustomDiscreteModel(n, m, f, step_source; jacobian=nothing, params=Float64[], preamble="")
+
+A user-defined `DiscreteDynamics` model (src/discrete_dynamics.jl:1-108; test/discrete_dynamics_test.jl:5-63): `f(x, u, t, dt)` is the Julia
+`discrete_dynamics` (CPU, per knot point), `step_source` the body of `template <class S> __device__ void step(const S* x, const S* u, T t, T h, S* xn) const`
+for the batched GPU path, `jacobian` the body of its own `jacobian!(model, J, xn, x, u, t, dt)` (what `UserDefined()` evaluates; without it the reference's
+"User-defined discrete dynamics Jacobian not defined." error).  The default diff method is `ForwardAD()`, as `@autodiff` gives a discrete model.
+"""
+struct CustomDiscreteModel{F} <: RobotDynamics.DiscreteDynamics
+    n::Int
+    m::Int
+    f::F
+    handle::Handle
+end
+CustomDiscreteModel(n::Integer, m::Integer, f, step_source::AbstractString; jacobian::Union{Nothing,AbstractString}=nothing, params=Float64[], preamble::AbstractString="") =
+    CustomDiscreteModel(Int(n), Int(m), f, Handle(Val(:discrete), n, m, step_source, jacobian, preamble, collect(Float64, params), ROT_QUAT, Cint[]))
+RobotDynamics.state_dim(model::CustomDiscreteModel) = model.n
+RobotDynamics.control_dim(model::CustomDiscreteModel) = model.m
+RobotDynamics.discrete_dynamics(model::CustomDiscreteModel, x, u, t, dt) = model.f(x, u, t, dt)
+RobotDynamics.discrete_dynamics!(model::CustomDiscreteModel, xn, x, u, t, dt) = (xn .= model.f(x, u, t, dt); nothing)
+RobotDynamics.default_diffmethod(::CustomDiscreteModel) = RD.ForwardAD()
+"`true` for a model whose rule is RDHIP_DISCRETE (rdhip_model_is_discrete)"
+function is_discrete(model)
+    r = Ref{Cint}(0)
+    check(nothing, ccall((:rdhip_model_is_discrete, librdhip), Cint, (Ptr{Cvoid}, Ref{Cint}), handle(model), r))
+    return r[] != 0
 end
 const AnyCustom = Union{CustomModel,CustomLieModel}
 RobotDynamics.state_dim(model::CustomModel) = model.n
@@ -588,6 +640,7 @@ function RobotDynamics.jacobian!(::RK2, sig::RD.FunctionSignature, model, J, xn,
 end
 
 rulecode(::RD.ContinuousDynamics) = CONTINUOUS
+rulecode(::CustomDiscreteModel) = DISCRETE
 rulecode(m::RD.DiscretizedDynamics) = rulecode(RD.integration(m))
 rulecode(::RD.Euler) = EULER
 rulecode(::RK2) = RULE_RK2
@@ -837,7 +890,9 @@ function error_expansion!(fun::RD.DiscretizedDynamics, E::Dense{T,3}, Y::Union{N
 end
 
 # errstate_jacobian!(model, G[:,:,k], Z[k]) for all k (src/statevectortype.jl:119-122; src/liestate.jl:262-298).
-# `clear=false` reproduces the reference: G is accumulated into, not cleared (RotationState models).
+# `clear=false` reproduces the reference: G is accumulated into, not cleared (RotationState models).  If you zero G before every call -- the reference's own
+# pattern, src/trajectories.jl:428-433 -- pass `clear=true` instead and drop the zeroing: G leaves as one dense write of whole lines (63 us at 262 144
+# quadrotor knots) where the untouched-entries mode pays a read-modify-write of every line for its 21 scattered values (131 us, plus your memset).
 function RobotDynamics.errstate_jacobian!(fun::RD.AbstractModel, G::Dense{T,3}, Z::AbstractPackedTrajectory{n,m,T}; clear::Bool=false,
                                           ctx::Union{Nothing,Context}=nothing) where {n,m,T}
     _checkmodel(fun, Z)

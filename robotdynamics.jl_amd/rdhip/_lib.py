@@ -17,7 +17,7 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_NO_DEVIC
 MODEL_CARTPOLE, MODEL_DOUBLE_INTEGRATOR, MODEL_LINEAR, MODEL_SATELLITE, MODEL_QUADROTOR, MODEL_SATELLITE_PAIR, MODEL_LIE_SATELLITE, MODEL_CUSTOM = range(8)
 ROT_QUAT, ROT_MRP, ROT_RP = range(3)
 FRAME_WORLD, FRAME_BODY = range(2)
-CONTINUOUS, EULER, RK2, RK3, RK4, IMPLICIT_MIDPOINT = -1, 0, 1, 2, 3, 4
+CONTINUOUS, EULER, RK2, RK3, RK4, IMPLICIT_MIDPOINT, DISCRETE = -1, 0, 1, 2, 3, 4, 5
 FORWARD_AD, FINITE_DIFF, USER_DEFINED = range(3)
 F64, F32 = range(2)
 DEVICE, HOST = range(2)
@@ -68,6 +68,9 @@ _SIGS = {
     "rdhip_model_set_newton": (C.c_int, [_P, C.c_int, C.c_double]),
     "rdhip_model_balance_columns": (C.c_int, [_P]),
     "rdhip_model_set_cascade": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rdhip_model_create_custom_discrete": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _DP, C.c_int, C.c_int, _IP, C.c_int, C.POINTER(_P)]),
+    "rdhip_model_set_user_jacobian": (C.c_int, [_P, C.c_char_p]),
+    "rdhip_model_is_discrete": (C.c_int, [_P, _IP]),
     "rdhip_model_dims": (C.c_int, [_P, _IP, _IP, _IP, _IP]),
     "rdhip_model_statevectortype": (C.c_int, [_P, _IP]),
     "rdhip_model_liestate": (C.c_int, [_P, _IP, _IP, _IP]),
