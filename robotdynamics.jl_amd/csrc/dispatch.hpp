@@ -351,8 +351,10 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             // The walk's second part (fused.hpp FusedWalk): the rollout workgroups produce G tiles per step, the nj Jacobian workgroups consume nj tiles per
             // tile time; while the rollout runs, the consumers get through  A = nj (K - 1) step / tile_time  tiles.  If that is (nearly) everything the
             // consumers keep up and there is no second part; otherwise the tiles behind A are shared by ALL workgroups, the former rollout workgroups
-            // included.  fp32, satellite RK4 (tune/tune_c5.hip, 4 096 x 256, round 5's consumers: 2.9 us per tile against 0.46 us per step): the best
-            // split of a sweep sits at 0.6-0.7 K, ratio 4.6 (it was 7.2, 0.40 K, while every tile paid a poll); calibrated on the satellite only.
+            // included.  fp32, satellite RK4 (tune/tune_c5.hip QUICK mode -- one process per split, 1.5 s of load first, the first measurement behind it:
+            // the only numbers that repeat to +-1 us; a sweep inside one process drifts by 10 % with the chip's power state --, 4 096 x 256): 234 / 228 /
+            // 221 / 224 / 227 / 231 / 232 us at 0.40 / 0.45 / 0.50 / 0.55 / 0.60 / 0.65 / 0.70 K, i.e. ratio 5.9 (at the minimum the former rollout
+            // workgroups and the Jacobian workgroups end together, 205-213 and 208-218 us); calibrated on the satellite only.
             // fp64 takes NO second part: its 126 KB tiles are bandwidth-bound on three quarters of the chip already (the plain kernel is faster on
             // 192 workgroups than on 256, launch_split_kernel above) -- 4 096 x 101 knots 162-166 us without, 173-181 us with a split anywhere
             // between 0.3 and 0.55 K.  RDHIP_FUSED_RATIO (tuning) forces a ratio for either type.
@@ -362,7 +364,7 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             const long long nj_env = [] { const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS"); return e ? atoll(e) : 0LL; }();
             auto split_of = [&](long long ntiles, long long nj) -> long long {
                 if (sizeof(T) == 8 && !(ratio_env > 0)) return 0;
-                const double ratio = ratio_env > 0 ? ratio_env : 4.6;
+                const double ratio = ratio_env > 0 ? ratio_env : 5.9;
                 const double A = (double)nj * (double)(K - 1) / ratio;
                 if (G < 8 || A >= 0.85 * (double)ntiles) return 0;
                 long long sp = (long long)A; sp -= sp % G;

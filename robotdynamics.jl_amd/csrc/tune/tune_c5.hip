@@ -61,9 +61,10 @@ int main(int argc, char** argv) {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int G = (int)((M + 63) / 64);
-    using FL = FusedLds<Fn, TT, Cas, 4, SatPlan, FNC>;
+        using FL = FusedLds<Fn, TT, Cas, 4, SatPlan, FNC>;
+    const int GW = G;
     constexpr int FT = FUSED_THREADS;
-    auto kf = rollout_jac_fused_kernel<Fn, TT, Cas, 4, SatPlan, FNC, true>;
+        auto kf = rollout_jac_fused_kernel<Fn, TT, Cas, 4, SatPlan, FNC, true>;
     CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
     auto kj = jac_ad_split_kernel<Fn, TT, SatPlan, 4>;
     constexpr size_t ldsj = SplitLds<Fn, TT, SatPlan, 4>::BYTES;
@@ -81,7 +82,15 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %8.2f us  (%.3f of 8 TB/s on the judge's bytes)\n", name, ms * 1e3 / reps, alg / (ms * 1e-3 / reps) / 8e12);
     };
-    timeit("rollout alone (fused kernel, grid = G)", [&]() { hipLaunchKernelGGL(kf, dim3(G), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, (TT*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL); });
+    const bool quick = argc > 3 && argv[3][0] == 'f';
+    std::vector<double> fracs = {0.0, 0.4, 0.45, 0.5, 0.55, 0.6, 0.7};
+    if (quick) { fracs.clear(); for (int i = 4; i < argc; ++i) fracs.push_back(atof(argv[i])); }
+    if (quick) {      // ~200 ms of load first: the clocks settle over ~100 ms, a short warm-up measures the ramp
+        for (int i = 0; i < 6000; ++i) { ++epoch; hipLaunchKernelGGL(kf, dim3(256), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, 0LL); }
+        CK(hipStreamSynchronize(s));
+    }
+    if (!quick) {
+    timeit("rollout alone (fused kernel, grid = G)", [&]() { hipLaunchKernelGGL(kf, dim3(GW), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, (TT*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL); });
     timeit("Jacobians alone (256 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr, (unsigned*)nullptr); });
     {   // the non-split tile loop: 4 waves that compute and then copy, 256 threads, two workgroups per CU (a 6-wave workgroup above 128 registers never
         // shares a CU with a second one, whatever the occupancy API says: tune/occ_place.hip)
@@ -98,7 +107,7 @@ int main(int argc, char** argv) {
         auto cons_only = cons_only_w<1>; auto cons_only2 = cons_only_w<2>;
         CK(hipFuncSetAttribute((const void*)cons_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
         CK(hipFuncSetAttribute((const void*)cons_only2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
-        ++epoch; hipLaunchKernelGGL(kf, dim3(G), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, (TT*)nullptr, prog, epoch << 32, 0LL);
+        ++epoch; hipLaunchKernelGGL(kf, dim3(GW), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, (TT*)nullptr, prog, epoch << 32, 0LL);
         CK(hipStreamSynchronize(s));
         const unsigned long long pb = epoch << 32;
         timeit("consumer role alone behind the rollout (256)", [&]() { hipLaunchKernelGGL(cons_only, dim3(256), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
@@ -140,28 +149,30 @@ int main(int argc, char** argv) {
         timeit("consumer role alone behind the rollout (192)", [&]() { hipLaunchKernelGGL(cons_only, dim3(192), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
     }
     timeit("Jacobians alone (192 workgroups)", [&]() { hipLaunchKernelGGL(kj, dim3(192), dim3(512), ldsj, s, fn, N, Z, t, dt, J, (TT*)nullptr, (unsigned*)nullptr); });
-    for (double split_frac : {0.0, 0.3, 0.4, 0.45, 0.5, 0.55, 0.6, 0.7})
-    for (int nj : {occ * 256 - G}) {
+    }
+    for (double split_frac : fracs)
+    for (int nj : {occ * 256 - GW}) {
         if (nj <= 0) continue;
-        char name[96]; snprintf(name, sizeof name, "fused: %d rollout + %d Jacobian workgroups, split at %.2f", G, nj, split_frac);
+        char name[96]; snprintf(name, sizeof name, "fused: %d rollout + %d Jacobian workgroups, split at %.2f", GW, nj, split_frac);
         const long long split = (long long)(split_frac * K) * G;
-        timeit(name, [&]() { ++epoch; hipLaunchKernelGGL(kf, dim3(G + nj), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, split); });
+        timeit(name, [&]() { ++epoch; hipLaunchKernelGGL(kf, dim3(GW + nj), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, split); });
 #if defined(RD_FUSED_STAMP)
         std::vector<unsigned long long> hp(4096);
         CK(hipMemcpy(hp.data(), stamps, 4096 * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ULL; for (int b = 0; b < G + nj; ++b) t0 = std::min(t0, hp[2048 + b]);
+        unsigned long long t0 = ~0ULL; for (int b = 0; b < GW + nj; ++b) t0 = std::min(t0, hp[2048 + b]);
         double rs = 0, re = 0, js = 0, je = 0, jemin = 1e30, remin = 1e30;
-        for (int b = 0; b < G; ++b) { rs = std::max(rs, (hp[2048 + b] - t0) * 0.01); re = std::max(re, (hp[1024 + b] - t0) * 0.01); remin = std::min(remin, (hp[1024 + b] - t0) * 0.01); }
-        for (int b = G; b < G + nj; ++b) { js = std::max(js, (hp[2048 + b] - t0) * 0.01); je = std::max(je, (hp[1024 + b] - t0) * 0.01); jemin = std::min(jemin, (hp[1024 + b] - t0) * 0.01); }
-        double p2 = 0, p2min = 1e30; for (int b = 0; b < G; ++b) { if (hp[3072 + b] > t0) { p2 = std::max(p2, (hp[3072 + b] - t0) * 0.01); p2min = std::min(p2min, (hp[3072 + b] - t0) * 0.01); } }
+        for (int b = 0; b < GW; ++b) { rs = std::max(rs, (hp[2048 + b] - t0) * 0.01); re = std::max(re, (hp[1024 + b] - t0) * 0.01); remin = std::min(remin, (hp[1024 + b] - t0) * 0.01); }
+        for (int b = GW; b < GW + nj; ++b) { js = std::max(js, (hp[2048 + b] - t0) * 0.01); je = std::max(je, (hp[1024 + b] - t0) * 0.01); jemin = std::min(jemin, (hp[1024 + b] - t0) * 0.01); }
+        double p2 = 0, p2min = 1e30; for (int b = 0; b < GW; ++b) { if (hp[3072 + b] > t0) { p2 = std::max(p2, (hp[3072 + b] - t0) * 0.01); p2min = std::min(p2min, (hp[3072 + b] - t0) * 0.01); } }
         printf("    rollout workgroups: last start %.1f us, end %.1f .. %.1f us (their second phase: %.1f .. %.1f);  Jacobian workgroups: last start %.1f us, end %.1f .. %.1f us\n", rs, remin, re, p2min, p2, js, jemin, je);
         CK(hipMemset(stamps + 3072, 0, 1024 * 8));
 #endif
     }
+    if (!quick)
     {   // check: the fused launch's Jacobians against the plain kernel's on the same rolled-out states
         TT* J2; CK(hipMalloc(&J2, N * NX * NZ * sizeof(TT)));
         CK(hipMemsetAsync(J, 0xff, N * NX * NZ * sizeof(TT), s));
-        ++epoch; hipLaunchKernelGGL(kf, dim3(G + occ * 256 - G), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, (long long)(0.4 * K) * G);
+        ++epoch; hipLaunchKernelGGL(kf, dim3(occ * 256), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, (long long)(0.4 * K) * G);
         hipLaunchKernelGGL(kj, dim3(256), dim3(512), ldsj, s, fn, N, Z, t, dt, J2, (TT*)nullptr, (unsigned*)nullptr);
         CK(hipStreamSynchronize(s));
         std::vector<TT> a((size_t)N * NX * NZ), b((size_t)N * NX * NZ);
