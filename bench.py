@@ -116,6 +116,19 @@ def _timed_us(fn, reps, warm=20, load_s=0.1):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def _pmc_rows(case):
+    """HBM bytes per launch of the non-flagship kernels from the committed counter run (tools/pmc_kernels.sh -> profiles/r05/pmc_kernels.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, calibrated in the same session); {} when the file is missing.  Not measured in this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05", "pmc_kernels.json")) as fh:
+            return {r["kernel"]: r for r in json.load(fh)["rows"] if r["case"] == case}
+    except Exception:
+        return {}
+
+
+PMC_SOURCE = "profiles/r05/pmc_kernels.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes, calibrated on 1 GiB in the same session); not measured in this run"
+
+
 def secondary_metrics(dev, reps):
     """SURVEY 8(d) secondary metrics on rank 0's GPU, HIP-event timed back-to-back launches, bare C-ABI calls: RK4 discrete_dynamics evaluations/s
     (C3's other half, 65 536 satellite knot points), error-state Jacobians/s (C4's per-GPU kernel, Quadrotor, 262 144 knot points, dense G), and
@@ -147,6 +160,10 @@ def secondary_metrics(dev, reps):
     b = 13 * 8 + 13 * 12 * 8
     out["errstate_jacobian_quadrotor"] = {"knot_points": Nq, "value": Nq / (us * 1e-6), "unit": "error-state Jacobians/s", "us_per_launch": us, "bytes_per_knot": b,
                                           "frac_of_hbm_peak": Nq * b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    pr = _pmc_rows("errstate_jacobian_262144").get("errstate_tile_kernel")
+    if pr:
+        out["errstate_jacobian_quadrotor"].update({"traffic": pr["write_bytes"] + pr["read_bytes"], "traffic_over_algorithmic": (pr["write_bytes"] + pr["read_bytes"]) / (Nq * b),
+                                                   "traffic_source": PMC_SOURCE})
     # the other diff methods / rules on the headline batch (same bytes per knot point as the headline kernel)
     dm = RD.DiscretizedDynamics(sat, RD.RK4)
     dmi = RD.DiscretizedDynamics(sat, RD.ImplicitMidpoint)
@@ -198,10 +215,17 @@ def secondary_metrics(dev, reps):
         c5 = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stacks, None, time_major=True)
         us = _timed_us(lambda i: c5(), 20, warm=2)
         alg = Mc * Kr * ((1080 + 52) + (116 + 16))
-        return {"trajectories": 2 * Mc, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mc * Kr / (us * 1e-6),
-                "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi", "dtype": "f32",
-                "algorithmic_bytes": alg, "bytes_per_knot": {"satellite": 1080 + 52, "cartpole": 116 + 16},
-                "GBps": alg / (us * 1e-6) / 1e9, "frac_of_hbm_peak": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        res = {"trajectories": 2 * Mc, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mc * Kr / (us * 1e-6),
+               "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi", "dtype": "f32",
+               "algorithmic_bytes": alg, "bytes_per_knot": {"satellite": 1080 + 52, "cartpole": 116 + 16},
+               "GBps": alg / (us * 1e-6) / 1e9, "frac_of_hbm_peak": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        pr = _pmc_rows("c5_whole_one_call_fp32") if Mc == 4096 else {}
+        if all(k in pr for k in ("rollout_jac_fused_kernel", "rollout_kernel", "jac_ad_small_kernel")):
+            # one call = the satellite's fused launch + the cartpole's four pieces (rollout + Jacobians each); the counters also see what the judge's
+            # bytes leave out: the rollouts' own reads of controls and times
+            tr = sum((pr[k]["write_bytes"] + pr[k]["read_bytes"]) * n for k, n in (("rollout_jac_fused_kernel", 1), ("rollout_kernel", 4), ("jac_ad_small_kernel", 4)))
+            res.update({"traffic": tr, "traffic_over_algorithmic": tr / alg, "traffic_source": PMC_SOURCE})
+        return res
     for key, Mc in (("c5_whole_one_gpu_one_call_fp32", 4096), ("c5_share_one_call_fp32", Mr)):
         try:
             out[key] = c5_case(Mc)

@@ -45,6 +45,46 @@ function RD.dynamics(model::Cartpole, x, u)
     return [qd; qdd]
 end
 
+# test/cartpole_model.jl:57-96: the hand-written continuous Jacobian -- what UserDefined() evaluates (dyn_case: key Jud_rk4; user_jacobian_case below)
+function RD.jacobian!(model::Cartpole, J, xdot, x, u, t)
+    mc, mp, l, g = model.mc, model.mp, model.l, model.g
+    q = x[SA[1, 2]]; qd = x[SA[3, 4]]
+    s = sin(q[2]); c = cos(q[2])
+    H = @SMatrix [mc+mp mp*l*c; mp*l*c mp*l^2]
+    C = @SMatrix [0 -mp*qd[2]*l*s; 0 0]
+    G = @SVector [0, mp * g * l * s]
+    B = @SVector [1, 0]
+    qdd = -H \ (C * qd + G - B * u[1])
+    dH = SA[0 -mp*l*s*qdd[2] 0 0 0; 0 -mp*l*s*qdd[1] 0 0 0]
+    dC = SA[0 -mp*l*c*qd[2]^2 0 -2*mp*l*qd[2]*s 0; 0 0 0 0 0]
+    dG = SA[0 0 0 0 0; 0 mp*g*l*c 0 0 0]
+    dB = SA[0 0 0 0 1; 0 0 0 0 0]
+    J[1:2, :] .= 0
+    J[1, 3] = 1.0
+    J[2, 4] = 1.0
+    J[3:4, :] .= H \ (-dH - dC - dG + dB)
+    return nothing
+end
+
+# test/discrete_dynamics_test.jl:5-63: a model that IS a discrete map (no integrator) with its own Jacobian
+struct DiscreteDI <: RobotDynamics.DiscreteDynamics end
+RD.state_dim(::DiscreteDI) = 4
+RD.control_dim(::DiscreteDI) = 2
+RD.discrete_dynamics(::DiscreteDI, x, u, t, dt) = SA[x[1] + x[3] * dt, x[2] + x[4] * dt, x[3] + u[1] * dt, x[4] + u[2] * dt]
+function RD.discrete_dynamics!(::DiscreteDI, xn, x, u, t, dt)
+    xn[1] = x[1] + x[3] * dt; xn[2] = x[2] + x[4] * dt; xn[3] = x[3] + u[1] * dt; xn[4] = x[4] + u[2] * dt
+    return nothing
+end
+function RD.jacobian!(::DiscreteDI, J, xn, x, u, t, dt)
+    J .= 0
+    J[1, 1] = 1; J[1, 3] = dt; J[2, 2] = 1; J[2, 4] = dt; J[3, 3] = 1; J[3, 5] = dt; J[4, 4] = 1; J[4, 6] = dt
+    return nothing
+end
+function RD.jacobian!(::RD.StaticReturn, ::RD.ForwardAD, model::DiscreteDI, J, y, z)
+    f(_z) = RD.evaluate(model, RD.getstate(z, _z), RD.getcontrol(z, _z), RD.getparams(z))
+    J .= ForwardDiff.jacobian(f, RD.getdata(z))
+end
+
 # test/double_integrator.jl:97-107
 RD.@autodiff struct DI{D} <: RobotDynamics.ContinuousDynamics end
 RD.state_dim(::DI{D}) where {D} = 2D
@@ -380,6 +420,64 @@ function tv_case()
     end
 end
 
+# ------------------------------------------------------------------------------------------------ round 5: discrete models, user Jacobians, NaN knot points
+# discrete_di.npz / userjac_cartpole.npz / nan_satellite.npz hold the inputs (tests/golden/make_golden_round5.py); the product's plug-in bodies
+# (rdhip_model_create_custom_discrete, rdhip_model_set_user_jacobian) and its NaN contract (include/rdhip.h) are tested against these quantities
+function discrete_case()
+    d = npzread(joinpath(HERE, "discrete_di.npz"))
+    Z, t, dt = d["Z"], d["t"], d["dt"]; N = size(Z, 1)
+    model = DiscreteDI()
+    out = Dict{String,Any}("Z" => Z, "t" => t, "dt" => dt, "xn" => zeros(N, 4), "J_user" => zeros(N, 4, 6), "J_ad" => zeros(N, 4, 6),
+                           "e" => zeros(N - 1, 4), "J1" => zeros(N - 1, 4, 6), "J2" => zeros(N - 1, 4, 6))
+    J = zeros(4, 6); J2 = zeros(4, 6); y = zeros(4); y2 = zeros(4)
+    for k = 1:N
+        z = knot(Z, t, dt, k, 4, 2)
+        out["xn"][k, :] = RD.discrete_dynamics(model, z)
+        RD.jacobian!(RD.StaticReturn(), RD.UserDefined(), model, J, y, z); out["J_user"][k, :, :] = J
+        RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), model, J, y, z); out["J_ad"][k, :, :] = J
+        if k < N
+            z2 = knot(Z, t, dt, k + 1, 4, 2)
+            out["e"][k, :] = RD.dynamics_error(model, z2, z)
+            RD.dynamics_error_jacobian!(RD.StaticReturn(), RD.UserDefined(), model, J2, J, y2, y, z2, z)       # src/discrete_dynamics.jl:111-113, 160-176
+            out["J1"][k, :, :] = J; out["J2"][k, :, :] = J2
+        end
+    end
+    npzwrite(joinpath(HERE, "ref_discrete_di.npz"), out)
+end
+function user_jacobian_case()
+    d = npzread(joinpath(HERE, "userjac_cartpole.npz"))
+    Z, t, dt = d["Z"], d["t"], d["dt"]; N = size(Z, 1)
+    p = d["params"]; model = Cartpole(p[1], p[2], p[3], p[4])
+    out = Dict{String,Any}("Z" => Z, "t" => t, "dt" => dt, "Jc_user" => zeros(N, 4, 5))
+    J = zeros(4, 5); y = zeros(4)
+    rules = (("euler", RD.Euler), ("rk3", RD.RK3), ("rk4", RD.RK4))
+    for (rn, _) in rules
+        out["Jd_user_$rn"] = zeros(N, 4, 5)
+    end
+    for k = 1:N
+        z = knot(Z, t, dt, k, 4, 1)
+        RD.jacobian!(RD.StaticReturn(), RD.UserDefined(), model, J, y, z); out["Jc_user"][k, :, :] = J
+        for (rn, Q) in rules          # the integrators' chain rule on the stage Jacobians (src/integration.jl:149-177, 302-337)
+            RD.jacobian!(RD.StaticReturn(), RD.UserDefined(), RD.DiscretizedDynamics{Q}(model), J, y, z); out["Jd_user_$rn"][k, :, :] = J
+        end
+    end
+    npzwrite(joinpath(HERE, "ref_userjac_cartpole.npz"), out)
+end
+function nan_case()        # a NaN-filled knot point (src/trajectories.jl:83) and dt = Inf on the last one (:104-108) through jacobian! and discrete_dynamics
+    d = npzread(joinpath(HERE, "nan_satellite.npz"))
+    Z, t, dt = d["Z"], d["t"], d["dt"]; N = size(Z, 1)
+    model = Sat{QR}(Float64(d["mass"][]), S33(d["J"]), false)
+    dm = RD.DiscretizedDynamics{RD.RK4}(model)
+    out = Dict{String,Any}("Z" => Z, "t" => t, "dt" => dt, "xn_rk4" => zeros(N, 13), "Jd_rk4" => zeros(N, 13, 19))
+    J = zeros(13, 19); y = zeros(13)
+    for k = 1:N
+        z = knot(Z, t, dt, k, 13, 6)
+        out["xn_rk4"][k, :] = RD.discrete_dynamics(dm, z)
+        RD.jacobian!(RD.StaticReturn(), RD.ForwardAD(), dm, J, y, z); out["Jd_rk4"][k, :, :] = J
+    end
+    npzwrite(joinpath(HERE, "ref_nan_satellite.npz"), out)
+end
+
 # ------------------------------------------------------------------------------------------------ the Julia host of this repository, once per wrapper
 # (robotdynamics.jl_amd/julia/RobotDynamicsHIP.jl needs librdhip.so and a GPU: skipped with a message otherwise).  Every batched wrapper is
 # called once on a small satellite batch and compared with the reference's per-knot loop computed above in this same session.
@@ -430,6 +528,7 @@ function main()
         rollout_case(name, Q, rn)
     end
     tv_case()
+    discrete_case(); user_jacobian_case(); nan_case()
     host_smoke()
     println("wrote reference-generated fixtures ref_*.npz to ", HERE, " (RobotDynamics ", pkgversion(RD), ")")
 end

@@ -27,7 +27,7 @@ def load(name):
         r = dict(np.load(ref))
         for k in ("Z", "t", "dt", "X", "Xbar", "X0"):
             if k in r and k in d:
-                assert np.array_equal(r[k], d[k]), f"ref_{name}.npz was generated from different inputs"
+                assert np.array_equal(r[k], d[k], equal_nan=True), f"ref_{name}.npz was generated from different inputs"
         d.update({k: v for k, v in r.items() if not (np.issubdtype(v.dtype, np.floating) and np.isnan(v).all())})
         d["_reference_derived"] = np.asarray(True)
     return d

@@ -494,3 +494,52 @@ def test_user_written_continuous_jacobian_of_the_cartpole(rule):
     Js = [RD.alloc_jacobians(fun, 300, Z.data), RD.alloc_jacobians(fun, N - 300, Z.data)]
     RD.jacobian_multi_(sig, RD.UserDefined(), fun, Js, None, Zs)
     np.testing.assert_array_equal(np.concatenate([host(Js[0]), host(Js[1])]), host(J))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the round's committed fixtures (tests/golden/make_golden_round5.py; with Julia: ref_*.npz from make_golden_reference.jl take their place key by key)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def test_discrete_model_and_user_jacobian_fixtures():
+    sig = RD.StaticReturn()
+    d = H.load("discrete_di")
+    N = d["Z"].shape[0]
+    di = RD.CustomDiscreteModel(4, 2, DI_STEP, jacobian=DI_JAC)
+    Z = RD.PackedTrajectory(4, 2, d["Z"], d["t"], d["dt"]).to("cuda")
+    J = RD.alloc_jacobians(di, N, Z.data); Y = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    for diff, key in ((RD.UserDefined(), "J_user"), (RD.ForwardAD(), "J_ad")):
+        RD.jacobian_(sig, diff, di, J, Y, Z)
+        np.testing.assert_allclose(host(J), d[key], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(host(Y), d["xn"], rtol=0, atol=1e-15)
+    J1 = RD.alloc_jacobians(di, N - 1, Z.data); J2 = RD.alloc_jacobians(di, N - 1, Z.data)
+    RD.dynamics_error_jacobian_(sig, RD.UserDefined(), di, J2, J1, None, None, Z)
+    np.testing.assert_allclose(host(J1), d["J1"], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(host(J2), d["J2"])
+    np.testing.assert_allclose(host(RD.dynamics_error(di, Z)), d["e"], rtol=0, atol=1e-15)
+    # the cartpole's hand-written Jacobian through UserDefined(): directly, and through every explicit rule's chain rule
+    d = H.load("userjac_cartpole")
+    N = d["Z"].shape[0]
+    cart = RD.CustomModel(4, 1, H.CARTPOLE_SRC, params=list(d["params"]), jacobian=CART_JAC)
+    Z = RD.PackedTrajectory(4, 1, d["Z"], d["t"], d["dt"]).to("cuda")
+    for rule, key in ((None, "Jc_user"), (RD.Euler, "Jd_user_euler"), (RD.RK2, "Jd_user_rk2"), (RD.RK3, "Jd_user_rk3"), (RD.RK4, "Jd_user_rk4")):
+        fun = cart if rule is None else RD.DiscretizedDynamics(cart, rule)
+        J = RD.alloc_jacobians(fun, N, Z.data)
+        RD.jacobian_(sig, RD.UserDefined(), fun, J, None, Z)
+        np.testing.assert_allclose(host(J), d[key], rtol=0, atol=TOL * max(1.0, np.abs(d[key]).max()))
+
+
+def test_nan_filled_knot_point_fixture():
+    """A knot point as Traj(n, m, dt, N) creates it (NaN-filled, src/trajectories.jl:83) and dt = Inf on the last knot (:104-108): every other knot point's
+    x_next and Jacobian are those of the clean batch (to the fixture's 1e-10), the poisoned one's are NaN."""
+    d = H.load("nan_satellite")
+    N = d["Z"].shape[0]
+    sat = RD.Satellite(mass=float(d["mass"]), J=d["J"])
+    dm = RD.DiscretizedDynamics(sat, RD.RK4)
+    Z = RD.PackedTrajectory(13, 6, d["Z"], d["t"], d["dt"]).to("cuda")
+    J = RD.alloc_jacobians(dm, N, Z.data); Y = torch.empty((N, 13), dtype=torch.float64, device="cuda")
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, Y, Z)
+    bad = np.concatenate([d["poisoned"], d["inf_dt"]])
+    good = np.setdiff1d(np.arange(N), bad)
+    np.testing.assert_allclose(host(J)[good], d["Jd_rk4"][good], rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(Y)[good], d["xn_rk4"][good], rtol=0, atol=TOL)
+    p = int(d["poisoned"][0])
+    assert np.isnan(host(Y)[p]).all() and np.isnan(host(J)[p]).any()

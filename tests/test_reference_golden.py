@@ -18,9 +18,11 @@ def test_generator_is_committed_and_covers_every_fixture():
     src = open(os.path.join(H.GOLDEN, "make_golden_reference.jl")).read()
     for needle in ("using RobotDynamics", "npzwrite", "dyn_case", "exp_case", "err_case", "FiniteDifference", "MRP{Float64}", "RodriguesParam{Float64}",
                    "RD.errstate_jacobian!", "RD.∇errstate_jacobian!", "RD.state_diff", "RD.dynamics_error", "DiscretizedDynamics{Q}",
-                   "RD.ImplicitMidpoint", "ImplicitFunctionTheorem", "RD.rollout!", "TVPendulum", "TVSat", "RobotDynamicsHIP", "host_smoke"):
+                   "RD.ImplicitMidpoint", "ImplicitFunctionTheorem", "RD.rollout!", "TVPendulum", "TVSat", "RobotDynamicsHIP", "host_smoke",
+                   "DiscreteDI <: RobotDynamics.DiscreteDynamics", "discrete_case()", "user_jacobian_case()", "nan_case()", "RD.dynamics_error_jacobian!"):
         assert needle in src, needle
-    for key in ("xdot", "Jc", "xn_$rn", "Jd_$rn", "Jfd_rk4", "E_$rn", "err_$rn", '"G"', '"dG"', '"dX"', "xn_implicit", "J_ift", "ref_rollout_", "ref_tv_"):
+    for key in ("xdot", "Jc", "xn_$rn", "Jd_$rn", "Jfd_rk4", "E_$rn", "err_$rn", '"G"', '"dG"', '"dX"', "xn_implicit", "J_ift", "ref_rollout_", "ref_tv_",
+                "ref_discrete_di.npz", "ref_userjac_cartpole.npz", "ref_nan_satellite.npz", "Jd_user_$rn", "J_user"):
         assert key in src, key
 
 
