@@ -79,7 +79,9 @@ int rdhip_version(void);
 int rdhip_device_count(int* count);
 /* stream_mode RDHIP_STREAM_OWN: the context creates (and owns) a non-blocking HIP stream, `stream` is ignored;
  * RDHIP_STREAM_BORROW: `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream;
- * NULL = the device's default stream) and all launches go to it. */
+ * NULL = the device's default stream) and all launches go to it.  A borrowed stream must OUTLIVE the context: destroy the context (rdhip_ctx_destroy) before
+ * the stream -- the library keeps the stream of the device's last fused rollout -> Jacobians launch to order the next one behind it (one spin-waiting launch
+ * in flight per device), and forgets it only when its context is destroyed. */
 int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** out);
 int rdhip_ctx_destroy(rdhip_ctx* ctx);
 int rdhip_ctx_synchronize(rdhip_ctx* ctx);
@@ -371,7 +373,7 @@ int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
  * With device pointers every model runs on its own internal stream between one fork and one join on the context's stream: the rollouts' latency
  * chains (a handful of compute units each) run side by side and the Jacobian workgroups share the rest of the chip (ONE model of the call -- the one
  * with the most Jacobian bytes among those that have it -- takes the overlapped single launch of rdhip_rollout_jacobian, the others their two
- * launches: see there); results are those of the single-model calls, and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
+ * launches: see there); the simulated states are those of the single-model calls bit for bit, the Jacobians agree with them to rounding (the one-launch and the two-launch form of a model compile the same column code separately, and which model of a call gets the one-launch form depends on the other models), and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
  * the other.  (HIP maps streams onto a few hardware queues -- four by default, GPU_MAX_HW_QUEUES: a process that keeps many other streams busy
  * can find two models of a call on one queue, i.e. running one after the other: measured 281 instead of 160 us for the C5 share.) */
 int rdhip_rollout_jacobian_multi(rdhip_ctx* ctx, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype,

@@ -611,7 +611,8 @@ static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, in
         // the previous fused launch went to ANOTHER stream: an event recorded there now (behind that launch) and waited for here.  Consecutive
         // fused launches on one stream -- a solver's loop -- cost nothing extra.
         if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
-        // (a borrowed stream its owner has destroyed meanwhile: recording fails, and whatever ran on it has been waited for by the destruction)
+        // (rdhip.h: a borrowed stream outlives its context, and a context's destruction forgets its stream -- fused_forget_stream; should a caller break
+        // that contract the record below fails on most runtimes, and whatever ran on the stream has been waited for by its destruction)
         if (hipEventRecord(g_fused_done[slot], g_fused_stream[slot]) != hipSuccess) (void)hipGetLastError();
         else if (hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
     }

@@ -15,7 +15,9 @@
 // Producers never wait for consumers and lower workgroup indices are dispatched first, so ONE such launch cannot deadlock however many workgroups
 // are resident; two of them in flight on one device could (each one's consumers holding the compute units the other's producers are queued for),
 // which is why the library keeps at most one in flight per device (api.hip fused_launch).  The Jacobian store stream then runs UNDER the rollout chain, a few steps behind it, and what is left after the last step is the tail
-// of one chunk.  Results are bit-identical to rdhip_rollout followed by rdhip_jacobian: the same rollout waves, the same column code.
+// of one chunk.  The simulated states are bit-identical to rdhip_rollout's (the same rollout waves, the same machine code: rdhip_rollout runs THIS kernel
+// with grid = G); the Jacobians agree with rdhip_jacobian's to rounding (the same column code, compiled a second time inside this kernel: contraction into
+// fused multiply-adds may differ) -- tests hold them to 1e-14 (fp64) / 2e-6 (fp32).
 #pragma once
 #include "cascade.hpp"
 
