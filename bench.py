@@ -634,6 +634,11 @@ def main():
     extras = small = None
     if rank == 0 and not args.no_extras:
         try:
+            # The headline's context (its own stream + the overlap mode's internal one) has done its work: close it before the secondary metrics.  HIP maps a
+            # process's streams onto FOUR hardware queues; with those two still alive, the child streams of config 5's one-call form (one per model, one for
+            # the pipelined pieces) landed on a queue that was already taken and its kernels ran one behind the other: 290 us in this process where the same
+            # call takes 260 us in a process of its own (tools/c5_one_call.py, profiles/r05/c5.jsonl -- same box, same run).
+            bctx.synchronize(); bctx.close()
             extras, small = secondary_metrics(dev, args.extras_reps)
         except Exception as e:
             extras = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -374,8 +374,10 @@ int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
  * chains (a handful of compute units each) run side by side and the Jacobian workgroups share the rest of the chip (ONE model of the call -- the one
  * with the most Jacobian bytes among those that have it -- takes the overlapped single launch of rdhip_rollout_jacobian, the others their two
  * launches: see there); the simulated states are those of the single-model calls bit for bit, the Jacobians agree with them to rounding (the one-launch and the two-launch form of a model compile the same column code separately, and which model of a call gets the one-launch form depends on the other models), and work queued on the context afterwards sees all of them.  Host arrays and capturing streams run the models one after
- * the other.  (HIP maps streams onto a few hardware queues -- four by default, GPU_MAX_HW_QUEUES: a process that keeps many other streams busy
- * can find two models of a call on one queue, i.e. running one after the other: measured 281 instead of 160 us for the C5 share.) */
+ * the other.  (HIP maps a process's streams onto a few hardware queues -- four by default, GPU_MAX_HW_QUEUES -- and the call uses up to two internal
+ * streams per additional model: a process that HOLDS other streams, busy or not, can find two models of a call on one queue, i.e. running one after
+ * the other: measured 281 instead of 160 us for the C5 share beside four busy streams, and 290 instead of 260 us for the whole of config 5 beside one
+ * idle context that owned its stream and had launch overlap on.  Destroy contexts that are done, or raise GPU_MAX_HW_QUEUES.) */
 int rdhip_rollout_jacobian_multi(rdhip_ctx* ctx, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype,
                                  const long long* K, const long long* M, int layout, void* const* Z, const double* const* t, const double* const* dt,
                                  const void* const* X0, void* const* J, int memspace);
