@@ -354,7 +354,8 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * latency chain -- for the RigidBody{QuatRotation} models (satellite, quadrotor), explicit rules, RDHIP_FORWARD_AD, RDHIP_TIME_MAJOR data with
  * 16-byte aligned J and M * n * (n+m) * sizeof(T) a multiple of 16 (M even in fp64, a multiple of 4 in fp32) and at most half as many 64-trajectory
  * groups as the device has compute units; every other combination runs rollout and Jacobians as launches of their own -- back to back, or, for
- * RDHIP_TIME_MAJOR stacks of 262 144 knot points and more with at least 64 knots per trajectory (small models, custom models, the models of a
+ * RDHIP_TIME_MAJOR stacks of 262 144 knot points and more with at least 64 knots per trajectory and at most half as many 64-trajectory groups as the
+ * device has compute units -- a rollout that is a latency chain, not one that fills the chip -- (small models, custom models, the models of a
  * mixed-model call that did not get the overlapped launch), in four pieces of consecutive knots with the Jacobians of a finished piece on an
  * internal stream beside the rollout of the next (RDHIP_ROLLJAC_PIPE_MIN_KNOTS in the environment moves the limit, 0 = never; results are those of
  * the two plain launches).  rdhip_ctx_last_rollout_jacobian_launches says which (1 = overlapped in one launch, 2 = back to back, more = in pieces).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are

@@ -1153,7 +1153,11 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     // the satellite's fused launch -- they were the end of the call.
     static const long long pipe_min = [] { const char* e = getenv("RDHIP_ROLLJAC_PIPE_MIN_KNOTS"); return e ? atoll(e) : 262144LL; }();     // tuning switch (0 = never)
     constexpr long long PIECES = 4;
-    if (!implicit && layout == RDHIP_TIME_MAJOR && pipe_min > 0 && N >= pipe_min && K >= 16 * PIECES && !stream_is_capturing(c)) {
+    // ... and only while the rollout is a LATENCY chain that leaves most of the chip idle (one workgroup per 64 trajectories on at most half of the
+    // compute units): a batch of 16 384 trajectories fills the chip with its rollout alone, its Jacobians have nothing to run on beside it, and the
+    // pieces only add launches -- 16 384 x 64 fp64 satellite knots (no fused launch: 256 groups) 489 us in pieces, 390 us as the two plain launches
+    const bool chain = 2 * ((Mt + 63) / 64) <= (long long)dev_info().cus;
+    if (!implicit && layout == RDHIP_TIME_MAJOR && pipe_min > 0 && N >= pipe_min && K >= 16 * PIECES && chain && !stream_is_capturing(c)) {
         HIP_TRY(c, hipSetDevice(c->device));
         if (!c->pipe) HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe, hipStreamNonBlocking));
         if (!c->pipe_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->pipe_ev, hipEventDisableTiming));

@@ -70,6 +70,22 @@ def test_pipelined_rollout_jacobian_equals_the_two_plain_launches(dtype, K):
         np.testing.assert_allclose(Jg[:, j], Jo, rtol=0, atol=1e-10 if dtype == np.float64 else 2e-4)
 
 
+def test_a_rollout_that_fills_the_chip_is_not_cut_into_pieces():
+    """16 384 trajectories are 256 rollout workgroups: nothing is idle beside them, the Jacobians of a finished piece would have nowhere to run -- the
+    call issues its two plain launches (measured: 489 us in pieces against 390 us for 16 384 x 64 fp64 satellite knots)."""
+    rng = np.random.default_rng(19)
+    M, K = 16384, 64
+    dm = RD.DiscretizedDynamics(RD.Cartpole(), RD.RK4)
+    data = (0.2 * rng.random((M, K, 5))).astype(np.float32); t = np.tile(np.arange(K) * 0.01, (M, 1)); dt = np.full((M, K), 0.01)
+    st = _tm_stack(data, t, dt)
+    J = RD.alloc_jacobians(dm, K * M, st["data"])
+    assert RD.rollout_jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J, st, None, time_major=True) == 2
+    J2 = RD.alloc_jacobians(dm, K * M, st["data"])
+    RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dm, J2, None, _flat(RD.Cartpole(), st, K, M))
+    torch.cuda.synchronize()
+    assert torch.equal(J, J2)
+
+
 def test_pipelined_pieces_of_a_custom_model_and_a_second_call_on_the_same_context():
     """The pieces take any model that has no fused launch -- here a hipRTC cartpole -- and the internal stream is joined at the end of every call: a
     second call that reuses the arrays right away sees the first one's results."""
