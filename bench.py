@@ -522,7 +522,7 @@ def main():
                      "kernel_ms": s_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT,
                      "kernel_ms_is": "average launch duration of the dominant kernel ALONE on the chip: HIP events (rdhip_timer_*, on the context's stream) around K back-to-back "
                                      "launches on ONE stream, / K; agrees with the per-kernel average of the rocprofv3 --kernel-trace of `bench.py --no-overlap` "
-                                     "(profiles/r04/kernel_stats_single_stream.csv)",
+                                     "(profiles/r05/kernel_stats_single_stream.csv)",
                      "inputs": {"distinct_input_batches": NBUF, "kernel_ms_one_input_batch": same_ms,
                                 "note": "steps rotate over NBUF separate Z/t/dt arrays (different seeds) as well as NBUF outputs; kernel_ms_one_input_batch = the same "
                                         "measurement with every step reading batch 0 (rounds 1-3)"},
