@@ -559,3 +559,58 @@ def test_nan_filled_knot_point_fixture():
     np.testing.assert_allclose(host(Y)[good], d["xn_rk4"][good], rtol=0, atol=TOL)
     p = int(d["poisoned"][0])
     assert np.isnan(host(Y)[p]).all() and np.isnan(host(J)[p]).any()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# fallback kernels (profiles/r05/kernel_reach.txt: templates the suite never launched): outputs that are only sizeof(T)-aligned, LieStates too wide for the tile kernels
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _misaligned(shape_cmajor, dtype=None):
+    """a dense (N, c, r) stack whose first element sits 8 bytes behind a 16-byte boundary, as the (N, r, c) view the host functions take"""
+    dtype = dtype or torch.float64
+    n_el = int(np.prod(shape_cmajor))
+    buf = torch.empty(n_el + 2, dtype=dtype, device="cuda")
+    off = 1 if buf.data_ptr() % 16 == 0 else 0
+    flat = buf[off:off + n_el]
+    assert flat.data_ptr() % 16 == 8 or dtype != torch.float64
+    return flat.view(*shape_cmajor).transpose(1, 2)
+
+
+def test_outputs_that_are_not_16_byte_aligned_take_the_plain_tile_kernels():
+    """The split-role kernels copy a tile as 16-byte units: a Jacobian stack that starts 8 bytes off such a boundary (a view into a bigger buffer) goes
+    to the kernels whose waves compute and then copy (jac_ad_unrolled_kernel for models with a column plan, jac_ad_loop_kernel for the others), the
+    error-state Jacobian to errstate_clear_kernel -- same numbers."""
+    rng = np.random.default_rng(29)
+    N = 20000                                              # (past the column-split kernel of small batches: 8 192 knot points on a whole MI355X)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    sat = RD.Satellite()
+    dm = RD.DiscretizedDynamics(sat, RD.RK4)
+    Zn = H.rand_rigid(rng, N, 6); t = np.arange(N) * 0.1; dt = np.full(N, 0.1)
+    Z = RD.PackedTrajectory(13, 6, Zn, t, dt).to("cuda")
+    Jo, Yo = O.satellite().jacobian(O.RK4, O.FORWARD_AD, Zn, t, dt)
+    J = _misaligned((N, 19, 13))
+    RD.jacobian_(sig, AD, dm, J, None, Z)
+    assert "jac_ad_unrolled_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
+    np.testing.assert_allclose(host(J), Jo, rtol=0, atol=TOL)
+    # a model without a compile-time column plan and more than ten columns: RigidBody{MRP}
+    mrp = RD.Satellite(R=RD.MRP)
+    dmm = RD.DiscretizedDynamics(mrp, RD.RK4)
+    Zm = np.concatenate([rng.random((N, 3)), 0.3 * rng.random((N, 3)), rng.random((N, 12))], axis=1)
+    ZM = RD.PackedTrajectory(12, 6, Zm, t, dt).to("cuda")
+    Ja = RD.alloc_jacobians(dmm, N, ZM.data)
+    RD.jacobian_(sig, AD, dmm, Ja, None, ZM)
+    aligned_name = RD.last_kernel_name()
+    Jm = _misaligned((N, 18, 12))
+    RD.jacobian_(sig, AD, dmm, Jm, None, ZM)
+    assert "jac_ad_loop_kernel" in RD.last_kernel_name() and RD.last_kernel_name() != aligned_name, (RD.last_kernel_name(), aligned_name)
+    np.testing.assert_allclose(host(Jm), host(Ja), rtol=0, atol=1e-13)
+    # errstate_jacobian!, clear = True, G 8 bytes off
+    quad = RD.Quadrotor()
+    X = torch.as_tensor(H.rand_rigid(rng, N, 4)[:, :13]).cuda()
+    Ga = RD.alloc_errstate_jacobians(quad, N, X)
+    RD.errstate_jacobian_(quad, Ga, X, clear=True)
+    G = _misaligned((N, 12, 13))
+    G.fill_(7.0)
+    RD.errstate_jacobian_(quad, G, X, clear=True)
+    assert "errstate_clear_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
+    assert torch.equal(G, Ga)
+
