@@ -449,33 +449,46 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    # kernel time: ONE pair of HIP events around the K launches of the timed region, recorded on the context's own stream through the library's
-    # stopwatch (rdhip_timer_start / _stop: both sit behind a join of the context's two streams): kernel_ms = event time / K = the average
-    # launch duration including the inter-launch gap, i.e. what a caller looping over batches sees per launch.
+    # THE timed region: exactly K steps between two barrier + synchronize brackets, wall clock (nothing else inside it)
     t0 = _time.perf_counter()
-    bctx.timer_start()
     for i in range(args.steps):
         step(i)
-    kern_ms = bctx.timer_stop() / args.steps           # (synchronises on the stop event)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = _time.perf_counter() - t0
+    # time per launch of the same steps as a JOB (launch overlap on): a region of its own of at least 400 launches between the library's stopwatch
+    # events -- inside the region above, the stopwatch's two events, the join of the context's streams and the event synchronisation were part of what
+    # `value` measured (a few per cent of the driver's K = 20 steps)
+    n_ov = max(args.steps, 400)
+    bctx.timer_start()
+    for i in range(n_ov):
+        step(i)
+    kern_ms = bctx.timer_stop() / n_ov                  # (synchronises on the stop event)
     kernel_name = L.last_kernel_name()                  # the kernel the library dispatched the timed calls to (rdhip_last_kernel_name), not a literal
     # The same K steps on ONE stream (overlap off): back-to-back launches of the dominant kernel ALONE on the chip.  HIP events around them / K =
     # the kernel's average launch duration (plus the ~1 us gap between launches of one stream) -- this is what `roofline` describes and what the
     # per-kernel average of a rocprofv3 --kernel-trace of `bench.py --no-overlap` agrees with.
-    def timed_single(fns, nsteps):
+    single_blocks = {}
+
+    def timed_single(fns, nsteps, tag=None):
+        # The kernel's average launch duration needs a region long enough for the stopwatch's own cost to vanish: a pair of events + the synchronisation
+        # behind K = 20 launches (the driver's K: half a millisecond) adds 1.5 us to every launch (27.4-29.0 us in each of 20 such blocks where 2 000
+        # launches in one block give 26.3).  So this measurement -- not `value`, which is the wall clock of exactly K steps -- times at least 400 launches.
         for i in range(min(args.warmup, 200)):
             fns[i % NBUF]()
         bctx.synchronize()
+        n = max(nsteps, 400)
         bctx.timer_start()
-        for i in range(nsteps):
+        for i in range(n):
             fns[i % NBUF]()
-        return bctx.timer_stop() / nsteps
+        ms = bctx.timer_stop() / n
+        if tag:
+            single_blocks[tag] = {"launches_timed": n, "steps": nsteps}
+        return ms
     if not args.no_overlap:
         bctx.set_overlap(False)
-        s_ms = timed_single(calls, args.steps)
+        s_ms = timed_single(calls, args.steps, "kernel_ms")
     else:
         s_ms = kern_ms
     same_ms = timed_single(calls_same_input, max(200, args.steps // 4))     # one input batch for every step: does rotating the 11 MB of inputs move the time?
@@ -521,13 +534,16 @@ def main():
                      "kernel": kernel_name, "kernel_source": "rdhip_last_kernel_name() after the timed region: the kernel the library dispatched these calls to",
                      "kernel_ms": s_ms, "algorithmic_bytes_per_launch": N * BYTES_PER_KNOT,
                      "kernel_ms_is": "average launch duration of the dominant kernel ALONE on the chip: HIP events (rdhip_timer_*, on the context's stream) around K back-to-back "
-                                     "launches on ONE stream, / K; agrees with the per-kernel average of the rocprofv3 --kernel-trace of `bench.py --no-overlap` "
+                                     "launches on ONE stream, / K (at least 400 launches: behind fewer, the stopwatch's own events and synchronisation "
+                                     "are 1.5 us of every launch -- kernel_ms_region); agrees with the per-kernel average of the rocprofv3 --kernel-trace of `bench.py --no-overlap` "
                                      "(profiles/r05/kernel_stats_single_stream.csv)",
+                     "kernel_ms_region": single_blocks.get("kernel_ms"),
                      "inputs": {"distinct_input_batches": NBUF, "kernel_ms_one_input_batch": same_ms,
                                 "note": "steps rotate over NBUF separate Z/t/dt arrays (different seeds) as well as NBUF outputs; kernel_ms_one_input_batch = the same "
                                         "measurement with every step reading batch 0 (rounds 1-3)"},
                      "overlapped": {"ms_per_launch_overlapped": kern_ms, "achieved": achieved_ov, "frac": achieved_ov / HBM_PEAK_GBS, "launch_overlap": (not args.no_overlap),
-                                    "is": "job-level throughput of the timed region that `value` comes from: with rdhip_ctx_set_overlap(1) consecutive launches alternate between the "
+                                    "launches_timed": n_ov,
+                                    "is": "job-level time per launch of the steps `value` is measured on (a region of its own, see kernel_ms_is): with rdhip_ctx_set_overlap(1) consecutive launches alternate between the "
                                           "context's two streams and overlap in time (two launches share the chip; each one's own duration is LONGER than kernel_ms), so this is "
                                           "time per launch of the job, not a kernel duration"}},
     }
