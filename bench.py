@@ -174,6 +174,27 @@ def secondary_metrics(dev, reps):
         us = _timed_us(lambda i: calls[i % NBUF](), max(20, reps // 4))
         out[key] = {"knot_points": N, "value": N / (us * 1e-6), "unit": "knot-point Jacobians/s", "us_per_launch": us, "bytes_per_knot": BYTES_PER_KNOT,
                     "frac_of_hbm_peak": N * BYTES_PER_KNOT / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    # ImplicitMidpoint + IFT as a JOB: what separates this kernel from the explicit one is the first tile's Newton chain standing alone in front of every
+    # launch -- a second launch in flight hides it.  Own-stream context with launch overlap on, the library's stopwatch; closed again
+    # before config 5's one-call form needs the hardware queues.
+    try:
+        octx = L.Context(dev.index if hasattr(dev, "index") and dev.index is not None else 0)
+        octx.set_overlap(True)
+        ocalls = [RD.prepare_jacobian(RD.StaticReturn(), RD.ImplicitFunctionTheorem(RD.ForwardAD()), dmi, Jx[k], Xs[k], Z, ctx=octx) for k in range(NBUF)]
+        for i in range(300):
+            ocalls[i % NBUF]()
+        octx.synchronize()
+        n_o = max(400, reps)
+        octx.timer_start()
+        for i in range(n_o):
+            ocalls[i % NBUF]()
+        us_o = octx.timer_stop() * 1e3 / n_o
+        out["jacobian_implicit_midpoint_ift_satellite"]["with_launch_overlap"] = {"us_per_launch": us_o, "frac_of_hbm_peak": N * BYTES_PER_KNOT / (us_o * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                                                 "is": "rdhip_ctx_set_overlap(1): consecutive calls alternate between two streams of one context"}
+        del ocalls
+        octx.synchronize(); octx.close()
+    except Exception as e:
+        out["jacobian_implicit_midpoint_ift_satellite"]["with_launch_overlap"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     del Jx
     # the headline operator on a LARGE batch (1 M knot points, 16 tiles per workgroup and more: the tile loop's dynamic schedule); inputs and
     # outputs rotate over two sets (2 x 2.2 GB)
