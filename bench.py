@@ -223,7 +223,7 @@ def secondary_metrics(dev, reps):
     # 4 096 Cartpole + 4 096 Satellite trajectories x 256 knots, the N = 1 point of its scaling curve -- and (b) one GPU's share of the 8-GPU split
     # (512 + 512).  Algorithmic bytes per simulated + linearised knot point: satellite 1 080 (Jacobian) + 52 (the state the rollout
     # writes), cartpole 116 + 16.
-    def c5_case(Mc):
+    def c5_case(Mc, own_ctx=None):
         funs, stacks, Jc = [], [], []
         for mdl, mctl in ((RD.Cartpole(), 1), (sat, NU)):
             n = RD.state_dim(mdl)
@@ -233,9 +233,26 @@ def secondary_metrics(dev, reps):
                   "t": torch.as_tensor(np.ascontiguousarray(np.broadcast_to((np.arange(Kr) * 0.01)[:, None], (Kr, Mc)))).to(dev),
                   "dt": torch.full((Kr, Mc), 0.01, dtype=torch.float64, device=dev)}
             funs.append(fun); stacks.append(st); Jc.append(RD.alloc_jacobians(fun, Mc * Kr, st["data"]))
-        c5 = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stacks, None, time_major=True)
-        us = _timed_us(lambda i: c5(), 20, warm=2)
+        c5 = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stacks, None, time_major=True, ctx=own_ctx)
         alg = Mc * Kr * ((1080 + 52) + (116 + 16))
+        if own_ctx is not None:                            # the library's stopwatch on the context's own stream (both behind a join of its streams)
+            for i in range(4):
+                c5()
+            own_ctx.synchronize()
+            t_end = _time.perf_counter() + 0.1
+            while _time.perf_counter() < t_end:
+                for _ in range(20):
+                    c5()
+                own_ctx.synchronize()
+            own_ctx.timer_start()
+            for i in range(40):
+                c5()
+            us = own_ctx.timer_stop() * 1e3 / 40
+            return {"us_per_call": us, "GBps": alg / (us * 1e-6) / 1e9, "frac_of_hbm_peak": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "is": "the same call on a context that owns its stream with rdhip_ctx_set_overlap(1): the second model runs on the context's internal stream and a "
+                          "call that repeats the previous one neither forks nor joins (rdhip.h) -- the long model's launches follow each other without the three "
+                          "packets (join wait, fork record, launch) that cost the plain form ~18 us per call"}
+        us = _timed_us(lambda i: c5(), 20, warm=2)
         res = {"trajectories": 2 * Mc, "knot_points_per_trajectory": Kr, "us_per_call": us, "value": 2 * Mc * Kr / (us * 1e-6),
                "unit": "simulated + linearised knot points/s", "entry_point": "rdhip_rollout_jacobian_multi", "dtype": "f32",
                "algorithmic_bytes": alg, "bytes_per_knot": {"satellite": 1080 + 52, "cartpole": 116 + 16},
@@ -247,9 +264,21 @@ def secondary_metrics(dev, reps):
             tr = sum((pr[k]["write_bytes"] + pr[k]["read_bytes"]) * n for k, n in (("rollout_jac_fused_kernel", 1), ("rollout_kernel", 4), ("jac_ad_small_kernel", 4)))
             res.update({"traffic": tr, "traffic_over_algorithmic": tr / alg, "traffic_source": PMC_SOURCE})
         return res
+    # (the overlap-mode form first, and its context closed again: the plain form's child streams stay alive with the default context, and HIP has four
+    # hardware queues for all of a process's streams)
+    c5_ov = {}
+    try:
+        octx = L.Context(dev.index if dev.index is not None else 0)
+        octx.set_overlap(True)
+        for key, Mc in (("c5_whole_one_gpu_one_call_fp32", 4096), ("c5_share_one_call_fp32", Mr)):
+            c5_ov[key] = c5_case(Mc, octx)
+        octx.synchronize(); octx.close()
+    except Exception as e:
+        c5_ov = {"error": f"{type(e).__name__}: {e}"[:200]}
     for key, Mc in (("c5_whole_one_gpu_one_call_fp32", 4096), ("c5_share_one_call_fp32", Mr)):
         try:
             out[key] = c5_case(Mc)
+            out[key]["with_launch_overlap"] = c5_ov.get(key, c5_ov.get("error"))
         except Exception as e:
             out[key] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # 16 x 4096: separate launches vs one fused launch

@@ -378,7 +378,13 @@ int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
  * the other.  (HIP maps a process's streams onto a few hardware queues -- four by default, GPU_MAX_HW_QUEUES -- and the call uses up to two internal
  * streams per additional model: a process that HOLDS other streams, busy or not, can find two models of a call on one queue, i.e. running one after
  * the other: measured 281 instead of 160 us for the C5 share beside four busy streams, and 290 instead of 260 us for the whole of config 5 beside one
- * idle context that owned its stream and had launch overlap on.  Destroy contexts that are done, or raise GPU_MAX_HW_QUEUES.) */
+ * idle context that owned its stream and had launch overlap on.  Destroy contexts that are done, or raise GPU_MAX_HW_QUEUES.)
+ * On a context that owns its stream with launch overlap on (rdhip_ctx_set_overlap) a call with TWO models runs its second model on the context's internal
+ * stream and does not wait for it at its end -- the next operation of any other kind does (ORDERING RULE above; rdhip_ctx_fence before handing the stream
+ * to other code) -- and a call that REPEATS the previous one argument for argument (a solver's loop) does not fork either: each stream re-issues its own
+ * kernels on its own arrays, in order.  The context's stream then carries the long model's launches back to back, without the join wait, the fork record
+ * and the launch behind them (three packets, ~18 us between the fused launches of consecutive calls): BASELINE config 5 on one GPU 244-252 us per call
+ * instead of 257-262, its 8-way share 132-135 instead of 151. */
 int rdhip_rollout_jacobian_multi(rdhip_ctx* ctx, int nmodels, const rdhip_model* const* models, const int* rule, int diff, int dtype,
                                  const long long* K, const long long* M, int layout, void* const* Z, const double* const* t, const double* const* dt,
                                  const void* const* X0, void* const* J, int memspace);

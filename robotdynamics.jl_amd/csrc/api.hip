@@ -66,6 +66,12 @@ struct rdhip_ctx {
     // rdhip_rollout_jacobian_multi: one child context (own stream, own progress words) per additional model, created on first use
     rdhip_ctx* child[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+    // ... in overlap mode a two-model call runs its second model on the INTERNAL stream (a child context that borrows it) and neither forks nor joins
+    // when it repeats the previous call argument for argument: `multi_pending` = work on the internal stream that NO later operation may overtake
+    // (side_join orders the context's stream behind it), `multi_sig` = the arguments of that call
+    rdhip_ctx* side_child = nullptr;
+    bool multi_pending = false;
+    unsigned long long multi_sig = 0;
     // rdhip_rollout_jacobian, models without the fused launch, time-major stacks: the Jacobians of a finished piece of the rollout run on this stream
     // while the rollout goes on (created on first use)
     hipStream_t pipe = nullptr;
@@ -178,6 +184,7 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_progress) (void)hipFree(c->d_progress);
     if (c->d_sched) (void)hipFree(c->d_sched);
+    if (c->side_child) { (void)rdhip_ctx_destroy(c->side_child); c->side_child = nullptr; }      // (borrows c->side: first)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (hipEvent_t e : {c->side_done, c->main_mark, c->main_done}) if (e) (void)hipEventDestroy(e);
     for (auto& ch : c->child) if (ch) { (void)rdhip_ctx_destroy(ch); ch = nullptr; }
@@ -191,10 +198,11 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
 }
 // order the context's stream behind whatever the internal stream still runs (no-op unless overlap mode has put work there)
 static int side_join(rdhip_ctx* c) {
+    c->multi_sig = 0;                              // whatever comes next is not the repetition of a mixed-model call any more
     if (!c->side_pending) return RDHIP_OK;
     HIP_TRY(c, hipEventRecord(c->side_done, c->side));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_done, 0));
-    c->side_pending = false;
+    c->side_pending = false; c->multi_pending = false;
     c->pend[0].clear(); c->pend[1].clear();       // (the context's stream is ordered behind the internal one, and future internal work starts behind a fresh mark)
     return RDHIP_OK;
 }
@@ -735,7 +743,7 @@ int rdhip_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int d
                    void* J, void* Y, int memspace) {
     const char* what = "rdhip_jacobian";
     const bool ov = c && c->overlap && memspace == RDHIP_DEVICE && !c->capturing && M && M->d.kind != RDHIP_MODEL_CUSTOM && (rule != RDHIP_IMPLICIT_MIDPOINT || Y != nullptr);
-    if (c) c->in_overlapped_call = ov;
+    if (c) c->in_overlapped_call = ov && !c->multi_pending;     // (a mixed-model call left work on the internal stream that is in no footprint list: join first)
     int rc = check_common(c, M, dtype, N, memspace);
     if (c) c->in_overlapped_call = false;
     if (rc) return rc;
@@ -1213,13 +1221,33 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         return RDHIP_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    { const int rc = side_join(c); if (rc) return rc; }     // the fork event below must sit behind the overlap mode's internal stream as well (ORDERING RULE, rdhip.h)
+    // Overlap mode (contexts that own their stream, rdhip_ctx_set_overlap), two models: the second model runs on the context's INTERNAL stream and the
+    // call neither waits for it at its end -- the next operation of any other kind does (side_join: the ORDERING RULE of rdhip.h) -- nor forks when it
+    // REPEATS the previous call argument for argument (a solver's loop: every stream re-issues its own kernels on its own arrays, in order).  The
+    // context's stream then carries nothing but the long model's launches back to back; fork record, join wait and the launch behind them are three
+    // packets, ~18 us between one call's fused launch and the next one's.
+    const bool lazy = c->overlap && c->own_stream && nmodels == 2 && c->side != nullptr;
+    unsigned long long sig = 1469598103934665603ULL;
+    if (lazy) {
+        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ULL; };
+        mix((unsigned long long)diff); mix((unsigned long long)dtype); mix((unsigned long long)layout);
+        for (int p = 0; p < nmodels; ++p) {
+            mix((unsigned long long)(uintptr_t)models[p]); mix((unsigned long long)rule[p]); mix((unsigned long long)K[p]); mix((unsigned long long)Mt[p]);
+            mix((unsigned long long)(uintptr_t)Z[p]); mix((unsigned long long)(uintptr_t)t[p]); mix((unsigned long long)(uintptr_t)dt[p]);
+            mix((unsigned long long)(uintptr_t)(X0 ? X0[p] : nullptr)); mix((unsigned long long)(uintptr_t)J[p]);
+        }
+        if (sig == 0) sig = 1;
+    }
+    const bool chained = lazy && c->multi_pending && c->multi_sig == sig;
+    if (!chained) { const int rc = side_join(c); if (rc) return rc; }     // the fork event below must sit behind the overlap mode's internal stream as well (ORDERING RULE, rdhip.h)
     if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-    for (int p = 1; p < nmodels; ++p) {
+    if (lazy) {
+        if (!c->side_child) { const int rc = rdhip_ctx_create(c->device, (void*)c->side, RDHIP_STREAM_BORROW, &c->side_child); if (rc) return fail(c, rc, "%s: %s", what, rdhip_last_error(nullptr)); }
+    } else for (int p = 1; p < nmodels; ++p) {
         if (!c->child[p - 1]) { const int rc = rdhip_ctx_create(c->device, nullptr, RDHIP_STREAM_OWN, &c->child[p - 1]); if (rc) return fail(c, rc, "%s: %s", what, rdhip_last_error(nullptr)); }
         if (!c->join_ev[p - 1]) HIP_TRY(c, hipEventCreateWithFlags(&c->join_ev[p - 1], hipEventDisableTiming));
     }
-    HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));      // the children start behind the work already queued on this context
+    if (!chained) HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));      // the children start behind the work already queued on this context
     // ONE model of the call takes the fused (spin-waiting) launch -- the one with the most Jacobian bytes among those that have it; the others run
     // rollout and Jacobians as two launches on their streams (see fused_launch)
     int fused_model = -1; double fused_bytes = -1;
@@ -1249,20 +1277,24 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
     int rc0 = RDHIP_OK, slot = 0;
     for (int p = 0; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes its model last
         if (p == main_model) continue;
-        rdhip_ctx* ch = c->child[slot];
-        HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
+        rdhip_ctx* ch = lazy ? c->side_child : c->child[slot];
+        if (!chained) HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
         ch->allow_fused = (p == fused_model);
         rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
-        HIP_TRY(c, hipEventRecord(c->join_ev[slot], ch->stream));
+        if (!lazy) HIP_TRY(c, hipEventRecord(c->join_ev[slot], ch->stream));
         ++slot;
     }
+    if (lazy) { c->side_pending = true; c->multi_pending = true; }      // (whatever happened above: the internal stream has work nothing may overtake)
     if (rc0 == RDHIP_OK) {
         const int p = main_model;
         c->allow_fused = (fused_model == p);
+        c->in_overlapped_call = lazy;                        // (check_common must not join here: this call orders itself)
         rc0 = rdhip_rollout_jacobian(c, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
+        c->in_overlapped_call = false;
         c->allow_fused = true;
     }
+    if (lazy) { c->multi_sig = rc0 == RDHIP_OK ? sig : 0; return rc0; }
     for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results
     return rc0;
 }

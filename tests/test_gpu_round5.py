@@ -614,3 +614,49 @@ def test_outputs_that_are_not_16_byte_aligned_take_the_plain_tile_kernels():
     assert "errstate_clear_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
     assert torch.equal(G, Ga)
 
+
+
+def test_two_model_call_in_overlap_mode_repeats_without_fork_and_join():
+    """rdhip_rollout_jacobian_multi on a context that owns its stream, launch overlap on (rdhip.h): the second model runs on the internal stream, a call
+    that repeats the previous one argument for argument neither forks nor joins, and the next operation of any other kind -- a synchronise, a Jacobian
+    call that reads what the pair produced -- is ordered behind all of it.  Results are those of the same call on a plain context."""
+    from rdhip import _lib as L
+    rng = np.random.default_rng(47)
+    sig, AD = RD.StaticReturn(), RD.ForwardAD()
+    sat, cart = RD.Satellite(), RD.Cartpole()
+    dsat, dcart = RD.DiscretizedDynamics(sat, RD.RK4), RD.DiscretizedDynamics(cart, RD.RK4)
+    M, K = 1024, 96
+    N = M * K
+    t = np.tile(np.arange(K) * 0.01, (M, 1)); dt = np.full((M, K), 0.01)
+    dsatd = (0.3 * H.rand_rigid(rng, N, 6) + np.array([0] * 3 + [0.7, 0, 0, 0] + [0] * 12)).reshape(M, K, 19)
+    dcartd = 0.2 * rng.random((N, 5)).reshape(M, K, 5)
+    f32 = lambda a: a.astype(np.float32)      # noqa: E731
+
+    def build(ctx):
+        st_s, st_c = _tm_stack(dsatd, t, dt, f32), _tm_stack(dcartd, t, dt, f32)
+        Js, Jc = RD.alloc_jacobians(dsat, N, st_s["data"]), RD.alloc_jacobians(dcart, N, st_c["data"])
+        return RD.PreparedRolloutJacobianMulti(sig, AD, [dcart, dsat], [Jc, Js], [st_c, st_s], None, time_major=True, ctx=ctx), st_s, st_c, Js, Jc
+    plain, ps, pc, pJs, pJc = build(None)
+    plain(); torch.cuda.synchronize()
+    ctx = L.Context(0)
+    ctx.set_overlap(True)
+    call, st_s, st_c, Js, Jc = build(ctx)
+    for rep in range(5):                                    # call 0 forks, calls 1 .. 4 are repetitions: nothing but kernels on either stream
+        call()
+    ctx.synchronize()
+    for a, b in ((st_s["data"], ps["data"]), (st_c["data"], pc["data"]), (Js, pJs), (Jc, pJc)):
+        assert torch.equal(a, b)
+    # an operation of another kind right behind a repetition: a Jacobian call that overwrites the cartpole's J must come out on top
+    other = RD.PackedTrajectory(4, 1, 0.2 * rng.random((N, 5)).astype(np.float32), np.arange(N) * 0.01, np.full(N, 0.01)).to("cuda")
+    over = RD.prepare_jacobian(sig, AD, dcart, Jc, None, other, ctx=ctx)
+    ref = RD.alloc_jacobians(dcart, N, st_c["data"])
+    RD.jacobian_(sig, AD, dcart, ref, None, other); torch.cuda.synchronize()
+    for rep in range(4):
+        call(); call(); over()
+        ctx.synchronize()
+        assert torch.equal(Jc, ref), f"rep {rep}: the Jacobian call was overtaken by the pair's internal stream"
+        assert torch.equal(Js, pJs)
+    # ... and the pair right behind it starts from a fork again
+    call(); ctx.synchronize()
+    assert torch.equal(Jc, pJc) and torch.equal(Js, pJs)
+    ctx.close()
