@@ -7,6 +7,7 @@ python tools/bench_configs.py --only c5 > $out/c5.jsonl 2>> $out/configs.err
 python tools/bench_configs.py --only c5full >> $out/c5.jsonl 2>> $out/configs.err
 python tools/bench_configs.py --only body > $out/body.jsonl 2>> $out/configs.err
 bash tools/c5_timeline.sh 4096 > $out/c5_whole_timeline.txt 2>&1; bash tools/c5_timeline.sh 512 > $out/c5_share_timeline.txt 2>&1
+(python tools/c5_overlap.py 4096 40 plain; python tools/c5_overlap.py 4096 40; python tools/c5_overlap.py 512 40 plain; python tools/c5_overlap.py 512 40) 2>/dev/null | grep trajectories > $out/c5_overlap.txt
 python tools/bench_configs.py --only implicit --overlap > $out/implicit_overlap.jsonl 2>> $out/configs.err
 python tools/host_overhead.py > $out/host_overhead.txt 2>&1
 python tools/two_stream_bench.py 65536 1000 > $out/multi_stream.jsonl 2>/dev/null
