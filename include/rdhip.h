@@ -61,6 +61,8 @@ typedef enum {
 
 typedef enum { RDHIP_ROT_QUAT = 0, RDHIP_ROT_MRP = 1, RDHIP_ROT_RP = 2 } rdhip_rotation;   /* src/liestate.jl:42-46 */
 typedef enum { RDHIP_FRAME_WORLD = 0, RDHIP_FRAME_BODY = 1 } rdhip_velocity_frame;          /* src/rigidbody.jl:258 */
+/* the `errmap` argument of state_diff (src/liestate.jl:26-32,216-217): Rotations.jl's ErrorMap types [third party, restated: SURVEY App. A] */
+typedef enum { RDHIP_ERRMAP_CAYLEY = 0, RDHIP_ERRMAP_EXPONENTIAL = 1, RDHIP_ERRMAP_MRP = 2, RDHIP_ERRMAP_QUATVEC = 3, RDHIP_ERRMAP_IDENTITY = 4 } rdhip_errmap;
 /* QuadratureRule (src/integration.jl:69,109,258; RK2 = v0.3 explicit midpoint); RDHIP_CONTINUOUS = no discretisation */
 /* RDHIP_IMPLICIT_MIDPOINT (src/integration.jl:620-729): x1 + h f((x1+x2)/2, u1) - x2 = 0 solved by Newton's method (src/integration.jl:422-463);
  * accepted by rdhip_discrete_dynamics, rdhip_jacobian (implicit function theorem, src/integration.jl:517-538), rdhip_dynamics_error[_jacobian] */
@@ -79,9 +81,8 @@ int rdhip_version(void);
 int rdhip_device_count(int* count);
 /* stream_mode RDHIP_STREAM_OWN: the context creates (and owns) a non-blocking HIP stream, `stream` is ignored;
  * RDHIP_STREAM_BORROW: `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream;
- * NULL = the device's default stream) and all launches go to it.  A borrowed stream must OUTLIVE the context: destroy the context (rdhip_ctx_destroy) before
- * the stream -- the library keeps the stream of the device's last fused rollout -> Jacobians launch to order the next one behind it (one spin-waiting launch
- * in flight per device), and forgets it only when its context is destroyed. */
+ * NULL = the device's default stream) and all launches go to it; it must be alive whenever a call is made on the context (the library keeps no
+ * stream of another context: the device-wide ordering of fused rollout -> Jacobians launches goes through an event recorded at launch time). */
 int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** out);
 int rdhip_ctx_destroy(rdhip_ctx* ctx);
 int rdhip_ctx_synchronize(rdhip_ctx* ctx);
@@ -97,6 +98,21 @@ int rdhip_ctx_synchronize(rdhip_ctx* ctx);
 int rdhip_ctx_set_overlap(rdhip_ctx* ctx, int on);
 int rdhip_ctx_fence(rdhip_ctx* ctx);
 void* rdhip_ctx_stream(rdhip_ctx* ctx);
+/* Developer tuning knobs.  The dispatcher chooses kernels and launch shapes by size; every switch that overrides a choice lives in ONE list, read once
+ * per process from the environment variable RDHIP_TUNE="key=value,key=value" (unknown keys are reported on stderr).  rdhip_tune() merges more pairs at
+ * run time ("reset" / NULL: back to the environment's); it is meant for tests and tuning scripts, is not synchronised against concurrent launches,
+ * and NO knob changes a result.  Keys (csrc/common.hpp TuneKnobs):
+ *   static_grid=N            workgroups of the one-per-CU persistent launches (default: one per compute unit)
+ *   dyn_grid=N               workgroups of launches with the dynamic tile schedule (default: three quarters of the compute units)
+ *   dynamic_tiles=0          no launch takes the dynamic tile schedule
+ *   small=tile               the persistent tile loop for every batch size (no four-workgroups-per-tile form);  small_max=N  its limit in workgroups per CU (2)
+ *   rollout=plain|cascade|stream   force a rollout kernel where it applies
+ *   rolljac=split            rdhip_rollout_jacobian always as two launches
+ *   fused_ratio=x, fused_jac_workgroups=N, fused_tj_max_knots=N, rolljac_pipe_min_knots=N, multi_main=i     shape of the one-launch rollout -> Jacobians forms
+ *   ift=reg|3                ImplicitMidpoint Jacobians: the one-kernel register path / the three-launch path of round 2
+ * Not tuning, and still their own environment variables: RDHIP_DRY_RUN (contexts without a device: queries only), RDHIP_VERBOSE (reports fall-backs on
+ * stderr), RDHIP_CACHE_DIR (hipRTC code-object cache of custom models), RDHIP_RCCL_LIB / RDHIP_COMM_FORCE_RCCL (communicator). */
+int rdhip_tune(const char* pairs);
 /* message of the last failure on this context (ctx == NULL: last failure of a context-less call on this thread) */
 const char* rdhip_last_error(rdhip_ctx* ctx);
 /* Name (demangled, NUL-terminated, truncated to `capacity`) of the kernel the CALLING HOST THREAD launched last through the library: which
@@ -144,7 +160,11 @@ int rdhip_model_destroy(rdhip_model* model);
  * n <= 16, m <= 8, nparams <= 64.  Compilation errors come back as RDHIP_ERR_INVALID_ARG with the compiler log in rdhip_last_error(NULL)
  * (creation does not compile; the first use or rdhip_model_precompile does).  With the environment variable RDHIP_CACHE_DIR set, compiled
  * kernels are kept there as code objects (keyed by a hash of the generated source, the kernel templates and the HIP version) and later
- * processes load them instead of compiling. */
+ * processes load them instead of compiling.
+ * USER BODIES ARE COMPILED WITH THE LIBRARY'S FLAGS, -ffinite-math-only -fno-signed-zeros among them (this applies to dynamics, step and Jacobian bodies
+ * alike): the compiler may assume that no operand is NaN or Inf, so a guard written as `x != x`, `isnan(x)` or `isinf(x)` in a body can be folded away.
+ * A body that must detect a poisoned input tests the BIT PATTERN (`__double_as_longlong(x) & 0x7ff0000000000000` == the all-ones exponent), as the
+ * library does for the terminal-knot rule. */
 int rdhip_model_create_custom(int n, int m, const char* dynamics_body, const char* preamble, const double* params, int nparams,
                               int rotation, const int* P, int nP, rdhip_model** out);
 /* The user's OWN Jacobian of a custom continuous model -- `jacobian!(model, J, xdot, x, u, t)`, src/dynamics.jl:115-116 (test/cartpole_model.jl:57-96 is the
@@ -171,7 +191,11 @@ int rdhip_model_create_custom_discrete(int n, int m, const char* step_body, cons
                                        int rotation, const int* P, int nP, rdhip_model** out);
 int rdhip_model_is_discrete(const rdhip_model* model, int* discrete);
 /* setnewtoniters / setnewtontolerance of an ImplicitDynamicsModel (src/discretized_dynamics.jl:225-228); defaults 10 and 1e-12
- * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol. */
+ * (src/integration.jl:599-600).  The Newton loop stops per knot point when ||residual||_2 < tol.
+ * PARITY TOLERANCE of the implicit rule: two correct Newton iterations that stop at ||residual|| < tol return roots that differ by up to tol times the
+ * conditioning of the residual's Jacobian (the iteration has no further step that would make them agree), and the implicit-function-theorem Jacobian is
+ * linearised about that root.  The parity gate for RDHIP_IMPLICIT_MIDPOINT outputs is therefore 1e-9 on x_next and 1e-8 x max(1, |J|) on the Jacobian at
+ * the default tol = 1e-12 (observed: <= 3e-12 and <= 4e-11), not the 1e-10 of the explicit rules. */
 int rdhip_model_set_newton(rdhip_model* model, int newton_iters, double newton_tol);
 /* Custom models with n+m > 10: measure the cost of every Jacobian column (each is JIT-compiled alone, ~0.5 s per column, no GPU needed)
  * and assign the columns to the compute waves of the Jacobian kernel by cost instead of in contiguous ranges.  Optional; call it before
@@ -242,7 +266,7 @@ int rdhip_discrete_dynamics(rdhip_ctx* ctx, const rdhip_model* model, int rule, 
  * rule = RDHIP_IMPLICIT_MIDPOINT: diff = RDHIP_FORWARD_AD stands for ImplicitFunctionTheorem(ForwardAD()) (the only DiffMethod the reference
  * accepts for implicit models, src/discretized_dynamics.jl:243-249): the next state is solved for, then J = -J2[:,1:n] \ J1.
  * fp64 batches of 8 or more 64-knot tiles per workgroup (131 072 knot points on a whole MI355X) are scheduled dynamically (a device-wide counter hands
- * out the tiles; same results, bit for bit); RDHIP_DYNAMIC_TILES=0 in the environment keeps the static order, and so does a capturing stream. */
+ * out the tiles; same results, bit for bit); RDHIP_TUNE=dynamic_tiles=0 in the environment keeps the static order, and so does a capturing stream. */
 int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, long long N,
                    const void* Z, const double* t, const double* dt, void* J, void* Y, int memspace);
 
@@ -303,9 +327,26 @@ int rdhip_errstate_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int dtype,
 
 /* state_diff(model, x, x0) with the default CayleyMap: src/statevectortype.jl:102-104,145-146, src/liestate.jl:210-260.
  * dX: e x N.  Served for QuatRotation, MRP and RodriguesParam LieStates (test/liestate.jl:33-68): the rotation part is the vector of
- * Rodrigues parameters of q0^-1 q whatever the parameterisation. */
+ * Rodrigues parameters of q0^-1 q whatever the parameterisation.
+ * Tolerance of the parity gate: 1e-10 ABSOLUTE on rotation errors of magnitude <= 1e3 (tests/test_gpu_parity.py); the Cayley error v / w is unbounded
+ * as the relative rotation approaches 180 degrees, where the gate is 1e-10 RELATIVE to |v / w|. */
 int rdhip_state_diff(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
                      const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace);
+/* state_diff(model, x, x0, errmap) / state_diff!(model, dx, x, x0, errmap): src/liestate.jl:26-32 (the RotationState methods take any Rotations.jl
+ * ErrorMap), :216-217 (`Rotations.rotation_error(R(x_q...), R(x0_q...), errmap)` per rotation, = inv(errmap)(R0 \ R)), :239-250.  With
+ * dq = [w; v] the quaternion of R0^-1 R (for QuatRotation states conj(q0) (x) q of the NORMALISED inputs, sign not canonicalised; MRP / RodriguesParam
+ * states are converted first) the rotation part of dX is   [third party: Rotations.jl 1.x error maps, restated -- SURVEY App. A]
+ *   RDHIP_ERRMAP_CAYLEY       v / w                                       (InvCayleyMap; what rdhip_state_diff computes)
+ *   RDHIP_ERRMAP_EXPONENTIAL  atan(|v|, w) / |v| * v                      (InvExponentialMap = 0.5 logm(dq): half the rotation vector;
+ *                             |v| <= 1e-6: (1 - |v|^2 / (3 w^2)) / w * v, Rotations.jl's series branch)
+ *   RDHIP_ERRMAP_MRP          2 v / (1 + w)                               (InvMRPMap)
+ *   RDHIP_ERRMAP_QUATVEC      sign(w) v                                   (InvQuatVecMap; sign(0) = 0 as in Julia)
+ *   RDHIP_ERRMAP_IDENTITY     params(R0 \ R) in the state's own parameterisation: MRP states v / (1 + w), RodriguesParam states v / w.
+ *                             QuatRotation states: RDHIP_ERR_UNSUPPORTED -- the reference throws there too (a RotationError holds three values,
+ *                             IdentityMap of a quaternion returns four).
+ * All maps agree to first order (dX ~ v, half the rotation angle).  Vector parts: x - x0. */
+int rdhip_state_diff_map(rdhip_ctx* ctx, const rdhip_model* model, int dtype, long long N,
+                         const void* X, int ldx, const void* X0, int ldx0, int errmap, void* dX, int memspace);
 
 /* nabla-errstate_jacobian!(model, nablaG, x, xbar) (v0.3: nabla^2 differential!): src/statevectortype.jl:137-147,
  * src/liestate.jl:300-320.  nablaG: e x e x N.  clear as for rdhip_errstate_jacobian.  Rotation blocks grad^2-differential(R(x), xbar_rot): QuatRotation
@@ -357,10 +398,10 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * RDHIP_TIME_MAJOR stacks of 262 144 knot points and more with at least 64 knots per trajectory and at most half as many 64-trajectory groups as the
  * device has compute units -- a rollout that is a latency chain, not one that fills the chip -- (small models, custom models, the models of a
  * mixed-model call that did not get the overlapped launch), in four pieces of consecutive knots with the Jacobians of a finished piece on an
- * internal stream beside the rollout of the next (RDHIP_ROLLJAC_PIPE_MIN_KNOTS in the environment moves the limit, 0 = never; results are those of
+ * internal stream beside the rollout of the next (RDHIP_TUNE=rolljac_pipe_min_knots=N in the environment moves the limit, 0 = never; results are those of
  * the two plain launches).  rdhip_ctx_last_rollout_jacobian_launches says which (1 = overlapped in one launch, 2 = back to back, more = in pieces).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are
  * latency-sized; from 262 144 knot points on they run the two launches, which is faster there (4 096 x 101 fp64 knots: 204 vs 250 us;
- * RDHIP_FUSED_TJ_MAX_KNOTS in the environment moves the limit).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
+ * RDHIP_TUNE=fused_tj_max_knots=N in the environment moves the limit).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
  * The Jacobian workgroups of the overlapped launch hold their compute unit while they wait for the rollout workgroups of the SAME launch; the
  * library therefore keeps at most one such launch in flight per device and process (a second one, from any context, is ordered behind the first by
  * an event edge).  Outside its reach: launches replayed from captured graphs side by side, and other processes sharing the GPU -- do not run two of

@@ -52,7 +52,8 @@ enum { M_CARTPOLE = 0, M_DOUBLE_INTEGRATOR = 1, M_LINEAR = 2, M_SATELLITE = 3, M
        // that the time argument reaches every stage the way src/integration.jl passes it (t, t + h/2, t + h; implicit midpoint: residual
        // at t + h/2, Jacobian at t).  The product evaluates them as user-defined (hipRTC) models.
        M_TV_PENDULUM = 8,      // x = [th, thd]: thdd = -(a + b cos(w t)) sin(th) - c thd + u + b sin(w t)          params {a, b, w, c}
-       M_TV_SATELLITE = 9 };   // RigidBody satellite + disturbance: F += fd [cos wt, 0, sin wt] (world), tau += td [sin wt, cos wt, sin 2wt]   params {mass, J[9], fd, td, w}
+       M_TV_SATELLITE = 9,   // RigidBody satellite + disturbance: F += fd [cos wt, 0, sin wt] (world), tau += td [sin wt, cos wt, sin 2wt]   params {mass, J[9], fd, td, w}
+       M_LIE_STATE = 10 };     // a bare LieState{R,P} (src/liestate.jl:75-83; test/liestate.jl:33-68): no dynamics, the error-state maps only   params {nP, P...}
 enum { ROT_QUAT = 0, ROT_MRP = 1, ROT_RP = 2 };
 enum { FRAME_WORLD = 0, FRAME_BODY = 1 };
 enum { RULE_EULER = 0, RULE_RK2 = 1, RULE_RK3 = 2, RULE_RK4 = 3 };
@@ -642,6 +643,7 @@ static int model_lie(const OModel& M, OLie* s) {
         case M_SATELLITE: case M_QUADROTOR: case M_TV_SATELLITE: s->nP = 2; s->P[0] = 3; s->P[1] = 6; return 1;   // src/rigidbody.jl:48
         case M_SATELLITE_PAIR: s->nP = 3; s->P[0] = 0; s->P[1] = 3; s->P[2] = 3; return 1;     // examples/satellite_pair.jl:40
         case M_LIE_SATELLITE: s->nP = 2; s->P[0] = 3; s->P[1] = 0; return 1;                  // test/liemodel.jl:12
+        case M_LIE_STATE: s->nP = (int)M.p[0]; for (int i = 0; i < s->nP && i < 8; ++i) s->P[i] = (int)M.p[1 + i]; return s->nP >= 1 && s->nP <= 8;
         default: return 0;   // EuclideanState
     }
 }
@@ -667,6 +669,7 @@ int oracle_model_init(OModel* M, int kind, int rot, int frame, const double* par
         case M_LIE_SATELLITE: M->n = 3 + rp; M->m = 3; break;
         case M_TV_PENDULUM: M->n = 2; M->m = 1; break;
         case M_TV_SATELLITE: M->n = 9 + rp; M->m = 6; break;
+        case M_LIE_STATE: { OLie ls; if (!model_lie(*M, &ls)) return -1; M->n = lie_len(ls); M->m = 0; break; }
         default: return -1;
     }
     if (M->n > MAXN || M->m > MAXM) return -1;
@@ -764,8 +767,29 @@ int oracle_errstate_jacobian(const OModel* M, int N, const double* X, int ldx, i
     }
     return 0;
 }
-// state_diff(model, x, x0): Euclidean x - x0; rotations: rotation_error(q, q0, CayleyMap) = vec(q0^-1 q)/scalar
-int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const double* X0, int ldx0, double* dX) {
+// inv(errmap)(dq) of Rotations.jl 1.x [third party, restated from its published definitions; parity unpinned -- only CayleyMap's value is pinned by the
+// reference's tests, test/rbstate.jl:157], dq = [w; v] the quaternion of R0 \ R.  scaling(ExponentialMap) = 1/2, scaling(MRPMap) = 2, others 1:
+//   InvExponentialMap  0.5 logm(dq),  logm(dq) = 2 vector(_log_as_quat(dq)),  _log_as_quat: M = atan(theta, w) / theta for theta = |v| > 1e-6,
+//                      else (1 - theta^2 / (3 w^2)) / w;  the result is M v
+//   InvCayleyMap       v / w            InvMRPMap  2 v / (1 + w)            InvQuatVecMap  v sign(w)
+//   InvIdentityMap     params(R0 \ R): three values for MRP (v / (1 + w)) and RodriguesParam (v / w) states; four for a quaternion, which
+//                      Rotations.rotation_error cannot wrap in its three-element RotationError (it throws): rc -3 here
+static int errmap_inverse(int errmap, int rot, const double dq[4], double out[3]) {
+    const double w = dq[0]; const double* v = dq + 1; double M;
+    switch (errmap) {
+        case 0: M = 1.0 / w; for (int j = 0; j < 3; ++j) out[j] = v[j] / w; return 0;
+        case 1: { const double th = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); M = th > 1e-6 ? std::atan2(th, w) / th : (1.0 - th * th / (3.0 * w * w)) / w; break; }
+        case 2: M = 2.0 / (1.0 + w); break;
+        case 3: M = w > 0 ? 1.0 : (w < 0 ? -1.0 : 0.0); break;
+        case 4: if (rot == ROT_QUAT) return -3; M = rot == ROT_MRP ? 1.0 / (1.0 + w) : 1.0 / w; break;
+        default: return -1;
+    }
+    for (int j = 0; j < 3; ++j) out[j] = v[j] * M;
+    return 0;
+}
+// state_diff(model, x, x0[, errmap]) (src/liestate.jl:26-32,210-260): Euclidean x - x0; rotations: rotation_error(R, R0, errmap) = inv(errmap)(R0 \ R)
+// (:216-217); errmap 0 CayleyMap (the default) 1 ExponentialMap 2 MRPMap 3 QuatVecMap 4 IdentityMap
+int oracle_state_diff_map(const OModel* M, int N, const double* X, int ldx, const double* X0, int ldx0, int errmap, double* dX) {
     OLie s; int lie = model_lie(*M, &s); int n = M->n; int e = lie ? lie_errdim(s) : n;
     for (int k = 0; k < N; ++k) {
         const double* x = X + (size_t)k * ldx; const double* x0 = X0 + (size_t)k * ldx0; double* d = dX + (size_t)k * e;
@@ -776,14 +800,17 @@ int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const do
             if (v < s.nP - 1) {
                 double q[4], q0[4];
                 if (s.rot == ROT_QUAT) { qnormalize(x + r, q); qnormalize(x0 + r, q0); }
-                else { rot3_quat(s.rot, x + r, q); rot3_quat(s.rot, x0 + r, q0); }      // inv(CayleyMap)(R0 \ R) goes through the quaternion of R0 \ R
+                else { rot3_quat(s.rot, x + r, q); rot3_quat(s.rot, x0 + r, q0); }      // inv(errmap)(R0 \ R) goes through the quaternion of R0 \ R
                 double q0c[4] = {q0[0], -q0[1], -q0[2], -q0[3]}; double dq[4]; qmul(q0c, q, dq);
-                for (int j = 0; j < 3; ++j) d[c + j] = dq[1 + j] / dq[0];
+                const int rc = errmap_inverse(errmap, s.rot, dq, d + c); if (rc) return rc;
                 r += rot_params(s.rot); c += 3;
             }
         }
     }
     return 0;
+}
+int oracle_state_diff(const OModel* M, int N, const double* X, int ldx, const double* X0, int ldx0, double* dX) {
+    return oracle_state_diff_map(M, N, X, ldx, X0, ldx0, 0, dX);
 }
 // grad^2-differential(p, b) of the three-parameter rotations [3P, Rotations.jl; restated from its definition]: the contraction with b of the second
 // derivative of the composition map delta -> params(p * R(delta)) at delta = 0 (delta in the rotation's own parameters) -- the derivative with respect

@@ -15,6 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "librd_oracle.so")
 # enums -- numerically identical to include/rdhip.h
 CARTPOLE, DOUBLE_INTEGRATOR, LINEAR, SATELLITE, QUADROTOR, SATELLITE_PAIR, LIE_SATELLITE = range(7)
 TV_PENDULUM, TV_SATELLITE = 8, 9     # explicitly time-dependent test models (oracle only; the product runs them as user-defined models)
+LIE_STATE = 10                       # a bare LieState{R,P} (src/liestate.jl:75-83): the error-state maps only
 ROT_QUAT, ROT_MRP, ROT_RP = range(3)
 FRAME_WORLD, FRAME_BODY = range(2)
 EULER, RK2, RK3, RK4 = range(4)
@@ -222,12 +223,13 @@ class Model:
             raise NotImplementedError(f"rc={rc}")
         return Gc.transpose(0, 2, 1)
 
-    def state_diff(self, X, X0):
+    def state_diff(self, X, X0, errmap=0):
+        """errmap: 0 CayleyMap (the reference's default, src/liestate.jl:27) 1 ExponentialMap 2 MRPMap 3 QuatVecMap 4 IdentityMap"""
         X = np.ascontiguousarray(X, dtype=np.float64)
         X0 = np.ascontiguousarray(X0, dtype=np.float64)
         N = X.shape[0]
         out = np.empty((N, self.e))
-        rc = lib().oracle_state_diff(self._buf, N, _dp(X), X.shape[1], _dp(X0), X0.shape[1], _dp(out))
+        rc = lib().oracle_state_diff_map(self._buf, N, _dp(X), X.shape[1], _dp(X0), X0.shape[1], int(errmap), _dp(out))
         if rc:
             raise NotImplementedError(f"rc={rc}")
         return out
@@ -326,6 +328,10 @@ def satellite_pair(J1=np.eye(3), J2=2 * np.eye(3)):   # examples/satellite_pair.
 
 def lie_satellite(Jd=(1.0, 1.0, 1.0)):   # test/liemodel.jl:5
     return Model(LIE_SATELLITE, list(Jd))
+
+
+def lie_state(rot, P):   # LieState{R,P} (test/liestate.jl:33-68): state_diff / errstate_jacobian / nabla_errstate_jacobian of any partition
+    return Model(LIE_STATE, [len(P)] + [int(v) for v in P], rot=rot)
 
 
 def tv_pendulum(a=9.81, b=2.0, w=3.0, c=0.1):   # test model: thdd = -(a + b cos wt) sin th - c thd + u + b sin wt

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -21,6 +22,7 @@ using namespace rd;
 
 struct rdhip_ctx {
     int device;
+    unsigned long long serial = 0;        // unique per context of this process (never reused): identifies the issuer of the device's last fused launch
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
@@ -72,6 +74,7 @@ struct rdhip_ctx {
     rdhip_ctx* side_child = nullptr;
     bool multi_pending = false;
     unsigned long long multi_sig = 0;
+    std::vector<unsigned long long> multi_args;      // ... held exactly (the hash alone could collide: ADVICE r05)
     // rdhip_rollout_jacobian, models without the fused launch, time-major stacks: the Jacobians of a finished piece of the rollout run on this stream
     // while the rollout goes on (created on first use)
     hipStream_t pipe = nullptr;
@@ -124,7 +127,54 @@ static void build_lie(rdhip_model* M) {
     }
 }
 
+// ---- tuning knobs (common.hpp TuneKnobs): RDHIP_TUNE="key=value,..." read once per process; rdhip_tune() merges more pairs at run time ----
+static int parse_tune(rd::TuneKnobs& k, const char* s, std::string* bad) {
+    std::string str(s ? s : "");
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t end = str.find_first_of(",; ", pos);
+        if (end == std::string::npos) end = str.size();
+        const std::string kv = str.substr(pos, end - pos);
+        pos = end + 1;
+        if (kv.empty()) continue;
+        const size_t eq = kv.find('=');
+        const std::string key = kv.substr(0, eq), val = eq == std::string::npos ? "" : kv.substr(eq + 1);
+        const long long iv = atoll(val.c_str());
+        if (key == "static_grid") k.static_grid = iv;
+        else if (key == "dyn_grid") k.dyn_grid = iv;
+        else if (key == "dynamic_tiles") k.dynamic_tiles = !(val == "0");
+        else if (key == "small") k.small = val.empty() ? 0 : val[0];
+        else if (key == "small_max") k.small_max = iv;
+        else if (key == "rollout") k.rollout = val.empty() ? 0 : val[0];
+        else if (key == "rolljac") k.rolljac = val.empty() ? 0 : val[0];
+        else if (key == "fused_ratio") k.fused_ratio = atof(val.c_str());
+        else if (key == "fused_jac_workgroups") k.fused_jac_workgroups = iv;
+        else if (key == "fused_tj_max_knots") k.fused_tj_max_knots = iv;
+        else if (key == "rolljac_pipe_min_knots") k.rolljac_pipe_min_knots = iv;
+        else if (key == "multi_main") k.multi_main = val.empty() ? -1 : (int)iv;
+        else if (key == "ift") k.ift = val.empty() ? 0 : val[0];
+        else { if (bad) *bad = key; return RDHIP_ERR_INVALID_ARG; }
+    }
+    return RDHIP_OK;
+}
+static rd::TuneKnobs knobs_from_env() {
+    rd::TuneKnobs k;
+    std::string bad;
+    if (const char* e = getenv("RDHIP_TUNE")) if (parse_tune(k, e, &bad) != RDHIP_OK) fprintf(stderr, "[rdhip] RDHIP_TUNE: unknown key '%s' (include/rdhip.h lists the knobs); the rest of the string is ignored\n", bad.c_str());
+    return k;
+}
+namespace rd { TuneKnobs& tune_knobs_mut() { static TuneKnobs k = knobs_from_env(); return k; } }
+
 extern "C" {
+
+int rdhip_tune(const char* pairs) {
+    if (!pairs || !pairs[0] || std::string(pairs) == "reset") { rd::tune_knobs_mut() = knobs_from_env(); return RDHIP_OK; }
+    rd::TuneKnobs k = rd::tune_knobs_mut();
+    std::string bad;
+    if (parse_tune(k, pairs, &bad) != RDHIP_OK) return fail(nullptr, RDHIP_ERR_INVALID_ARG, "rdhip_tune: unknown key '%s'", bad.c_str());
+    rd::tune_knobs_mut() = k;
+    return RDHIP_OK;
+}
 
 int rdhip_version(void) { return RDHIP_VERSION; }
 
@@ -158,6 +208,7 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     rdhip_ctx* c = new (std::nothrow) rdhip_ctx();
     if (!c) return fail(nullptr, RDHIP_ERR_HIP, "out of host memory");
     c->device = device_id; c->own_stream = (stream_mode == RDHIP_STREAM_OWN);
+    { static std::atomic<unsigned long long> next_serial{1}; c->serial = next_serial.fetch_add(1); }
     for (int i = 0; i < 8; ++i) { c->ws[i] = nullptr; c->ws_bytes[i] = 0; }
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) { if (c->own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); else c->stream = (hipStream_t)stream; }
@@ -172,13 +223,11 @@ int rdhip_ctx_create(int device_id, void* stream, int stream_mode, rdhip_ctx** o
     if (e != hipSuccess) { int rc = fail(nullptr, RDHIP_ERR_HIP, "context creation failed: %s", hipGetErrorString(e)); delete c; return rc; }
     *out = c; return RDHIP_OK;
 }
-static void fused_forget_stream(int device, hipStream_t s);
 int rdhip_ctx_destroy(rdhip_ctx* c) {
     if (!c) return RDHIP_OK;
     if (c->device < 0) { delete c; return RDHIP_OK; }      // dry context: nothing on any device
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    fused_forget_stream(c->device, c->stream);             // (synchronised above: nothing fused is in flight on it any more)
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -606,26 +655,27 @@ static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, con
 // model per call (the others run their two launches, whose workgroups wait for nobody, beside it).  Not covered: launches replayed from captured
 // graphs and other processes on the same GPU (rdhip.h says so).
 static std::mutex g_fused_mu;
+// Per device: an event recorded BEHIND the last fused launch on the stream that issued it -- at launch time, when that stream is alive by construction --
+// and who issued it (context serial + stream handle, compared only, never used).  The next fused launch from anybody else waits for the event; the same
+// issuer's next launch follows in stream order and waits for nothing.  Round 5 kept the raw stream instead and recorded on it LATER, from the next
+// launcher's call: a borrowed stream destroyed in between was undefined behaviour that rdhip.h could only forbid.  An event outlives
+// the stream it was recorded on.  (Cost: one marker packet behind a launch of 100 us and more; handle reuse -- a new stream at a destroyed one's address --
+// is why the context's serial is part of the identity.)
 static hipEvent_t g_fused_done[64] = {};
 static hipStream_t g_fused_stream[64] = {};
-static void fused_forget_stream(int device, hipStream_t s) {
-    std::lock_guard<std::mutex> g(g_fused_mu);
-    if (g_fused_stream[device & 63] == s) g_fused_stream[device & 63] = nullptr;
-}
+static unsigned long long g_fused_serial[64] = {};
 static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& f, bool capturing) {
     std::lock_guard<std::mutex> g(g_fused_mu);
     const int slot = c->device & 63;
-    if (!capturing && g_fused_stream[slot] && g_fused_stream[slot] != f.stream) {
-        // the previous fused launch went to ANOTHER stream: an event recorded there now (behind that launch) and waited for here.  Consecutive
-        // fused launches on one stream -- a solver's loop -- cost nothing extra.
-        if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
-        // (rdhip.h: a borrowed stream outlives its context, and a context's destruction forgets its stream -- fused_forget_stream; should a caller break
-        // that contract the record below fails on most runtimes, and whatever ran on the stream has been waited for by its destruction)
-        if (hipEventRecord(g_fused_done[slot], g_fused_stream[slot]) != hipSuccess) (void)hipGetLastError();
-        else if (hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
+    if (!capturing && g_fused_serial[slot] && !(g_fused_serial[slot] == c->serial && g_fused_stream[slot] == f.stream)) {
+        if (hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
     }
     const int k = family_rolljac(d, rule, diff, dtype, f);
-    if (k == RDHIP_OK && !capturing) g_fused_stream[slot] = f.stream;
+    if (k == RDHIP_OK && !capturing) {
+        if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
+        if (hipEventRecord(g_fused_done[slot], f.stream) != hipSuccess) return RDHIP_ERR_HIP;
+        g_fused_stream[slot] = f.stream; g_fused_serial[slot] = c->serial;
+    }
     return k;
 }
 
@@ -712,7 +762,7 @@ int rdhip_model_wrench_sparsity(const rdhip_model* M, int js[10]) {
 
 static bool stream_is_capturing(rdhip_ctx* c);
 // the counter words of this launch's dynamic tile schedule on stream `me` (0: the context's, 1: the internal one), or NULL: static schedule (a capturing
-// stream -- a graph would bake one slot into every replay --, RDHIP_DYNAMIC_TILES=0, or no memory for the words)
+// stream -- a graph would bake one slot into every replay --, RDHIP_TUNE=dynamic_tiles=0, or no memory for the words)
 // `ntiles`, `dtype`: of the launch -- only launches that can take the schedule at all (fp64, 8 tiles per workgroup of the reduced grid: dispatch.hpp
 // dyn_grid) use up a slot.
 // A slot is handed out on the promise that its words are zero: the launch that used it before leaves them so (its last workgroup resets them).  A
@@ -720,8 +770,7 @@ static bool stream_is_capturing(rdhip_ctx* c);
 // the slot would silently skip tiles.  So each time a stream's ring comes round, the whole ring is zeroed again ON that stream (every launch that used
 // it is then complete by stream order): a 2 KB fill per 32 big launches, and a poisoned slot heals within one turn of the ring.
 static unsigned* take_sched(rdhip_ctx* c, int me, long long ntiles, int dtype) {
-    static const bool off = [] { const char* e = getenv("RDHIP_DYNAMIC_TILES"); return e && e[0] == '0'; }();
-    if (off || dtype != RDHIP_F64 || ntiles < 8LL * (long long)dyn_grid((unsigned)dev_info().cus) || stream_is_capturing(c)) return nullptr;
+    if (!tune_knobs().dynamic_tiles || dtype != RDHIP_F64 || ntiles < 8LL * (long long)dyn_grid((unsigned)dev_info().cus) || stream_is_capturing(c)) return nullptr;
     if (!c->d_sched) {
         const size_t bytes = (size_t)2 * rdhip_ctx::NSCHED * rdhip_ctx::SCHED_WORDS * sizeof(unsigned);
         if (hipMalloc(&c->d_sched, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_sched = nullptr; return nullptr; }
@@ -1048,18 +1097,25 @@ int rdhip_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long 
     return s.finish(kernel_status(c, launch_errstate_jacobian(M->lie, dtype, c->stream, N, dX, ldx, clear, dG), what));
 }
 
-int rdhip_state_diff(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace) {
+int rdhip_state_diff_map(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* X0, int ldx0, int errmap, void* dX, int memspace) {
     const char* what = "rdhip_state_diff";
     int rc = check_common(c, M, dtype, N, memspace); if (rc) return rc;
     if (N > 0 && (!X || !X0 || !dX)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
     if (ldx < M->d.n || ldx0 < M->d.n) return fail(c, RDHIP_ERR_DIM_MISMATCH, "%s: leading dimension < state_dim=%d", what, M->d.n);
+    if (errmap < RDHIP_ERRMAP_CAYLEY || errmap > RDHIP_ERRMAP_IDENTITY) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad error map %d", what, errmap);
+    // IdentityMap of a quaternion is its four parameters; Rotations.rotation_error wraps the result in a three-element RotationError and throws
+    if (errmap == RDHIP_ERRMAP_IDENTITY && M->lie.nrot > 0 && M->lie.rot == RDHIP_ROT_QUAT)
+        return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: IdentityMap is defined for three-parameter rotations (MRP, RodriguesParam) only", what);
     const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;      // state_diff serves QuatRotation, MRP and RodriguesParam
-    if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, X, ldx, X0, ldx0, dX), what);
+    if (memspace == RDHIP_DEVICE) return kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, X, ldx, X0, ldx0, errmap, dX), what);
     Stage s(c);
     const void* a = s.in(X, (size_t)N * ldx * ts); const void* b = s.in(X0, (size_t)N * ldx0 * ts);
     void* o = s.out(dX, (size_t)N * d.e * ts);
     if (s.rc) return s.rc;
-    return s.finish(kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, a, ldx, b, ldx0, o), what));
+    return s.finish(kernel_status(c, launch_state_diff(M->lie, dtype, c->stream, N, a, ldx, b, ldx0, errmap, o), what));
+}
+int rdhip_state_diff(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX, int memspace) {
+    return rdhip_state_diff_map(c, M, dtype, N, X, ldx, X0, ldx0, RDHIP_ERRMAP_CAYLEY, dX, memspace);
 }
 
 int rdhip_nabla_errstate_jacobian(rdhip_ctx* c, const rdhip_model* M, int dtype, long long N, const void* X, int ldx, const void* Xb, int ldxb,
@@ -1139,7 +1195,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     // multiple of 16, short runs of output) and was measured SLOWER than rollout + Jacobians in two launches from a few hundred thousand knot points
     // on (4 096 x 101 fp64: 252 vs 221 us; 16 384 x 64: 365 vs 365; the latency-sized 512 x 256 fp32: 138 vs 148, so small stacks stay fused); the
     // Jacobian launch over the contiguous stack then also gets the dynamic tile schedule.  Time-major stacks are faster fused at every size measured.
-    static const long long tj_max = [] { const char* e = getenv("RDHIP_FUSED_TJ_MAX_KNOTS"); return e ? atoll(e) : 262144LL; }();
+    const long long tj_max = tune_knobs().fused_tj_max_knots;
     const bool tj_two_launches = layout != RDHIP_TIME_MAJOR && N >= tj_max;
     if (!implicit && c->allow_fused && !tj_two_launches && family_rolljac(d, rule, diff, dtype, f) == RDHIP_OK) {      // (probe: nothing is launched)
         // ONE launch: rollout workgroups + Jacobian workgroups that consume finished chunks through progress words (fused.hpp)
@@ -1159,7 +1215,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     // carries in registers), so states and Jacobians are those of the two plain launches.  BASELINE config 5's cartpole half (4 096 x 256 fp32):
     // rollout 124 us + Jacobians 19 us one after the other; inside the mixed-model call the Jacobians started at 173 us and took 98 us beside
     // the satellite's fused launch -- they were the end of the call.
-    static const long long pipe_min = [] { const char* e = getenv("RDHIP_ROLLJAC_PIPE_MIN_KNOTS"); return e ? atoll(e) : 262144LL; }();     // tuning switch (0 = never)
+    const long long pipe_min = tune_knobs().rolljac_pipe_min_knots;     // tuning switch (0 = never)
     constexpr long long PIECES = 4;
     // ... and only while the rollout is a LATENCY chain that leaves most of the chip idle (one workgroup per 64 trajectories on at most half of the
     // compute units): a batch of 16 384 trajectories fills the chip with its rollout alone, its Jacobians have nothing to run on beside it, and the
@@ -1183,15 +1239,20 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
             if (rc.K >= 2 || k0 == 0) { k = kernel_status(c, family_rollout(d, rule, dtype, rc), what); ++launches; }
             if (k) break;
             // what the Jacobians of this piece read is complete once the piece's rollout is -- except its last knot's successor, which they do not need
-            HIP_TRY(c, hipEventRecord(c->pipe_ev, c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->pipe, c->pipe_ev, 0));
+            // (a failure here must not skip the join below: Jacobian pieces already queued on c->pipe would be left unordered against c->stream)
+            hipError_t he = hipEventRecord(c->pipe_ev, c->stream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(c->pipe, c->pipe_ev, 0);
+            if (he != hipSuccess) { k = fail(c, RDHIP_ERR_HIP, "%s: ordering a Jacobian piece behind its rollout failed: %s", what, hipGetErrorString(he)); break; }
             LaunchArgs jc = j;
             jc.stream = c->pipe; jc.N = nk * Mt; jc.Z = rc.Z; jc.t = rc.t; jc.dt = rc.dt; jc.J = (char*)dJ + (size_t)k0 * jb; jc.sched = nullptr;
             k = kernel_status(c, family_jacobian(d, rule, diff, dtype, jc), what); ++launches;
         }
         // (the context's stream is ordered behind the Jacobians whatever happened above)
-        HIP_TRY(c, hipEventRecord(c->pipe_done, c->pipe));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipe_done, 0));
+        {
+            hipError_t he = hipEventRecord(c->pipe_done, c->pipe);
+            if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->pipe_done, 0);
+            if (he != hipSuccess) { (void)hipStreamSynchronize(c->pipe); if (!k) k = fail(c, RDHIP_ERR_HIP, "%s: joining the Jacobian pieces failed: %s", what, hipGetErrorString(he)); }
+        }
         c->last_rolljac_launches = launches;
         return memspace == RDHIP_HOST ? s.finish(k) : k;
     }
@@ -1228,8 +1289,9 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
     // packets, ~18 us between one call's fused launch and the next one's.
     const bool lazy = c->overlap && c->own_stream && nmodels == 2 && c->side != nullptr;
     unsigned long long sig = 1469598103934665603ULL;
+    std::vector<unsigned long long> argv_now;
     if (lazy) {
-        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ULL; };
+        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ULL; argv_now.push_back(v); };
         mix((unsigned long long)diff); mix((unsigned long long)dtype); mix((unsigned long long)layout);
         for (int p = 0; p < nmodels; ++p) {
             mix((unsigned long long)(uintptr_t)models[p]); mix((unsigned long long)rule[p]); mix((unsigned long long)K[p]); mix((unsigned long long)Mt[p]);
@@ -1238,7 +1300,7 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         }
         if (sig == 0) sig = 1;
     }
-    const bool chained = lazy && c->multi_pending && c->multi_sig == sig;
+    const bool chained = lazy && c->multi_pending && c->multi_sig == sig && c->multi_args == argv_now;
     if (!chained) { const int rc = side_join(c); if (rc) return rc; }     // the fork event below must sit behind the overlap mode's internal stream as well (ORDERING RULE, rdhip.h)
     if (!c->fork_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     if (lazy) {
@@ -1266,14 +1328,14 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
     // ~0.5 us, its Jacobians a stream at ~5 TB/s -- one after the other, or overlapped for the model with the fused launch.  Same-box A/B: the whole
     // of BASELINE config 5 on one GPU (the satellite's fused launch is the long part) 343 us with the cartpole on the context's stream, 294 us with
     // the satellite there; one GPU's share of it (both rollouts ~120 us, the cartpole's Jacobians behind its own) 160 us / 174 us.
-    static const char* main_env = getenv("RDHIP_MULTI_MAIN");      // tuning switch: a model index
+    const int main_env = tune_knobs().multi_main;                  // tuning switch: a model index (-1: the estimate below)
     int main_model = 0; double longest = -1;
     for (int p = 0; p < nmodels; ++p) {
         const double chain = 0.5 * (double)(K[p] > 1 ? K[p] - 1 : 0), stream = jbytes[p] / 5.0e6;
         const double est = p == fused_model ? (chain > stream ? chain : stream) : chain + stream;
         if (est > longest) { longest = est; main_model = p; }
     }
-    if (main_env && main_env[0] >= '0' && main_env[0] < '0' + nmodels) main_model = main_env[0] - '0';
+    if (main_env >= 0 && main_env < nmodels) main_model = main_env;
     int rc0 = RDHIP_OK, slot = 0;
     for (int p = 0; p < nmodels && rc0 == RDHIP_OK; ++p) {  // the side streams first: the context's own stream takes its model last
         if (p == main_model) continue;
@@ -1294,7 +1356,7 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         c->in_overlapped_call = false;
         c->allow_fused = true;
     }
-    if (lazy) { c->multi_sig = rc0 == RDHIP_OK ? sig : 0; return rc0; }
+    if (lazy) { c->multi_sig = rc0 == RDHIP_OK ? sig : 0; c->multi_args.swap(argv_now); return rc0; }
     for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results
     return rc0;
 }

@@ -61,6 +61,28 @@ inline DevInfo dev_info() {
     }
     return cache[slot];
 }
+// ---- tuning knobs -----------------------------------------------------------------------------------------------------------------------------
+// Every developer switch of the dispatcher in ONE place: parsed once per process from RDHIP_TUNE="key=value,key=value" (api.hip tune_knobs_mut; the
+// exported rdhip_tune() merges more pairs at run time -- tests and tuning scripts).  None of them changes a result; they select between kernels /
+// launch shapes that the dispatcher would otherwise choose by size.  include/rdhip.h lists them for users of the library.
+struct TuneKnobs {
+    long long static_grid = 0;            // workgroups of the one-per-CU persistent launches (0: one per compute unit)         tune/tune_grid.hip
+    long long dyn_grid = 0;               // workgroups of launches with the dynamic tile schedule (0: three quarters of the CUs)
+    bool dynamic_tiles = true;            // dynamic_tiles=0: no launch takes the dynamic tile schedule
+    char small = 0;                       // small=tile: the tile loop for every batch size (no four-workgroups-per-tile form)
+    long long small_max = 2;              // workgroups per CU up to which the four-workgroups-per-tile form is used
+    char rollout = 0;                     // rollout=plain|cascade|stream: force a rollout kernel where it applies
+    char rolljac = 0;                     // rolljac=split: rollout + Jacobians always as two launches
+    double fused_ratio = 0;               // the rollout-step / tile-time ratio the fused launch's second part is sized with (0: 5.9 for fp32, none for fp64)
+    long long fused_jac_workgroups = 0;   // Jacobian workgroups of a fused launch (0: every CU the rollout groups leave)
+    long long fused_tj_max_knots = 262144;      // trajectory-major stacks from this many knot points on take two launches
+    long long rolljac_pipe_min_knots = 262144;  // time-major stacks of models without the fused launch are pipelined in pieces from this size on (0: never)
+    int multi_main = -1;                  // rdhip_rollout_jacobian_multi: the model that gets the fused launch (-1: the one with most Jacobian bytes)
+    char ift = 0;                         // ift=reg: the one-kernel register path; ift=3: Newton kernel + tile kernel + gated exact kernel (round 2)
+};
+TuneKnobs& tune_knobs_mut();              // api.hip
+inline const TuneKnobs& tune_knobs() { return tune_knobs_mut(); }
+
 // persistent grid for the tile kernels: as many workgroups as fit on the chip at once (LDS- and wave-limited), never more than tiles
 inline unsigned tile_grid(size_t lds_bytes, int threads, long long ntiles) {
     const DevInfo di = dev_info();
@@ -95,8 +117,7 @@ inline unsigned tile_grid_occ(const void* kernel, size_t lds_bytes, int threads,
         per_cu_of[dev & 63][kernel] = per_cu;
     }
     const unsigned lds_bound = tile_grid(lds_bytes, threads, ntiles);
-    // RDHIP_STATIC_GRID (tuning): workgroups per launch of the one-per-CU persistent kernels instead of one per compute unit (tune/tune_grid.hip)
-    static const long long grid_env = [] { const char* e = getenv("RDHIP_STATIC_GRID"); return e ? atoll(e) : 0LL; }();
+    const long long grid_env = tune_knobs().static_grid;     // (tuning) workgroups per launch of the one-per-CU persistent kernels instead of one per compute unit
     if (grid_env > 0 && per_cu == 1) { const long long r0 = ntiles < grid_env ? ntiles : grid_env; return (unsigned)(r0 < (long long)lds_bound ? r0 : (long long)lds_bound); }
     const long long g = (long long)dev_info().cus * per_cu;
     const long long r = ntiles < g ? ntiles : g;
@@ -109,12 +130,14 @@ inline unsigned tile_grid_occ(const void* kernel, size_t lds_bytes, int threads,
 // than 256.  Every workgroup streams its own 126 KB slab; fewer concurrent streams meet fewer open DRAM rows per bank (a streaming fill shows the same
 // preference), and the counter keeps the smaller grid balanced.  Static launches of a few tiles per workgroup (the 65 536-knot headline: 4 per
 // workgroup) lose to tile quantisation what they gain (27.15 us on 256, 26.85 on 160, 27.4 on 176, 28.6 on 192) and keep the whole chip; fp32
-// tiles are half the size and want all 256 (1 M knots: 205 us on 256, 217-222 on 192).  RDHIP_DYN_GRID overrides (tuning).
+// tiles are half the size and want all 256 (1 M knots: 205 us on 256, 217-222 on 192).  RDHIP_TUNE=dyn_grid=N overrides (tuning).
+// Only where it was measured: kernels with ONE workgroup per compute unit (full == the CU count).  A kernel whose tiles are small enough for two or three
+// workgroups per CU (LieSatellite: 45 KB) keeps its full grid -- round 5 cut those to 192 workgroups too, a quarter of what fits.
 inline unsigned dyn_grid(unsigned full) {
-    static const long long env = [] { const char* e = getenv("RDHIP_DYN_GRID"); return e ? atoll(e) : 0LL; }();
+    const long long env = tune_knobs().dyn_grid;
     const unsigned cus = (unsigned)dev_info().cus;
     if (env > 0) return (unsigned)(env < (long long)full ? env : (long long)full);
-    if (full < cus) return full;
+    if (full != cus) return full;
     const unsigned g = (cus * 3 / 4) & ~7u;
     return g >= 8 ? g : full;
 }
@@ -229,7 +252,7 @@ struct LieDesc {
     signed char err_src[16];    // state_diff: error index -> state index for vector parts, -1-k for rotation k parts
 };
 int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, int clear, void* G);
-int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX);
+int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, int errmap, void* dX);
 // dynamics-error helpers (errstate.hip): E[:,k] -= Z[0:n, k+1] ; J2[k] = [-I 0]
 int launch_sub_next_state(int dtype, hipStream_t s, long long pairs, int n, int nz, const void* Z, void* E);
 int launch_fill_neg_identity(int dtype, hipStream_t s, long long pairs, int n, int nz, void* J2);

@@ -18,6 +18,19 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? RDHIP_OK : RDHIP_
 // which (model, rule) pairs get the compile-time-column ForwardAD kernel (big code, structural sparsity folded)
 template <class Mdl, int RULE> struct UnrollPolicy { static constexpr bool value = false; static constexpr int NC = 0; using Plan = void; };
 
+// LEAN variants of a model family: they keep every operator (evaluation, the three diff methods on the split-role tile loop, error-state expansion,
+// implicit rules, rollouts) but not the forms that exist only to shave latency off special shapes -- the one-launch rollout -> Jacobians kernel
+// (the caller's two launches instead) and the four-workgroups-per-tile kernel for batches below 8 192 knot points (the tile loop instead).  Round 6:
+// the full-inertia rigid bodies (fam_rigid.hpp; the reference's own models all carry Diagonal inertias) -- those two forms were 12 MB of their code.
+template <class Mdl> struct LeanVariant { static constexpr bool value = false; };
+
+// does (model, rule) have the one-launch rollout -> Jacobians kernel (fused.hpp)?  A cascade structure, a four-wave compile-time column plan with four copy
+// waves, and not a lean variant
+template <class Mdl, int RULE, class = void> struct FusedFormOf { static constexpr bool value = false; };
+template <class Mdl, int RULE> struct FusedFormOf<Mdl, RULE, typename std::enable_if<(Cascade<Mdl>::NB > 1) && UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC == 4 && !LeanVariant<Mdl>::value>::type> {
+    static constexpr bool value = UnrollPolicy<Mdl, RULE>::Plan::NG == 4;
+};
+
 // column plan of the implicit-function-theorem tile kernel: the model's ForwardAD plan if it has one (the per-column costs have the same
 // ordering: a column costs what it can reach downstream), contiguous ranges otherwise
 template <class Mdl, class = void> struct IftPlanOf { using Plan = ContiguousPlan<Mdl::NX + Mdl::NU, 4>; };
@@ -41,12 +54,12 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     const unsigned grid = (unsigned)((a.N + 63) / 64);
     const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
     using Cas = Cascade<decltype(Fn::m)>;
-    static const char* roll_env = getenv("RDHIP_ROLLOUT");                 // tuning switch: "plain" / "cascade" / "stream" force a kernel where it applies
+    const char roll_env = tune_knobs().rollout;                            // tuning switch: 'p'lain / 'c'ascade / 's'tream force a kernel where it applies (0: by size)
     if constexpr (Fn::RULE_ID != RULE_IMPLICIT_MIDPOINT) {
         // the throughput regime (rollout_stream.hpp): at least two 64-trajectory groups per CU.  Chunks move as whole 16-byte units, so every run of
         // the stack must start on a 16-byte boundary; other shapes take the one-lane-per-trajectory kernel there (the cascade kernel buys latency, not
         // traffic: 0.30-0.36 of the roofline at 65 536 x 32 / 262 144 x 16 where the plain kernel reaches 0.37-0.44 and the streaming one 0.41-0.49)
-        const bool forced = roll_env && roll_env[0] == 's';
+        const bool forced = roll_env == 's';
         if ((forced || (!roll_env && (long long)grid >= 2LL * dev_info().cus)) && a.K >= 1) {
             typedef unsigned int V4 __attribute__((ext_vector_type(4)));
             constexpr int ZB = (Fn::NX + Fn::NU) * (int)sizeof(T);
@@ -79,32 +92,34 @@ template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     }
     if constexpr (Cas::NB > 1) {
         // one wavefront per cascade block + an IO wavefront (cascade.hpp): the latency chain of a step shrinks to the longest block's
-        const bool plain = roll_env && roll_env[0] == 'p';
+        const bool plain = roll_env == 'p';
         if (!plain && a.K < (1LL << 26) && a.N < (1LL << 26)) {            // (the IO wave's per-lane offsets are 32-bit)
             constexpr int R = 4;
             // models whose rollout + Jacobians can run as one launch (fused.hpp) roll out through THAT kernel (rollout workgroups only): the two-call
             // and the one-call path then execute the same machine code and agree to the last bit
-            if constexpr (Fn::RULE_ID != RULE_IMPLICIT_MIDPOINT) {
+            if constexpr (Fn::RULE_ID != RULE_IMPLICIT_MIDPOINT && FusedFormOf<typename std::remove_cv<decltype(Fn::m)>::type, Fn::RULE_ID>::value) {
                 using Mdl = typename std::remove_cv<decltype(Fn::m)>::type;
-                if constexpr (UnrollPolicy<Mdl, Fn::RULE_ID>::value && UnrollPolicy<Mdl, Fn::RULE_ID>::NC == 4) {
-                    using Plan = typename UnrollPolicy<Mdl, Fn::RULE_ID>::Plan;
-                    // (only where the one-launch form exists at all, i.e. while the rollout groups leave half of the chip to Jacobian workgroups: a
-                    // big batch of short rollouts is throughput-bound and keeps the leaner 256-thread kernel and its write-back stores)
-                    if constexpr (Plan::NG == 4) if (2LL * grid <= (long long)dev_info().cus) {
-                        constexpr size_t ldsf = FusedLds<Fn, T, Cas, R, Plan, 4>::BYTES;
-                        auto kf = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, 4>;
-                        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), ldsf) != hipSuccess) return RDHIP_ERR_HIP;
-                        RD_LAUNCH(kf, dim3(grid), dim3(FUSED_THREADS), ldsf, a.stream, fn, a.K, a.N, (int)grid, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0,
-                                           (T*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL);
-                        return hip_status(hipGetLastError());
-                    }
+                using Plan = typename UnrollPolicy<Mdl, Fn::RULE_ID>::Plan;
+                // ... while the rollout groups leave half of the chip free (the regime the one-launch form exists for: a latency chain on a few CUs).
+                // Between that and the streaming regime above (8 192 .. 32 768 trajectories) every SIMD has a trajectory wave of its own and the
+                // one-lane kernel below is as fast as the cascade kernel was (rollout_stream.hpp: 0.6 of the roofline at 16 384 x 64) -- round 6 dropped
+                // the cascade kernel's instantiations for these models (2 MB of code for that one window).
+                if (2LL * grid <= (long long)dev_info().cus) {
+                    constexpr size_t ldsf = FusedLds<Fn, T, Cas, R, Plan, 4>::BYTES;
+                    auto kf = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, 4>;
+                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kf), ldsf) != hipSuccess) return RDHIP_ERR_HIP;
+                    RD_LAUNCH(kf, dim3(grid), dim3(FUSED_THREADS), ldsf, a.stream, fn, a.K, a.N, (int)grid, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0,
+                                       (T*)nullptr, (unsigned long long*)nullptr, 0ULL, 0LL);
+                    return hip_status(hipGetLastError());
                 }
+                if (roll_env == 'c') return RDHIP_ERR_UNSUPPORTED;          // (tuning switch rollout=cascade: no such kernel for this model)
+            } else {
+                constexpr size_t lds = CascadeLds<Fn, Cas, R>::BYTES;
+                auto kern = rollout_cascade_kernel<Fn, T, Cas, R>;
+                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+                RD_LAUNCH(kern, dim3(grid), dim3((Cas::NB + 1) * TILE), lds, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
+                return hip_status(hipGetLastError());
             }
-            constexpr size_t lds = CascadeLds<Fn, Cas, R>::BYTES;
-            auto kern = rollout_cascade_kernel<Fn, T, Cas, R>;
-            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-            RD_LAUNCH(kern, dim3(grid), dim3((Cas::NB + 1) * TILE), lds, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
-            return hip_status(hipGetLastError());
         }
     }
     RD_LAUNCH((rollout_kernel<Fn, T>), dim3(grid), dim3(64), 0, a.stream, fn, a.K, a.N, sj, sk, (T*)a.Z, a.t, a.dt, (const T*)a.X0);
@@ -146,6 +161,27 @@ template <class Fn, class T, class Plan, int NC, class K, class KD> int launch_s
 template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel(K kernel, const Fn& fn, const LaunchArgs& a) {
     return launch_split_kernel<Fn, T, Plan, NC>(kernel, kernel, fn, a);
 }
+// Bodies other than the ForwardAD flagship carry the dynamic tile schedule in their ONE fp64 instantiation (DYN = true; launches below 8 tiles per
+// workgroup pass no counter words and the loop takes its static order at run time).  Round 5 shipped a second, schedule-free instantiation of each for
+// those launches: the dormant schedule costs them 0.3-0.5 us of ~28 (kernels.hpp SingleBatchDyn), the second copies cost 4.5 MB of code and nothing
+// ever measured or tested most of them (profiles/r05/kernel_reach.txt).  The flagship keeps both (jac_ad_split_kernel).
+template <class Fn, class T, class Plan, int NC, class KD> int launch_split_kernel_rt(KD kernel_dyn, const Fn& fn, const LaunchArgs& a) {
+    constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
+    const long long ntiles = (a.N + TILE - 1) / TILE;
+    constexpr int threads = (Plan::NG + NC) * TILE;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_dyn), lds) != hipSuccess) return RDHIP_ERR_HIP;
+    const unsigned full = tile_grid_occ(reinterpret_cast<const void*>(kernel_dyn), lds, threads, ntiles);
+    if (a.sched) {
+        const unsigned gd = dyn_grid(full);
+        if (ntiles >= 8LL * gd) {
+            RD_LAUNCH(kernel_dyn, dim3(gd), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
+            return hip_status(hipGetLastError());
+        }
+    }
+    RD_LAUNCH(kernel_dyn, dim3(full), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, (unsigned*)nullptr);
+    return hip_status(hipGetLastError());
+}
 
 // the same loop for kernels without a separate f(z) output (signature ..., J)
 template <class Fn, class T, class Plan, int NC, class K> int launch_split_kernel_j(K kernel, const Fn& fn, const LaunchArgs& a) {
@@ -171,31 +207,27 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
     constexpr size_t lds = SplitLds<Fn, T, Plan, NC>::BYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
     constexpr int threads = (Plan::NG + NC) * TILE;
-    if constexpr (sizeof(T) == 8) {                      // the instantiation with the dynamic tile schedule (see launch_split_kernel)
-        if (a.sched) {
-            auto kd = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB, true>;
-            const unsigned gd = dyn_grid(tile_grid_occ(reinterpret_cast<const void*>(kd), lds, threads, a.multi->pod.total));
-            if (a.multi->pod.total >= 8LL * gd) {
-                if (ensure_dynamic_lds(reinterpret_cast<const void*>(kd), lds) != hipSuccess) return RDHIP_ERR_HIP;
-                RD_LAUNCH(kd, dim3(gd), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
-                return hip_status(hipGetLastError());
-            }
+    // fp64: ONE instantiation that carries the dynamic tile schedule and takes it at run time (counter words + 8 or more tiles per workgroup of the reduced
+    // grid), like launch_split_kernel_rt; fp32 tiles never take it (kernels.hpp DYN_OK)
+    auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB, sizeof(T) == 8>;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+    const unsigned full = tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total);
+    if (sizeof(T) == 8 && a.sched) {
+        const unsigned gd = dyn_grid(full);
+        if (a.multi->pod.total >= 8LL * gd) {
+            RD_LAUNCH(kern, dim3(gd), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
+            return hip_status(hipGetLastError());
         }
     }
-    auto kern = jac_split_multi_kernel<Fn, T, Plan, NC, Body, MINB>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, threads, a.multi->pod.total)), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), (unsigned*)nullptr);
+    RD_LAUNCH(kern, dim3(full), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), (unsigned*)nullptr);
     return hip_status(hipGetLastError());
 }
-template <class Fn, class T, class Plan, class Body> int launch_tile_multi(const Fn& fn, const LaunchArgs& a) {
-    constexpr size_t lds = JacLds<Fn, T, Plan>::BYTES;
-    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS of a gfx950 CU");
-    auto kern = jac_tile_multi_kernel<Fn, T, Plan, Body>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-    RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, Plan::NG * TILE, a.multi->pod.total)), dim3(Plan::NG * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
-    return hip_status(hipGetLastError());
-}
-// several packed trajectories, one launch: the same kernel choice as launch_jacobian below, every body on a MultiBatch
+// several packed trajectories, one launch.  Round 6: the one-launch form exists for ForwardAD -- the reference's default diff method
+// of a DiscretizedDynamics (src/discretized_dynamics.jl:190) -- on 16-byte aligned outputs: the small-model kernel, or the split-role tile loop on the
+// body the single-batch kernel uses.  Every other case (FiniteDifference, the UserDefined chain rule, outputs that are not 16-byte aligned) returns
+// RDHIP_ERR_UNSUPPORTED before anything is launched and rdhip_jacobian_multi runs the batches as separate rdhip_jacobian calls (api.hip): same results.
+// The batch-table instantiations of those bodies were 52 % of the library's device code (tools/code_size.py on the round-5 build: 66 of 101 MB of
+// symbols) and nothing measured or tested them (profiles/r05/kernel_reach.txt: 10 of 1 021 launched).
 template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff, const LaunchArgs& a) {
     using Fn = Fun<Mdl, RULE>;
     using T = typename Fn::T;
@@ -206,42 +238,24 @@ template <class Mdl, int RULE> int launch_jacobian_multi(const Mdl& m, int diff,
     const long long ntiles = a.multi->pod.total;
     if (ntiles == 0) return RDHIP_OK;
     const bool al = a.multi->aligned16;
-    if (diff == RDHIP_FORWARD_AD) {
-        if constexpr (NZ <= 10 && !(UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0)) {       // (a small model with a split-role plan of its own -- LieSatellite -- takes the tile loop)
-            constexpr size_t lds = SmallLds<Fn, T>::BYTES;
-            auto kern = jac_ad_small_multi_kernel<Fn, T>;
-            if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
-            constexpr int W = SmallLds<Fn, T>::WAVES;
-            RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
-            return hip_status(hipGetLastError());
-        } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
-            using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
-            constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
-            if constexpr (NC > 0) { if (al) return launch_split_multi<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>, (sizeof(T) == 4 ? RD_F32_MINB : 1)>(fn, a); }
-            return launch_tile_multi<Fn, T, Plan, AdUnrolledBody<Fn, T, Plan>>(fn, a);
-        } else {
-            if constexpr (split_fits) { if (al) return launch_split_multi<Fn, T, DefPlan, 4, AdLoopBody<Fn, T, DefPlan>>(fn, a); }
-            return launch_tile_multi<Fn, T, DefPlan, AdLoopBody<Fn, T, DefPlan>>(fn, a);
-        }
-    } else if (diff == RDHIP_FINITE_DIFF) {
-        if constexpr (RULE != RULE_CONTINUOUS && Cascade<Mdl>::NB > 1 && FdPlanOf<Mdl>::value) {
-            using Plan = typename FdPlanOf<Mdl>::Plan;
-            if (al) return launch_split_multi<Fn, T, Plan, 4, FdCascadeBody<Fn, T, Plan, Cascade<Mdl>>>(fn, a);
-        }
-        if constexpr (split_fits) { if (al) return launch_split_multi<Fn, T, DefPlan, 4, FdBody<Fn, T, DefPlan>>(fn, a); }
-        return launch_tile_multi<Fn, T, DefPlan, FdBody<Fn, T, DefPlan>>(fn, a);
-    } else if (diff == RDHIP_USER_DEFINED) {
-        if constexpr (Mdl::HAS_USER_JACOBIAN) {
-            if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
-                using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
-                constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
-                if (al) return launch_split_multi<Fn, T, Plan, NC, ChainUnrolledBody<Fn, T, Plan>>(fn, a);
-            }
-            return launch_tile_multi<Fn, T, DefPlan, ChainBody<Fn, T, DefPlan>>(fn, a);
-        }
-        else return RDHIP_ERR_NOT_IMPLEMENTED;
-    }
-    return RDHIP_ERR_INVALID_ARG;
+    if (diff < RDHIP_FORWARD_AD || diff > RDHIP_USER_DEFINED) return RDHIP_ERR_INVALID_ARG;
+    if (diff != RDHIP_FORWARD_AD) return RDHIP_ERR_UNSUPPORTED;
+    if constexpr (NZ <= 10 && !(UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0)) {       // (a small model with a split-role plan of its own -- LieSatellite -- takes the tile loop)
+        constexpr size_t lds = SmallLds<Fn, T>::BYTES;
+        auto kern = jac_ad_small_multi_kernel<Fn, T>;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
+        constexpr int W = SmallLds<Fn, T>::WAVES;
+        RD_LAUNCH(kern, dim3(tile_grid_occ(reinterpret_cast<const void*>(kern), lds, W * TILE, (ntiles + W - 1) / W)), dim3(W * TILE), lds, a.stream, fn, to_multi_batch<T>(*a.multi));
+        return hip_status(hipGetLastError());
+    } else if constexpr (UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC > 0) {
+        using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
+        constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
+        if (al) return launch_split_multi<Fn, T, Plan, NC, AdUnrolledBody<Fn, T, Plan>, (sizeof(T) == 4 ? RD_F32_MINB : 1)>(fn, a);
+        return RDHIP_ERR_UNSUPPORTED;
+    } else if constexpr (split_fits) {
+        if (al) return launch_split_multi<Fn, T, DefPlan, 4, AdLoopBody<Fn, T, DefPlan>>(fn, a);
+        return RDHIP_ERR_UNSUPPORTED;
+    } else return RDHIP_ERR_UNSUPPORTED;
 }
 
 template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const LaunchArgs& a) {
@@ -267,15 +281,13 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
         } else if constexpr (UnrollPolicy<Mdl, RULE>::value) {
             using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
             constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
-            if constexpr (Plan::NG == 4) {
+            if constexpr (Plan::NG == 4 && !LeanVariant<Mdl>::value) {
                 // small batches (at most two of these workgroups per CU: up to 8 192 knot points on a whole MI355X): the columns of a tile over four
                 // workgroups.  rocprofv3 medians against the tile loop: 4.8 vs 7.5 us up to 512 knot points, 5.7 vs 8.7 at 4 096, 8.0 vs 8.7 at 8 192;
                 // with four per CU 10.8 vs 8.6 at 12 288 and 12.8 vs 9.3 at 16 384 (tools/small_trace.sh)
-                static const char* small_mode = getenv("RDHIP_SMALL");     // tuning switch: "tile" keeps the tile loop for every size
                 const long long ntiles = (a.N + TILE - 1) / TILE;
-                static const char* small_max = getenv("RDHIP_SMALL_MAX");  // tuning: workgroups per CU up to which the column-split kernel is used
-                const long long per_cu = small_max ? atoll(small_max) : 2;
-                if (4 * ntiles <= per_cu * (long long)dev_info().cus && !(small_mode && small_mode[0] == 't')) {
+                const long long per_cu = tune_knobs().small_max;           // (tuning: small_max / small=tile, common.hpp TuneKnobs)
+                if (4 * ntiles <= per_cu * (long long)dev_info().cus && tune_knobs().small != 't') {
                     constexpr size_t lds = ColSplitLds<Fn, T>::BYTES;
                     auto kern = jac_ad_colsplit_kernel<Fn, T, Plan>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
@@ -292,7 +304,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
             return launch_jac_kernel<Fn, T, Plan>(jac_ad_unrolled_kernel<Fn, T, Plan>, fn, a);
         } else {
             if constexpr (split_fits)
-                if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, jac_ad_loop_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
+                if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel_rt<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
                   else return launch_split_kernel<Fn, T, DefPlan, 4>(jac_ad_loop_split_kernel<Fn, T, DefPlan, 4>, fn, a); }
             return launch_jac_kernel<Fn, T, DefPlan>(jac_ad_loop_kernel<Fn, T, DefPlan>, fn, a);
         }
@@ -300,11 +312,11 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
         // models with a cascade structure and a column plan: perturbed evaluations integrate only the blocks a column can change (cascade.hpp)
         if constexpr (RULE != RULE_CONTINUOUS && Cascade<Mdl>::NB > 1 && FdPlanOf<Mdl>::value) {
             using Plan = typename FdPlanOf<Mdl>::Plan;
-            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4, true>, fn, a);
+            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel_rt<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4, true>, fn, a);
               else return launch_split_kernel<Fn, T, Plan, 4>(jac_fd_cascade_kernel<Fn, T, Plan, Cascade<Mdl>, 4>, fn, a); }
         }
-        if constexpr (split_fits)
-            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, jac_fd_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
+        else if constexpr (split_fits)                     // (aligned outputs of a model with a cascade plan never get here: no instantiation for them)
+            if (aligned16(a.J) && aligned16(a.Y)) { if constexpr (sizeof(T) == 8) return launch_split_kernel_rt<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4, true>, fn, a);
               else return launch_split_kernel<Fn, T, DefPlan, 4>(jac_fd_split_kernel<Fn, T, DefPlan, 4>, fn, a); }
         return launch_jac_kernel<Fn, T, DefPlan>(jac_fd_kernel<Fn, T, DefPlan>, fn, a);
     } else if (diff == RDHIP_USER_DEFINED) {
@@ -313,7 +325,7 @@ template <class Mdl, int RULE> int launch_jacobian(const Mdl& m, int diff, const
                 using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
                 constexpr int NC = UnrollPolicy<Mdl, RULE>::NC;
                 if (aligned16(a.J) && aligned16(a.Y))
-                    { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, jac_chain_split_kernel<Fn, T, Plan, NC, true>, fn, a);
+                    { if constexpr (sizeof(T) == 8) return launch_split_kernel_rt<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC, true>, fn, a);
                       else return launch_split_kernel<Fn, T, Plan, NC>(jac_chain_split_kernel<Fn, T, Plan, NC>, fn, a); }
             }
             return launch_jac_kernel<Fn, T, DefPlan>(jac_chain_kernel<Fn, T, DefPlan>, fn, a);
@@ -329,12 +341,11 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
     using Fn = Fun<Mdl, RULE>;
     using T = typename Fn::T;
     using Cas = Cascade<Mdl>;
-    if constexpr (Cas::NB > 1 && UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC == 4) {
+    if constexpr (Cas::NB > 1 && UnrollPolicy<Mdl, RULE>::value && UnrollPolicy<Mdl, RULE>::NC == 4 && !LeanVariant<Mdl>::value) {
         using Plan = typename UnrollPolicy<Mdl, RULE>::Plan;
         constexpr int NC = 4, R = 4;
         if constexpr (Plan::NG == 4) {
-            static const char* mode = getenv("RDHIP_ROLLJAC");              // tuning switch: "split" keeps the two launches
-            if (mode && mode[0] == 's') return RDHIP_ERR_UNSUPPORTED;
+            if (tune_knobs().rolljac == 's') return RDHIP_ERR_UNSUPPORTED;      // tuning switch rolljac=split: the two launches
             const long long K = a.K, M = a.N;
             if (diff != RDHIP_FORWARD_AD || !a.progress || K < 1 || M < 1 || K >= (1LL << 26) || M >= (1LL << 26)) return RDHIP_ERR_UNSUPPORTED;
             // time-major tiles are copied as aligned 16-byte units of one slab: every knot's row of tiles must start aligned (trajectory-major
@@ -347,6 +358,8 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             const long long cus = dev_info().cus;
             // the rollout workgroups must leave most of the chip to the Jacobians (and all of them must be resident together with consumers)
             if (G * FUSED_PROGRESS_STRIDE > a.progress_words || 2 * G > cus) return RDHIP_ERR_UNSUPPORTED;
+            // (FusedWalk counts items and virtual indices in 32 bits: K G items + one grid of slack; a stack that large does not fit a GPU's memory, but say so)
+            if (K * G + 4 * cus >= (1LL << 32)) return RDHIP_ERR_UNSUPPORTED;
             if (a.probe) return RDHIP_OK;
             // The walk's second part (fused.hpp FusedWalk): the rollout workgroups produce G tiles per step, the nj Jacobian workgroups consume nj tiles per
             // tile time; while the rollout runs, the consumers get through  A = nj (K - 1) step / tile_time  tiles.  If that is (nearly) everything the
@@ -357,11 +370,9 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
             // workgroups and the Jacobian workgroups end together, 205-213 and 208-218 us); calibrated on the satellite only.
             // fp64 takes NO second part: its 126 KB tiles are bandwidth-bound on three quarters of the chip already (the plain kernel is faster on
             // 192 workgroups than on 256, launch_split_kernel above) -- 4 096 x 101 knots 162-166 us without, 173-181 us with a split anywhere
-            // between 0.3 and 0.55 K.  RDHIP_FUSED_RATIO (tuning) forces a ratio for either type.
-            static const double ratio_env = [] { const char* e = getenv("RDHIP_FUSED_RATIO"); return e ? atof(e) : 0.0; }();
-            // test switch: fewer Jacobian workgroups (read per call -- tests/test_gpu_round4.py toggles it inside one process; a look-up in the environment
-            // costs a fraction of a microsecond in front of a launch of 100 us and more)
-            const long long nj_env = [] { const char* e = getenv("RDHIP_FUSED_JAC_WORKGROUPS"); return e ? atoll(e) : 0LL; }();
+            // between 0.3 and 0.55 K.  RDHIP_TUNE=fused_ratio=x (tuning) forces a ratio for either type.
+            const double ratio_env = tune_knobs().fused_ratio;
+            const long long nj_env = tune_knobs().fused_jac_workgroups;     // test switch: fewer Jacobian workgroups (tests/test_gpu_round4.py sets it through rdhip_tune)
             auto split_of = [&](long long ntiles, long long nj) -> long long {
                 if (sizeof(T) == 8 && !(ratio_env > 0)) return 0;
                 const double ratio = ratio_env > 0 ? ratio_env : 5.9;
@@ -417,7 +428,7 @@ template <class Mdl, int RULE> int launch_errexp(const Mdl& m, const LaunchArgs&
     if (a.N == 0) return RDHIP_OK;
     if (!aligned16(a.J) || !aligned16(a.Y)) return RDHIP_ERR_INVALID_ARG;
     Fn fn{{m}};
-    { if constexpr (sizeof(T) == 8) return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, jac_errexp_split_kernel<Fn, T, Plan, NC, true>, fn, a);
+    { if constexpr (sizeof(T) == 8) return launch_split_kernel_rt<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC, true>, fn, a);
       else return launch_split_kernel<Fn, T, Plan, NC>(jac_errexp_split_kernel<Fn, T, Plan, NC>, fn, a); }
 }
 template <class Mdl> int dispatch_errexp_rule(const Mdl& m, int rule, const LaunchArgs& a) {
@@ -493,8 +504,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         if (a.K == 0) return RDHIP_OK;
         if constexpr (Cascade<Mdl>::NB > 1) {
             // one wavefront per cascade block + the IO wavefront, every wave solving its block of the implicit equation per step (ImplicitRollFun)
-            static const char* roll_mode = getenv("RDHIP_ROLLOUT");         // tuning switch: "plain" keeps one lane per trajectory
-            if (a.flag && !(roll_mode && roll_mode[0] == 'p') && a.K < (1LL << 26) && a.N < (1LL << 26)) {
+            if (a.flag && tune_knobs().rollout != 'p' && a.K < (1LL << 26) && a.N < (1LL << 26)) {      // (tuning switch rollout=plain keeps one lane per trajectory)
                 using RFn = ImplicitRollFun<Mdl>;
                 using Cas = Cascade<Mdl>;
                 constexpr size_t ldsr = CascadeLds<RFn, Cas, 4>::BYTES;
@@ -522,11 +532,11 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         using IFn = IftFun<Mdl>;
         using IPlan = typename IftPlanOf<Mdl>::Plan;
         if constexpr (!reg_is_exact && NZ > 10 && SplitLds<IFn, T, IPlan, 4>::BYTES <= 160 * 1024) {
-            static const char* ift_mode = getenv("RDHIP_IFT");             // tuning switches: "reg" = the one-kernel register path, "3" = Newton kernel + tile kernel + gated exact kernel (round 2)
-            if (a.flag && aligned16(a.J) && !(ift_mode && ift_mode[0] == 'r')) {
+            const char ift_mode = tune_knobs().ift;                        // tuning switches: 'r' = the one-kernel register path, '3' = Newton kernel + tile kernel + gated exact kernel (round 2)
+            if (a.flag && aligned16(a.J) && ift_mode != 'r') {
                 // ONE launch: the tile kernel's compute waves run the Newton solve themselves, x_next leaves through the tile loop's f(z) slab, and the
                 // tiles that need the exact solve are redone by their own workgroup behind the loop (implicit.hpp IftBody)
-                if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && !(ift_mode && ift_mode[0] == '3'))
+                if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && ift_mode != '3')
                     return launch_split_kernel<IFn, T, IPlan, 4>(implicit_ift_split_kernel<IFn, T, IPlan, 4>, IFn{m, a.newton_tol, a.flag, a.newton_iters, IftBody<IFn, T, IPlan>::HELPER ? 2 : 1, nullptr}, a);
                 RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags | 2);
                 LaunchArgs b = a;

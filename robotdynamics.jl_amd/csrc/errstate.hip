@@ -19,6 +19,12 @@ __device__ const signed char LH_SGN[4][3] = {{-1, -1, -1}, {1, -1, 1}, {1, 1, -1
 template <class T> __device__ __forceinline__ T rsqrt_(T x);
 template <> __device__ __forceinline__ double rsqrt_<double>(double x) { return 1.0 / sqrt(x); }
 template <> __device__ __forceinline__ float rsqrt_<float>(float x) { return 1.0f / sqrtf(x); }
+template <class T> __device__ __forceinline__ T sqrtT(T x);
+template <> __device__ __forceinline__ double sqrtT<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float sqrtT<float>(float x) { return sqrtf(x); }
+template <class T> __device__ __forceinline__ T atan2T(T y, T x);
+template <> __device__ __forceinline__ double atan2T<double>(double y, double x) { return atan2(y, x); }
+template <> __device__ __forceinline__ float atan2T<float>(float y, float x) { return atan2f(y, x); }
 
 template <class T>
 __global__ void __launch_bounds__(256) errstate_clear_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, T* __restrict__ G) {
@@ -185,8 +191,24 @@ __global__ void __launch_bounds__(256) errstate3_kernel(LieDesc d, long long N, 
     }
 }
 
+
+// inv(errmap)(dq) for dq = [w; v], the quaternion of R0^-1 R (src/liestate.jl:216-217: Rotations.rotation_error(R, R0, errmap); rdhip.h lists the maps).
+// `rot`: the state's parameterisation -- IdentityMap returns the relative rotation's own parameters (MRP v / (1 + w), RodriguesParam v / w).
+template <class T> __device__ __forceinline__ void errmap_apply(int errmap, int rot, T w, const T (&v)[3], T (&o)[3]) {
+    T M;
+    if (errmap == RDHIP_ERRMAP_EXPONENTIAL) {
+        const T th = sqrtT<T>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        M = th > T(1e-6) ? atan2T<T>(th, w) / th : (T(1) - th * th / (T(3) * w * w)) / w;
+    } else if (errmap == RDHIP_ERRMAP_MRP) M = T(2) / (T(1) + w);
+    else if (errmap == RDHIP_ERRMAP_QUATVEC) M = w > T(0) ? T(1) : (w < T(0) ? T(-1) : T(0));
+    else if (errmap == RDHIP_ERRMAP_IDENTITY && rot == RDHIP_ROT_MRP) M = T(1) / (T(1) + w);
+    else M = T(1) / w;                                   // CayleyMap; IdentityMap of a RodriguesParam state
+    o[0] = errmap == RDHIP_ERRMAP_CAYLEY ? v[0] / w : v[0] * M;      // (the Cayley error keeps the division it has always had: bit-identical to rounds 1-5)
+    o[1] = errmap == RDHIP_ERRMAP_CAYLEY ? v[1] / w : v[1] * M;
+    o[2] = errmap == RDHIP_ERRMAP_CAYLEY ? v[2] / w : v[2] * M;
+}
 template <class T>
-__global__ void __launch_bounds__(256) state_diff_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, T* __restrict__ dX) {
+__global__ void __launch_bounds__(256) state_diff_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, int errmap, T* __restrict__ dX) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * d.e) return;
     const long long k = idx / d.e;
@@ -218,10 +240,10 @@ __global__ void __launch_bounds__(256) state_diff_kernel(LieDesc d, long long N,
     const T b0 = qb[0], b1 = -qb[1], b2 = -qb[2], b3 = -qb[3];                   // conj(q0)
     // dq = conj(q0) (x) q ; Cayley error = vec(dq) / scalar(dq)  (rotation_error(q, q0, CayleyMap), test/rbstate.jl:157)
     const T w = b0 * a0 - b1 * a1 - b2 * a2 - b3 * a3;
-    const T v = (j == 0) ? (b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2)
-              : (j == 1) ? (b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1)
-                         : (b0 * a3 + b1 * a2 - b2 * a1 + b3 * a0);
-    dX[idx] = v / w;
+    const T v[3] = {b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2, b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1, b0 * a3 + b1 * a2 - b2 * a1 + b3 * a0};
+    T o[3];
+    errmap_apply<T>(errmap, d.rot, w, v, o);
+    dX[idx] = o[j];
 }
 
 template <class T>
@@ -362,7 +384,7 @@ int launch_errstate_jacobian(const LieDesc& d, int dtype, hipStream_t s, long lo
 // lane then computes all e error coordinates of its knot point (each relative rotation once, not once per component), and the e x 128 output
 // tile leaves as a lane-contiguous sweep.
 template <class T, int MAXLD>
-__global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, T* __restrict__ dX) {
+__global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long long N, const T* __restrict__ X, int ldx, const T* __restrict__ X0, int ldx0, int errmap, T* __restrict__ dX) {
     constexpr int NB = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sd[];
     T* xa = reinterpret_cast<T*>(smem_sd);
@@ -419,9 +441,10 @@ __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long lo
             const T b0 = qb[0], b1 = -qb[1], b2 = -qb[2], b3 = -qb[3];
             const T w = b0 * a0 - b1 * a1 - b2 * a2 - b3 * a3;                   // same expressions as state_diff_kernel below
             T* oc = o + d.rot_col0[rot];
-            oc[0] = (b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2) / w;
-            oc[1] = (b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1) / w;
-            oc[2] = (b0 * a3 + b1 * a2 - b2 * a1 + b3 * a0) / w;
+            const T v[3] = {b0 * a1 + b1 * a0 + b2 * a3 - b3 * a2, b0 * a2 - b1 * a3 + b2 * a0 + b3 * a1, b0 * a3 + b1 * a2 - b2 * a1 + b3 * a0};
+            T er[3];
+            errmap_apply<T>(errmap, d.rot, w, v, er);
+            oc[0] = er[0]; oc[1] = er[1]; oc[2] = er[2];
         }
     }
     __syncthreads();
@@ -430,22 +453,22 @@ __global__ void __launch_bounds__(128) state_diff_tile_kernel(LieDesc d, long lo
     for (int i = tid; i < total; i += NB) { const int r = i / d.e; dst[i] = out[r * RS + (i - r * d.e)]; }
 }
 
-template <class T> static int sdiff_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX) {
+template <class T> static int sdiff_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, int errmap, void* dX) {
     if (N == 0) return RDHIP_OK;
     const size_t lds = (size_t)128 * (ldx + ldx0 + (d.e | 1)) * sizeof(T);
     if (ldx <= 16 && ldx0 <= 16 && lds <= 64 * 1024) {
-        RD_LAUNCH((state_diff_tile_kernel<T, 16>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        RD_LAUNCH((state_diff_tile_kernel<T, 16>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, errmap, (T*)dX);
         return st(hipGetLastError());
     }
     if (ldx <= 32 && ldx0 <= 32 && lds <= 64 * 1024) {
-        RD_LAUNCH((state_diff_tile_kernel<T, 32>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+        RD_LAUNCH((state_diff_tile_kernel<T, 32>), dim3((unsigned)((N + 127) / 128)), dim3(128), lds, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, errmap, (T*)dX);
         return st(hipGetLastError());
     }
-    RD_LAUNCH((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, (T*)dX);
+    RD_LAUNCH((state_diff_kernel<T>), dim3(nblk(N * d.e)), dim3(256), 0, s, d, N, (const T*)X, ldx, (const T*)X0, ldx0, errmap, (T*)dX);
     return st(hipGetLastError());
 }
-int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, void* dX) {
-    return dtype == RDHIP_F64 ? sdiff_T<double>(d, s, N, X, ldx, X0, ldx0, dX) : sdiff_T<float>(d, s, N, X, ldx, X0, ldx0, dX);
+int launch_state_diff(const LieDesc& d, int dtype, hipStream_t s, long long N, const void* X, int ldx, const void* X0, int ldx0, int errmap, void* dX) {
+    return dtype == RDHIP_F64 ? sdiff_T<double>(d, s, N, X, ldx, X0, ldx0, errmap, dX) : sdiff_T<float>(d, s, N, X, ldx, X0, ldx0, errmap, dX);
 }
 template <class T> static int nabla_T(const LieDesc& d, hipStream_t s, long long N, const void* X, int ldx, const void* Xb, int ldxb, int clear, void* H) {
     if (N == 0) return RDHIP_OK;

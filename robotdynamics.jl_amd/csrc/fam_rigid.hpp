@@ -40,6 +40,9 @@ using QuadFdPlan = TablePlanS<17, 4, 2, 10, /*r*/ 2, 2, 2, /*q*/ 0, 0, 1, 1, /*v
 template <class T, bool B, bool D, bool GZ> struct FdPlanOf<RigidBody<T, WRENCH_SATELLITE, B, D, GZ>> { static constexpr bool value = true; using Plan = SatFdPlan; };
 template <class T, bool B, bool D, bool GZ> struct FdPlanOf<RigidBody<T, WRENCH_QUADROTOR, B, D, GZ>> { static constexpr bool value = true; using Plan = QuadFdPlan; };
 
+// full inertia (DIAG = false; also what a body-frame quadrotor with a gravity vector off the z axis runs on): the lean feature set (dispatch.hpp)
+template <class T, int W, bool B, bool GZ> struct LeanVariant<RigidBody<T, W, B, false, GZ>> { static constexpr bool value = true; };
+
 #define RD_RIGID_VARIANT_DECL(name)                                                                       \
     int name##_errexp(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);                     \
     int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);                   \

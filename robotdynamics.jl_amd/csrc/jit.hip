@@ -653,8 +653,7 @@ int jit_implicit(void* h, int mode, int dtype, const LaunchArgs& a) {
             JitKernel *kr, *ki;
             rc = jit_get(M, JOP_IMPLICIT_IFT, RDHIP_IMPLICIT_MIDPOINT, dtype, &ki); if (rc) return rc;
             int* flag = a.flag;
-            static const char* ift_mode = getenv("RDHIP_IFT");
-            if (tile_flags && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && !(ift_mode && ift_mode[0] == '3')) {
+            if (tile_flags && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && tune_knobs().ift != '3') {
                 // ONE launch (dispatch.hpp launch_implicit, implicit.hpp IftBody): Newton inside the tile kernel, x_next through its f(z) slab, flagged tiles
                 // redone by their own workgroup behind the loop.  IftFun<UserModel<T>> = { UserModel m; double tol; int* flag; int iters; int solve; const T* xn; }
                 std::vector<unsigned char> one(fn);

@@ -725,7 +725,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // counter also beats the static XCD ranges above, which it replaces when the words are there.  sched = {next, done, eight range counters (XR below)}:
     // all zero between launches -- the last workgroup to leave resets them.
     // (fp64 tiles only: the fp32 kernels run two workgroups per CU on half-size tiles -- twice the fetch rate on the one counter word -- and came out 8 %
-    // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_DYNAMIC_TILES=0/1)
+    // SLOWER with it, 181 -> 197 us for 1 M satellite knots, same box, RDHIP_TUNE=dynamic_tiles=0/1)
     // (Tune::DYN_F32, tune/tune_dyn.hip -DTT=float: the counter for fp32 tiles too, Tune::DYN_CHUNK tiles per atomic)
     constexpr bool DYN_OK = SchedOf<BT>::HAS && !GATHER && !WaitsOf<BT>::value && !HELPER && !EpilogueOf<Body>::value && (sizeof(T) == 8 || Tune::DYN_F32);
     constexpr int RD_DYN_CHUNK = Tune::DYN_CHUNK;

@@ -89,6 +89,18 @@ function last_kernel_name()
     return GC.@preserve buf unsafe_string(pointer(buf))
 end
 
+"""
+    tune(pairs::AbstractString)
+
+Merge `"key=value,..."` into the dispatcher's tuning knobs (`rdhip_tune`; `"reset"`: back to what the environment variable `RDHIP_TUNE` says).
+For tests and tuning scripts: no knob changes a result; `include/rdhip.h` lists the keys.
+"""
+function tune(pairs::AbstractString)
+    rc = ccall((:rdhip_tune, librdhip), Cint, (Cstring,), pairs)
+    rc == 0 || throw(RdhipError(rc, last_error(C_NULL)))
+    return nothing
+end
+
 const _default_ctx = Ref{Union{Nothing,Context}}(nothing)
 function default_context()
     if _default_ctx[] === nothing
@@ -920,32 +932,43 @@ function RobotDynamics.errstate_jacobian!(fun::RD.AbstractModel, G::Dense{T,3}, 
     check(c, rc)
 end
 
-# state_diff!(model, dx[:,k], x[:,k], x0[:,k]) for all k, default CayleyMap (src/statevectortype.jl:102-104,145-146; src/liestate.jl:210-260)
-function RobotDynamics.state_diff!(fun::RD.AbstractModel, dX::Dense{T,2}, X::Dense{T,2}, X0::Dense{T,2}; ctx::Union{Nothing,Context}=nothing) where {T}
+# the `errmap` argument of state_diff (src/liestate.jl:26-32): Rotations.jl's ErrorMap singletons -> rdhip_errmap codes (include/rdhip.h)
+errmapcode(::Rotations.CayleyMap) = Cint(0)
+errmapcode(::Rotations.ExponentialMap) = Cint(1)
+errmapcode(::Rotations.MRPMap) = Cint(2)
+errmapcode(::Rotations.QuatVecMap) = Cint(3)
+errmapcode(::Rotations.IdentityMap) = Cint(4)      # three-parameter rotations only: RDHIP_ERR_UNSUPPORTED for QuatRotation states, where the reference throws as well
+
+# state_diff!(model, dx[:,k], x[:,k], x0[:,k][, errmap]) for all k, default CayleyMap (src/statevectortype.jl:102-104,145-146; src/liestate.jl:26-32,210-260)
+function RobotDynamics.state_diff!(fun::RD.AbstractModel, dX::Dense{T,2}, X::Dense{T,2}, X0::Dense{T,2}, errmap::Rotations.ErrorMap=Rotations.CayleyMap();
+                                   ctx::Union{Nothing,Context}=nothing) where {T}
     n, e, N = RD.state_dim(fun), RD.errstate_dim(fun), size(X, 2)
     (size(X, 1) == n && size(X0) == size(X)) || throw(DimensionMismatch("X, X0 must be n x N"))
     size(dX) == (e, N) || throw(DimensionMismatch("dX must be e x N"))
     sp, found = _where(X, X0, dX)
     c = _ctx(ctx, found)
     GC.@preserve dX X X0 begin
-        rc = ccall((:rdhip_state_diff, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                   c.ptr, handle(fun), dtypecode(T), N, _p(X), n, _p(X0), n, _p(dX), sp)
+        rc = ccall((:rdhip_state_diff_map, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint),
+                   c.ptr, handle(fun), dtypecode(T), N, _p(X), n, _p(X0), n, errmapcode(errmap), _p(dX), sp)
     end
     check(c, rc)
 end
-RobotDynamics.state_diff(fun::RD.AbstractModel, X::Matrix{T}, X0::Matrix{T}; kw...) where {T} =
-    (dX = Matrix{T}(undef, RD.errstate_dim(fun), size(X, 2)); RD.state_diff!(fun, dX, X, X0; kw...); dX)
-# state_diff!(model, dX, Z, Z0): states taken out of two packed trajectories (leading dimension n+m)
-function RobotDynamics.state_diff!(fun::RD.AbstractModel, dX::Dense{T,2}, Z::AbstractPackedTrajectory{n,m,T}, Z0::AbstractPackedTrajectory{n,m,T};
-                                   ctx::Union{Nothing,Context}=nothing) where {n,m,T}
+RobotDynamics.state_diff(fun::RD.AbstractModel, X::Matrix{T}, X0::Matrix{T}, errmap::Rotations.ErrorMap=Rotations.CayleyMap(); kw...) where {T} =
+    (dX = Matrix{T}(undef, RD.errstate_dim(fun), size(X, 2)); RD.state_diff!(fun, dX, X, X0, errmap; kw...); dX)
+# state_diff!(model, dX, Z, Z0): states taken out of two packed trajectories (leading dimension n+m); the default CayleyMap through the plain entry point
+function RobotDynamics.state_diff!(fun::RD.AbstractModel, dX::Dense{T,2}, Z::AbstractPackedTrajectory{n,m,T}, Z0::AbstractPackedTrajectory{n,m,T},
+                                   errmap::Rotations.ErrorMap=Rotations.CayleyMap(); ctx::Union{Nothing,Context}=nothing) where {n,m,T}
     N = length(Z)
     length(Z0) == N || throw(DimensionMismatch("the two trajectories differ in length"))
     size(dX) == (RD.errstate_dim(fun), N) || throw(DimensionMismatch("dX must be e x N"))
     sp, found = _where(Z.data, Z0.data, dX)
     c = _ctx(ctx, found)
     GC.@preserve dX Z Z0 begin
-        rc = ccall((:rdhip_state_diff, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
-                   c.ptr, handle(fun), dtypecode(T), N, _p(Z.data), n + m, _p(Z0.data), n + m, _p(dX), sp)
+        rc = errmap isa Rotations.CayleyMap ?
+            ccall((:rdhip_state_diff, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint),
+                  c.ptr, handle(fun), dtypecode(T), N, _p(Z.data), n + m, _p(Z0.data), n + m, _p(dX), sp) :
+            ccall((:rdhip_state_diff_map, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Clonglong, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint),
+                  c.ptr, handle(fun), dtypecode(T), N, _p(Z.data), n + m, _p(Z0.data), n + m, errmapcode(errmap), _p(dX), sp)
     end
     check(c, rc)
 end

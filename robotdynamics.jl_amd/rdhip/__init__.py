@@ -7,7 +7,7 @@
     J = RD.alloc_jacobians(dmodel, len(Z), data); Y = ...
     RD.jacobian_(RD.StaticReturn(), RD.ForwardAD(), dmodel, J, Y, Z)   # jacobian!(sig, diff, model, J, y, z) for all k
 """
-from ._lib import Context, NoDeviceError, RdhipError, device_count, last_kernel_name, lib, LIB_PATH, HEADER_PATH, EXPORTS  # noqa: F401
+from ._lib import Context, NoDeviceError, RdhipError, device_count, last_kernel_name, lib, tune, LIB_PATH, HEADER_PATH, EXPORTS  # noqa: F401
 from .core import *  # noqa: F401,F403
 from .core import _gettimeinfo  # noqa: F401
 from . import parallel  # noqa: F401

@@ -17,6 +17,7 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_NO_DEVIC
 MODEL_CARTPOLE, MODEL_DOUBLE_INTEGRATOR, MODEL_LINEAR, MODEL_SATELLITE, MODEL_QUADROTOR, MODEL_SATELLITE_PAIR, MODEL_LIE_SATELLITE, MODEL_CUSTOM = range(8)
 ROT_QUAT, ROT_MRP, ROT_RP = range(3)
 FRAME_WORLD, FRAME_BODY = range(2)
+ERRMAP_CAYLEY, ERRMAP_EXPONENTIAL, ERRMAP_MRP, ERRMAP_QUATVEC, ERRMAP_IDENTITY = range(5)
 CONTINUOUS, EULER, RK2, RK3, RK4, IMPLICIT_MIDPOINT, DISCRETE = -1, 0, 1, 2, 3, 4, 5
 FORWARD_AD, FINITE_DIFF, USER_DEFINED = range(3)
 F64, F32 = range(2)
@@ -85,7 +86,9 @@ _SIGS = {
     "rdhip_dynamics_error_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_error_expansion": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "rdhip_tune": (C.c_int, [C.c_char_p]),
     "rdhip_state_diff": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
+    "rdhip_state_diff_map": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rdhip_nabla_errstate_jacobian": (C.c_int, [_P, _P, C.c_int, _LL, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rdhip_graph_begin_capture": (C.c_int, [_P]),
     "rdhip_graph_end_capture": (C.c_int, [_P, C.POINTER(_P)]),
@@ -157,6 +160,11 @@ def last_kernel_name():
     buf = C.create_string_buffer(1024)
     check(lib().rdhip_last_kernel_name(buf, 1024))
     return buf.value.decode()
+
+
+def tune(pairs):
+    """rdhip_tune: merge "key=value,..." into the dispatcher's tuning knobs ("reset": back to RDHIP_TUNE's); include/rdhip.h lists the keys."""
+    check(lib().rdhip_tune(pairs.encode() if isinstance(pairs, str) else pairs))
 
 
 def device_count():

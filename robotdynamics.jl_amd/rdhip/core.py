@@ -1802,25 +1802,60 @@ def state_diff_jacobian_(G, model, z):
     return errstate_jacobian_(model, G, z)
 
 
-def state_diff(model, x, x0):
-    """state_diff(model, x, x0) with the default CayleyMap: src/statevectortype.jl:104, src/liestate.jl:26-28."""
+class ErrorMap(_Trait):
+    """Rotations.ErrorMap (third party): the optional last argument of state_diff (src/liestate.jl:26-32)."""
+
+
+class CayleyMap(ErrorMap):           # the reference's default (src/liestate.jl:27,31): v / w
+    code = L.ERRMAP_CAYLEY
+
+
+class ExponentialMap(ErrorMap):      # 0.5 logm(dq): half the rotation vector
+    code = L.ERRMAP_EXPONENTIAL
+
+
+class MRPMap(ErrorMap):              # 2 v / (1 + w)
+    code = L.ERRMAP_MRP
+
+
+class QuatVecMap(ErrorMap):          # sign(w) v
+    code = L.ERRMAP_QUATVEC
+
+
+class IdentityMap(ErrorMap):         # params(R0 \ R); three-parameter rotations only (a quaternion has four: the reference throws)
+    code = L.ERRMAP_IDENTITY
+
+
+def _errmap_code(errmap):
+    if errmap is None:
+        return L.ERRMAP_CAYLEY
+    if isinstance(errmap, type) and issubclass(errmap, ErrorMap):
+        errmap = errmap()
+    if not isinstance(errmap, ErrorMap) or not hasattr(errmap, "code"):
+        raise TypeError("errmap must be one of CayleyMap, ExponentialMap, MRPMap, QuatVecMap, IdentityMap")
+    return errmap.code
+
+
+def state_diff(model, x, x0, errmap=None):
+    """state_diff(model, x, x0[, errmap]): src/statevectortype.jl:104, src/liestate.jl:26-28 (default CayleyMap())."""
     X, ldx, N, single = _states_of(model, x)
     X0, ldx0, N0, _ = _states_of(model, x0)
     if N != N0:
         raise ValueError("x and x0 hold different numbers of states")
     dx = _empty_like_data(X, (N, errstate_dim(model)))
-    state_diff_(model, dx, X, X0)
+    state_diff_(model, dx, X, X0, errmap)
     return dx[0] if single else dx
 
 
-def state_diff_(model, dx, x, x0):
-    """state_diff!(model, dx, x, x0): src/statevectortype.jl:102."""
+def state_diff_(model, dx, x, x0, errmap=None):
+    """state_diff!(model, dx, x, x0[, errmap]): src/statevectortype.jl:102, src/liestate.jl:30-32."""
+    code = _errmap_code(errmap)
     X, ldx, N, single = _states_of(model, x)
     X0, ldx0, _, _ = _states_of(model, x0)
     e = errstate_dim(model)
     if single and not (hasattr(dx, "ndim") and dx.ndim == 2):
         tmp = np.empty((1, e), dtype=X.dtype)
-        state_diff_(model, tmp, X, X0)
+        state_diff_(model, tmp, X, X0, errmap)
         dx[...] = tmp[0]
         return None
     _dense(dx, (N, e), "dx")
@@ -1829,7 +1864,7 @@ def state_diff_(model, dx, x, x0):
     if a0.dtype != ax.dtype:
         raise ValueError("x and x0 have different dtypes")
     ctx, space = _resolve_ctx([ax, a0, ad])
-    L.check(L.lib().rdhip_state_diff(ctx.handle, _cm(model)._handle, ax.dtype, N, ax.ptr, ldx, a0.ptr, ldx0, ad.ptr, space), ctx.handle)
+    L.check(L.lib().rdhip_state_diff_map(ctx.handle, _cm(model)._handle, ax.dtype, N, ax.ptr, ldx, a0.ptr, ldx0, code, ad.ptr, space), ctx.handle)
     return None
 
 

@@ -59,6 +59,11 @@ def oracle_model(name, d):
     return O.Model(kind, params, frame=frame, rot=int(d["rot"]) if "rot" in d else O.ROT_QUAT)      # rot: RigidBody{MRP|RodriguesParam} fixtures (make_golden_rot3.py)
 
 
+def errmap_oracle_model(d):
+    """the oracle's bare LieState for an errmap_* fixture (tests/golden/make_golden_round6.py)"""
+    return O.lie_state(int(d["rot"]), [int(v) for v in d["P"]])
+
+
 def three_parameter(name):
     """dyn_* fixtures of RigidBody{MRP} / RigidBody{RodriguesParam} (no user-defined Jacobian in the reference: src/rigidbody.jl:260)"""
     return "_mrp_" in name or "_rp_" in name

@@ -188,13 +188,9 @@ def test_fused_rollout_jacobians_when_tiles_share_cache_lines(shape):
     ref = om.rollout(O.RK4, data, t, dt)
     Jref = om.jacobian(O.RK4, O.FORWARD_AD, ref.reshape(M * K, -1), t.reshape(-1), dt.reshape(-1))[0].reshape(M, K, 13, 19)
     mk = (lambda: _tm_stack(data, t, dt, lambda a: a)) if tm else (lambda: {"data": torch.as_tensor(data).cuda(), "t": torch.as_tensor(t).cuda(), "dt": torch.as_tensor(dt).cuda()})
-    old = os.environ.get("RDHIP_FUSED_JAC_WORKGROUPS")
     try:
-        for nj in ("3", "16", None):
-            if nj is None:
-                os.environ.pop("RDHIP_FUSED_JAC_WORKGROUPS", None)
-            else:
-                os.environ["RDHIP_FUSED_JAC_WORKGROUPS"] = nj
+        for nj in ("3", "16", "0"):                                    # rdhip_tune: the dispatcher's knobs at run time (include/rdhip.h); 0 = every CU the rollout leaves
+            RD.tune("fused_jac_workgroups=" + nj)
             for rep in range(3):
                 st = mk()
                 J = RD.alloc_jacobians(dm, M * K, st["data"]).fill_(-5.0)
@@ -207,10 +203,7 @@ def test_fused_rollout_jacobians_when_tiles_share_cache_lines(shape):
                 np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
                 np.testing.assert_allclose(Jg, Jref, rtol=0, atol=TOL * max(1.0, np.abs(Jref).max()))
     finally:
-        if old is None:
-            os.environ.pop("RDHIP_FUSED_JAC_WORKGROUPS", None)
-        else:
-            os.environ["RDHIP_FUSED_JAC_WORKGROUPS"] = old
+        RD.tune("reset")
 
 
 def test_two_fused_launches_from_two_contexts_do_not_hang():

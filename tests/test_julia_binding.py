@@ -88,7 +88,7 @@ def test_every_batched_operator_has_a_device_path():
     entry point must be computed from the arrays (`sp`), i.e. DeviceArray arguments run in place on the GPU."""
     calls = jl_ccalls()
     compute = ["rdhip_dynamics", "rdhip_discrete_dynamics", "rdhip_jacobian", "rdhip_jacobian_multi", "rdhip_dynamics_error", "rdhip_dynamics_error_jacobian",
-               "rdhip_error_expansion", "rdhip_errstate_jacobian", "rdhip_state_diff", "rdhip_nabla_errstate_jacobian", "rdhip_rollout", "rdhip_rollout_layout", "rdhip_rollout_jacobian",
+               "rdhip_error_expansion", "rdhip_errstate_jacobian", "rdhip_state_diff", "rdhip_state_diff_map", "rdhip_nabla_errstate_jacobian", "rdhip_rollout", "rdhip_rollout_layout", "rdhip_rollout_jacobian",
                "rdhip_rollout_jacobian_multi"]
     for name in compute:
         for _, _, tail in calls[name]:
@@ -96,6 +96,9 @@ def test_every_batched_operator_has_a_device_path():
             assert re.search(r",\s*sp\)", call_args), f"{name}: memspace is not derived from the arguments"
             assert "HOST)" not in call_args, f"{name}: hard-wired RDHIP_HOST"
     txt = open(JL).read()
+    for needle in ("errmapcode(::Rotations.CayleyMap)", "errmapcode(::Rotations.ExponentialMap)", "errmapcode(::Rotations.MRPMap)", "errmapcode(::Rotations.QuatVecMap)",
+                   "errmapcode(::Rotations.IdentityMap)", "errmap::Rotations.ErrorMap=Rotations.CayleyMap()"):      # state_diff's optional error map (src/liestate.jl:26-32)
+        assert needle in txt, needle
     for needle in ("mutable struct DeviceArray", "struct DeviceTrajectory", "rdhip_malloc", "rdhip_memcpy_h2d", "rdhip_memcpy_d2h", "rdhip_graph_launch"):
         assert needle in txt
 

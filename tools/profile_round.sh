@@ -13,6 +13,6 @@ python tools/host_overhead.py > $out/host_overhead.txt 2>&1
 python tools/two_stream_bench.py 65536 1000 > $out/multi_stream.jsonl 2>/dev/null
 tools/abi_bench robotdynamics.jl_amd/lib/librdhip.so > $out/abi_bench.txt 2>&1
 python tools/ift_probe.py 1,4 300 2>/dev/null | grep ift > $out/ift_probe.jsonl
-python tools/small_probe.py 2>/dev/null > $out/small_batches.jsonl; RDHIP_SMALL=tile python tools/small_probe.py 2>/dev/null >> $out/small_batches.jsonl
+python tools/small_probe.py 2>/dev/null > $out/small_batches.jsonl; RDHIP_TUNE=small=tile python tools/small_probe.py 2>/dev/null >> $out/small_batches.jsonl
 tail -5 gpurun_out/$tag.log | cut -c1-300
 wc -l $out/configs.jsonl; cat $out/abi_bench.txt

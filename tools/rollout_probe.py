@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/rollout_probe.py -- rollout kernel timing over batch shapes (trajectories x knots) and dtypes: microseconds per launch and per step.
-RDHIP_ROLLOUT=plain selects the one-lane-per-trajectory kernel for rigid bodies (default: the cascade kernel)."""
+RDHIP_TUNE=rollout=plain selects the one-lane-per-trajectory kernel for rigid bodies (default: the cascade kernel)."""
 import json
 import os
 import sys
@@ -28,6 +28,6 @@ for model, name, m in ((sat, "satellite", 6), (quad, "quadrotor", 4)):
             fun = RD.DiscretizedDynamics(model, RD.RK4)
             us = timed(lambda i: RD.rollout_(RD.StaticReturn(), fun, {"data": data, "t": t, "dt": dt}), 10, warm=2)
             print(json.dumps({"model": name, "dtype": "f64" if dtype == np.float64 else "f32", "trajectories": M, "knots": K,
-                              "us_per_launch": round(us, 2), "us_per_step": round(us / (K - 1), 4), "mode": os.environ.get("RDHIP_ROLLOUT", "cascade")}), flush=True)
+                              "us_per_launch": round(us, 2), "us_per_step": round(us / (K - 1), 4), "mode": os.environ.get("RDHIP_TUNE", "rollout=cascade")}), flush=True)
     if "--all" not in sys.argv:
         break

@@ -1,5 +1,5 @@
 """Single small batches (one trajectory of 101 .. 8 192 knot points): the column-split kernel (default below 4 tiles per CU) against the tile loop
-(RDHIP_SMALL=tile), satellite / quadrotor RK4 ForwardAD Jacobian + x_next, bare C calls, outputs rotated."""
+(RDHIP_TUNE=small=tile), satellite / quadrotor RK4 ForwardAD Jacobian + x_next, bare C calls, outputs rotated."""
 import os, sys, json
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "robotdynamics.jl_amd"), os.path.join(R
 import rdhip as RD
 import bench_configs as BC
 rng = np.random.default_rng(2)
-tag = os.environ.get("RDHIP_SMALL", "colsplit") + os.environ.get("RDHIP_SMALL_MAX", "")
+tag = os.environ.get("RDHIP_TUNE", "colsplit")
 def emit(name, N, dt, us, alg, extra=None): print(json.dumps({"mode": tag, "name": name, "N": N, "us": round(us, 2), "frac": round(alg / us / 1e6 / 8, 3)}), flush=True)
 BC.emit = emit
 sat, quad = RD.Satellite(), RD.Quadrotor()

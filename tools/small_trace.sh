@@ -1,10 +1,10 @@
-# rocprofv3 kernel durations of single small batches: column-split kernel (RDHIP_SMALL_MAX = workgroups per CU up to which it is used) vs tile loop
+# rocprofv3 kernel durations of single small batches: column-split kernel (RDHIP_TUNE small_max = workgroups per CU up to which it is used) vs tile loop
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for m in "colsplit 1" "colsplit 2" "colsplit 4" "tile 1"; do
 set -- $m
 out=/tmp/small_$1_$2; mkdir -p $out
-(cd /tmp && RDHIP_SMALL=$1 RDHIP_SMALL_MAX=$2 rocprofv3 --kernel-trace --output-format csv -d $out -o x -- python $R/tools/small_probe.py > /dev/null 2>&1)
+(cd /tmp && RDHIP_TUNE="small=$1,small_max=$2" rocprofv3 --kernel-trace --output-format csv -d $out -o x -- python $R/tools/small_probe.py > /dev/null 2>&1)
 python - $out/x_kernel_trace.csv "$1$2" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
