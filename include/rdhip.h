@@ -11,8 +11,10 @@
  *   - packed trajectory ("PackedTrajectory"): Z is (n+m) x N column-major, knot point k occupies
  *     Z[k*(n+m) .. k*(n+m)+n+m), z = [x;u] exactly as KnotPoint.z (src/knotpoint.jl:146-153);
  *     t[N], dt[N] are ALWAYS fp64 (KnotPoint.t/.dt are Float64, src/knotpoint.jl:150-151).
- *   - terminal knot point: dt[k] == 0  =>  control reads as zeros (src/knotpoint.jl:67,123), and the
- *     control columns of any Jacobian are zero.
+ *   - terminal knot point: dt[k] == 0  =>  control reads as zeros (src/knotpoint.jl:67,123), and the control columns of a ForwardAD /
+ *     FiniteDifference Jacobian and of every discrete rule's Jacobian are zero (they differentiate through `!is_terminal(z) * u`, or carry a factor
+ *     dt).  RDHIP_USER_DEFINED with RDHIP_CONTINUOUS (or a custom model's own Jacobian body) hands back d f / d u at u = 0 as the reference does:
+ *     jacobian!(fun, J, y, state(z), control(z)), src/functionbase.jl:252-257.
  *   - Jacobians: J is n x (n+m) x N, each n x (n+m) slab column-major = the storage of
  *     DynamicsJacobian (src/jacobian.jl:26-37): A = J[:, 0:n], B = J[:, n:n+m].
  *   - dtype selects the arithmetic and storage type of Z / outputs (RDHIP_F64 or RDHIP_F32).
@@ -109,6 +111,7 @@ void* rdhip_ctx_stream(rdhip_ctx* ctx);
  *   rollout=plain|cascade|stream   force a rollout kernel where it applies
  *   rolljac=split            rdhip_rollout_jacobian always as two launches
  *   fused_ratio=x, fused_jac_workgroups=N, fused_tj_max_knots=N, rolljac_pipe_min_knots=N, multi_main=i     shape of the one-launch rollout -> Jacobians forms
+ *   mixed=0, mixed_idle=0|1  rdhip_rollout_jacobian_multi: never the one-launch form of a (satellite, cartpole) pair / where the cartpole's rollout runs in it
  *   ift=reg|3                ImplicitMidpoint Jacobians: the one-kernel register path / the three-launch path of round 2
  * Not tuning, and still their own environment variables: RDHIP_DRY_RUN (contexts without a device: queries only), RDHIP_VERBOSE (reports fall-backs on
  * stderr), RDHIP_CACHE_DIR (hipRTC code-object cache of custom models), RDHIP_RCCL_LIB / RDHIP_COMM_FORCE_RCCL (communicator). */
@@ -377,6 +380,15 @@ int rdhip_model_wrench_sparsity(const rdhip_model* model, int js[10]);
 #define RDHIP_TRAJECTORY_MAJOR 0   /* knot k of trajectory j at index j*K + k: M consecutive trajectories, what rdhip_rollout takes */
 #define RDHIP_TIME_MAJOR 1         /* knot k of trajectory j at index k*M + j: knot k of all trajectories contiguous */
 
+/* rollout! on SPLIT arrays -- states and controls in arrays of their own (what `states(Z)` / `controls(Z)` give, src/trajectories.jl; SURVEY 8b's
+ * rdhip_rollout(x0, U, ... -> X)): X n x K x M receives every simulated state (knot 0 = X0[:, j], or what X holds there when X0 is NULL), U m x (K-1) x M is
+ * read; t, dt: K x M as for rdhip_rollout_layout (dt of a trajectory's last knot is not used).  layout RDHIP_TRAJECTORY_MAJOR: state k of trajectory j at
+ * X + (j K + k) n, control k at U + (j (K-1) + k) m; RDHIP_TIME_MAJOR: X + (k M + j) n, U + (k M + j) m.  Same arithmetic as rdhip_rollout.
+ * Why it exists: a packed stack interleaves x and u, and an in-place rollout that writes whole lines has to write the controls back with the states --
+ * rdhip_rollout's streaming kernel moves 1.93 x the algorithmic bytes of a big batch (32 768 x 32 fp64 satellite knots); here U, t, dt are read once and X
+ * is written once (168 instead of 320 bytes per satellite knot point).  Explicit rules, compiled-in models; no alignment requirement.  src/trajectories.jl:436-441. */
+int rdhip_rollout_split(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M, int layout,
+                        void* X, const void* U, const double* t, const double* dt, const void* X0, int memspace);
 /* rdhip_rollout for either layout of the stack (rdhip_rollout = RDHIP_TRAJECTORY_MAJOR, the reference's "vector of trajectories").  Big batches
  * of models whose knot point is at least 128 bytes (the fp64 rigid bodies) -- from two 64-trajectory groups per compute unit on, 32 768 trajectories on an MI355X -- are streamed through LDS in chunks of knot points as
  * whole 16-byte units (csrc/rollout_stream.hpp; every run of the stack must start on a 16-byte boundary: Z 16-byte aligned and K (n+m) sizeof(T)

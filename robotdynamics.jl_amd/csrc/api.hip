@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -153,6 +154,8 @@ static int parse_tune(rd::TuneKnobs& k, const char* s, std::string* bad) {
         else if (key == "rolljac_pipe_min_knots") k.rolljac_pipe_min_knots = iv;
         else if (key == "multi_main") k.multi_main = val.empty() ? -1 : (int)iv;
         else if (key == "ift") k.ift = val.empty() ? 0 : val[0];
+        else if (key == "mixed") k.mixed = !(val == "0");
+        else if (key == "mixed_idle") k.mixed_idle = val.empty() ? -1 : (int)iv;
         else { if (bad) *bad = key; return RDHIP_ERR_INVALID_ARG; }
     }
     return RDHIP_OK;
@@ -664,19 +667,22 @@ static std::mutex g_fused_mu;
 static hipEvent_t g_fused_done[64] = {};
 static hipStream_t g_fused_stream[64] = {};
 static unsigned long long g_fused_serial[64] = {};
-static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& f, bool capturing) {
+static int spin_launch(rdhip_ctx* c, hipStream_t stream, bool capturing, const std::function<int()>& launch) {
     std::lock_guard<std::mutex> g(g_fused_mu);
     const int slot = c->device & 63;
-    if (!capturing && g_fused_serial[slot] && !(g_fused_serial[slot] == c->serial && g_fused_stream[slot] == f.stream)) {
-        if (hipStreamWaitEvent(f.stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
+    if (!capturing && g_fused_serial[slot] && !(g_fused_serial[slot] == c->serial && g_fused_stream[slot] == stream)) {
+        if (hipStreamWaitEvent(stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
     }
-    const int k = family_rolljac(d, rule, diff, dtype, f);
+    const int k = launch();
     if (k == RDHIP_OK && !capturing) {
         if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
-        if (hipEventRecord(g_fused_done[slot], f.stream) != hipSuccess) return RDHIP_ERR_HIP;
-        g_fused_stream[slot] = f.stream; g_fused_serial[slot] = c->serial;
+        if (hipEventRecord(g_fused_done[slot], stream) != hipSuccess) return RDHIP_ERR_HIP;
+        g_fused_stream[slot] = stream; g_fused_serial[slot] = c->serial;
     }
     return k;
+}
+static int fused_launch(rdhip_ctx* c, const ModelDesc& d, int rule, int diff, int dtype, const LaunchArgs& f, bool capturing) {
+    return spin_launch(c, f.stream, capturing, [&] { return family_rolljac(d, rule, diff, dtype, f); });
 }
 
 static int family_implicit(rdhip_ctx* c, const ModelDesc& d, int mode, int dtype, LaunchArgs a, int flag_set = 0) {
@@ -1154,6 +1160,35 @@ int rdhip_rollout_layout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype
     if (s.rc) return s.rc;
     return s.finish(kernel_status(c, implicit ? family_implicit(c, d, 3, dtype, a) : family_rollout(d, rule, dtype, a), what));
 }
+// rollout! on split arrays (rollout_split.hpp): the controls are read once, the states written once, in whole lines
+int rdhip_rollout_split(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, int layout, void* X, const void* U,
+                        const double* t, const double* dt, const void* X0, int memspace) {
+    const char* what = "rdhip_rollout_split";
+    int rc = check_common(c, M, dtype, Mt, memspace); if (rc) return rc;
+    if (K < 0) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: negative K", what);
+    rc = rule_ok(c, M, rule, RDHIP_EULER, RDHIP_IMPLICIT_MIDPOINT, what); if (rc) return rc;
+    if (layout != RDHIP_TRAJECTORY_MAJOR && layout != RDHIP_TIME_MAJOR) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: bad layout %d", what, layout);
+    if (rule == RDHIP_IMPLICIT_MIDPOINT) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: explicit rules only (an implicit rollout is a latency chain of Newton solves: rdhip_rollout)", what);
+    if (M->d.kind == RDHIP_MODEL_CUSTOM) return fail(c, RDHIP_ERR_UNSUPPORTED, "%s: compiled-in models only (custom models: rdhip_rollout)", what);
+    if (K * Mt == 0) return RDHIP_OK;
+    if (!X || !t || !dt || (K > 1 && !U)) return fail(c, RDHIP_ERR_INVALID_ARG, "%s: NULL data pointer", what);
+    rc = check_rotation(c, M, 0); if (rc) return rc;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4; const ModelDesc& d = M->d;
+    const size_t xb = (size_t)K * Mt * d.n * ts, ub = (size_t)(K - 1) * Mt * d.m * ts;
+    LaunchArgs a{}; a.stream = c->stream; a.N = Mt; a.K = K; a.time_major = layout == RDHIP_TIME_MAJOR;
+    Stage s(c);
+    a.Z = X; a.U = U; a.t = t; a.dt = dt; a.X0 = X0;
+    if (memspace == RDHIP_HOST) {
+        a.Z = s.out(X, xb, /*preload=*/X0 == nullptr); a.U = s.in(U, ub); a.t = (const double*)s.in(t, (size_t)K * Mt * 8); a.dt = (const double*)s.in(dt, (size_t)K * Mt * 8);
+        a.X0 = s.in(X0, (size_t)Mt * d.n * ts);
+        if (s.rc) return s.rc;
+    }
+    int k = RDHIP_OK;
+    if (K == 1) {                                                      // nothing to simulate: knot 0 is the initial state (both layouts hold it at the same place)
+        if (a.X0 && hipMemcpyAsync(const_cast<void*>(a.Z), a.X0, (size_t)Mt * d.n * ts, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) k = fail(c, RDHIP_ERR_HIP, "%s: copying the initial states failed", what);
+    } else k = kernel_status(c, family_rollout(d, rule, dtype, a), what);
+    return memspace == RDHIP_HOST ? s.finish(k) : k;
+}
 int rdhip_rollout(rdhip_ctx* c, const rdhip_model* M, int rule, int dtype, long long K, long long Mt, void* Z, const double* t, const double* dt,
                   const void* X0, int memspace) {
     return rdhip_rollout_layout(c, M, rule, dtype, K, Mt, RDHIP_TRAJECTORY_MAJOR, Z, t, dt, X0, memspace);
@@ -1282,6 +1317,30 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         return RDHIP_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    // ONE launch for the pair the one-launch form exists for (mixed.hpp: a satellite-type rigid body + the cartpole under one rule, time-major stacks,
+    // ForwardAD): both rollouts and both models' Jacobians in one grid on the context's stream -- no fork, no join, no second stream
+    if (nmodels == 2 && layout == RDHIP_TIME_MAJOR && diff == RDHIP_FORWARD_AD && tune_knobs().mixed && c->allow_fused) {
+        for (int pa = 0; pa < 2; ++pa) {
+            const int pb = 1 - pa;
+            bool ok = true;
+            for (int p = 0; p < 2; ++p) ok = ok && Z[p] && t[p] && dt[p] && J[p] && K[p] > 0 && Mt[p] > 0;
+            if (!ok) break;
+            LaunchArgs a{}, b{};
+            a.stream = c->stream; a.N = Mt[pa]; a.K = K[pa]; a.Z = Z[pa]; a.t = t[pa]; a.dt = dt[pa]; a.X0 = X0 ? X0[pa] : nullptr; a.J = J[pa]; a.time_major = 1;
+            b.stream = c->stream; b.N = Mt[pb]; b.K = K[pb]; b.Z = Z[pb]; b.t = t[pb]; b.dt = dt[pb]; b.X0 = X0 ? X0[pb] : nullptr; b.J = J[pb]; b.time_major = 1;
+            a.progress = c->d_progress; a.progress_words = PROGRESS_WORDS; a.probe = 1;
+            if (fam_mixed_rolljac(models[pa]->d, rule[pa], models[pb]->d, rule[pb], diff, dtype, a, b) != RDHIP_OK) continue;
+            if (dtype != RDHIP_F64 && dtype != RDHIP_F32) break;
+            if (c->side_pending) { const int rc = side_join(c); if (rc) return rc; }       // (ORDERING RULE of rdhip.h: behind whatever the overlap mode left on the internal stream)
+            c->multi_sig = 0;
+            a.probe = 0;
+            c->roll_epoch = (c->roll_epoch + 1) & 0x7fffffffULL; if (c->roll_epoch == 0) c->roll_epoch = 1;
+            a.pbase = c->roll_epoch << 32;
+            const int k = spin_launch(c, c->stream, false, [&] { return fam_mixed_rolljac(models[pa]->d, rule[pa], models[pb]->d, rule[pb], diff, dtype, a, b); });
+            c->last_rolljac_launches = 1;
+            return kernel_status(c, k, what);
+        }
+    }
     // Overlap mode (contexts that own their stream, rdhip_ctx_set_overlap), two models: the second model runs on the context's INTERNAL stream and the
     // call neither waits for it at its end -- the next operation of any other kind does (side_join: the ORDERING RULE of rdhip.h) -- nor forks when it
     // REPEATS the previous call argument for argument (a solver's loop: every stream re-issues its own kernels on its own arrays, in order).  The

@@ -78,6 +78,8 @@ struct TuneKnobs {
     long long fused_tj_max_knots = 262144;      // trajectory-major stacks from this many knot points on take two launches
     long long rolljac_pipe_min_knots = 262144;  // time-major stacks of models without the fused launch are pipelined in pieces from this size on (0: never)
     int multi_main = -1;                  // rdhip_rollout_jacobian_multi: the model that gets the fused launch (-1: the one with most Jacobian bytes)
+    int mixed_idle = -1;                  // mixed_idle=0/1: the small model's rollout on workgroups of its own / on the idle waves of the other model's rollout workgroups (-1: by size)
+    bool mixed = true;                    // mixed=0: rdhip_rollout_jacobian_multi never takes the one-launch form of a (satellite, cartpole) pair (mixed.hpp)
     char ift = 0;                         // ift=reg: the one-kernel register path; ift=3: Newton kernel + tile kernel + gated exact kernel (round 2)
 };
 TuneKnobs& tune_knobs_mut();              // api.hip
@@ -189,6 +191,7 @@ struct LaunchArgs {
     void* J;
     void* Y;            // eval: output; jacobian: optional f(z)
     const void* X0;     // rollout
+    const void* U;      // rollout on split arrays (rollout_split.hpp): controls m x (K-1) x M; Z then holds the states X n x K x M.  NULL: a packed stack
     void* J2;           // implicit dynamics_error_jacobian: d e / d z2 (J holds d e / d z1)
     int newton_iters;   // implicit rules
     double newton_tol;
@@ -214,6 +217,8 @@ struct LaunchArgs {
     int name##_rollout(const ModelDesc& md, int rule, int dtype, const LaunchArgs& a);       \
     int name##_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a);   /* mode 0: x_next, 1: x_next + IFT Jacobian, 2: dynamics error (+ Jacobians) of the pairs, 3: rollout */ \
     int name##_rolljac(const ModelDesc& md, int rule, int diff, int dtype, const LaunchArgs& a);   /* rollout + Jacobians in one launch (fused.hpp) or RDHIP_ERR_UNSUPPORTED before anything is launched */
+// the mixed-model batch as one launch (fam_mixed.hip, mixed.hpp): model A (args a) with the one-launch rollout -> Jacobians form + small model B (args b)
+int fam_mixed_rolljac(const ModelDesc& da, int rule_a, const ModelDesc& db, int rule_b, int diff, int dtype, const LaunchArgs& a, const LaunchArgs& b);
 RD_DECLARE_FAMILY(fam_cartpole)
 RD_DECLARE_FAMILY(fam_simple)      // double integrator, linear
 RD_DECLARE_FAMILY(fam_satellite)

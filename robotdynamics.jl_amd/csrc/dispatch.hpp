@@ -10,6 +10,7 @@
 #include "implicit.hpp"
 #include "fused.hpp"
 #include "rollout_stream.hpp"
+#include "rollout_split.hpp"
 
 namespace rd {
 
@@ -48,9 +49,21 @@ template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     RD_LAUNCH((eval_kernel<Fn, T>), dim3(grid), dim3(256), 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
+// rollout! on split arrays (rdhip_rollout_split): one streaming kernel for every batch size and both layouts
+template <class Fn> int launch_rollout_split(const Fn& fn, const LaunchArgs& a) {
+    using T = typename Fn::T;
+    using L = SplitRollCfg<Fn, T>;
+    static_assert(L::BYTES <= 160 * 1024, "chunk does not fit the LDS of a CU");
+    if (a.N == 0 || a.K < 2) return RDHIP_OK;                           // (K < 2: nothing to simulate; api.hip copies the initial state)
+    auto kern = rollout_split_kernel<Fn, T>;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+    RD_LAUNCH(kern, dim3((unsigned)((a.N + TILE - 1) / TILE)), dim3(SPLIT_THREADS), L::BYTES, a.stream, fn, a.K, a.N, a.time_major ? 1 : 0, (T*)a.Z, (const T*)a.U, a.t, a.dt, (const T*)a.X0);
+    return hip_status(hipGetLastError());
+}
 template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
     if (a.N == 0 || a.K == 0) return RDHIP_OK;
+    if (a.U) return launch_rollout_split(fn, a);
     const unsigned grid = (unsigned)((a.N + 63) / 64);
     const long long sj = a.time_major ? 1 : a.K, sk = a.time_major ? a.N : 1;
     using Cas = Cascade<decltype(Fn::m)>;

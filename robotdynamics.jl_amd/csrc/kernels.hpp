@@ -679,7 +679,8 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     T* zs = reinterpret_cast<T*>(smem + JB + L::Y_BYTES);
     double* ts = reinterpret_cast<double*>(smem + JB + L::Y_BYTES + (L::Z_ELEMS * sizeof(T) + 15) / 16 * 16);
     // resolved tiles of this workgroup's iterations 0 .. RING_N - 1 (static LDS next to the dynamic tile, as many entries as fit the CU's 160 KiB)
-    constexpr int RING_FREE = (int)((160 * 1024 - L::BYTES) / 64);
+    constexpr int RING_FREE = (int)(((long long)160 * 1024 - (long long)L::BYTES - 256) / 64);      // (256 bytes stay free for the loop's other static words: sched_ring, hbuf, epi_word -- a tile that
+                                                                                                     // left the ring EXACTLY the rest of the CU's LDS could not be launched with the schedule compiled in: SatellitePair fp64, found by the round-6 sweep)
     constexpr int RING_N = !BT::RING ? 0 : RING_FREE >= 64 ? 64 : RING_FREE >= 32 ? 32 : RING_FREE >= 16 ? 16 : RING_FREE >= 8 ? 8 : 0;
     __shared__ long long ring[RING_N > 0 ? RING_N : 1][8];
     constexpr bool HELPER = HelperOf<Body>::value;
@@ -1334,21 +1335,19 @@ template <class Fn, class T> struct SmallLds {
     static constexpr int JU = (int)((size_t)TILE * JN * sizeof(T) / 16), YU = (int)((size_t)TILE * NY * sizeof(T) / 16);     // whole 16-byte units of a full tile
     static_assert(((size_t)TILE * JN * sizeof(T)) % 16 == 0 && ((size_t)TILE * NY * sizeof(T)) % 16 == 0, "64-knot slabs are multiples of 16 bytes");
 };
-template <class Fn, class T, class BT>
-RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
+// the walk of ONE wave: tiles tile, tile + tstep, ... of the descriptor, `base` = the wave's private LDS region (SmallLds::WAVE_BYTES).  COH: the tile
+// inputs were written by other workgroups of the same launch (mixed.hpp): agent-scope loads, as in jac_split_loop
+template <class Fn, class T, class BT, bool COH = false>
+RD_DEV void jac_ad_small_walk(const Fn& fn, const BT& bt, long long tile, const long long tstep, unsigned char* base) {
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, NY = Fn::NY, JN = NY * NZ;
     using L = SmallLds<Fn, T>;
     using D = Dual<T, NZ>;
     using V4 = __attribute__((ext_vector_type(4))) unsigned int;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* base = smem + wave * L::WAVE_BYTES;
     T* jt = reinterpret_cast<T*>(base);
     T* yt = reinterpret_cast<T*>(base + L::J_BYTES);
     T* zs = reinterpret_cast<T*>(base + L::J_BYTES + L::Y_BYTES);
-    const long long ntiles = bt.ntiles(), tstep = (long long)gridDim.x * L::WAVES;
-    long long tile = (long long)blockIdx.x * L::WAVES + wave;
+    const long long ntiles = bt.ntiles();
     if (tile >= ntiles) return;
     constexpr int ZPT = (TILE * NZ + TILE - 1) / TILE;        // = NZ
     TileRef<T> cur = at_uniform<T>(bt, tile);
@@ -1357,7 +1356,7 @@ RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
         const int nkr = live ? (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE) : 0;
         const T* __restrict__ Zr = r.Z + r.k0 * NZ;
 #pragma unroll
-        for (int i = 0; i < ZPT; ++i) { const int e = i * TILE + lane; zpre[i] = Zr[e < nkr * NZ ? e : 0]; }
+        for (int i = 0; i < ZPT; ++i) { const int e = i * TILE + lane; zpre[i] = tile_load<COH>(Zr + (e < nkr * NZ ? e : 0)); }
         const int kl = lane < nkr ? lane : (nkr > 0 ? nkr - 1 : 0);
         tpre = r.t[r.k0 + kl]; hpre = r.dt[r.k0 + kl];
     };
@@ -1434,6 +1433,13 @@ RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
         wave_sync();
         cur = nx;
     }
+}
+template <class Fn, class T, class BT>
+RD_DEV void jac_ad_small_body(const Fn& fn, const BT& bt) {
+    using L = SmallLds<Fn, T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    jac_ad_small_walk<Fn, T, BT>(fn, bt, (long long)blockIdx.x * L::WAVES + wave, (long long)gridDim.x * L::WAVES, smem + wave * L::WAVE_BYTES);
 }
 template <class Fn, class T>
 __global__ void __launch_bounds__(4 * TILE) jac_ad_small_kernel(Fn fn, long long N, const T* __restrict__ Z, const double* __restrict__ tt,
@@ -1536,7 +1542,10 @@ template <class Fn, class T, class Plan> struct ChainBody {
 #pragma unroll
             for (int i = 0; i < NX; ++i) w[i] = (i == c) ? T(1) : T(0);
 #pragma unroll
-            for (int i = 0; i < NU; ++i) wu[i] = (NX + i == c && !fr.term) ? T(1) : T(0);   // terminal knot point: control columns are zero
+            // terminal knot point: the control columns of a DISCRETE rule are zero (h = 0).  The continuous rule hands the user's own Jacobian back as the
+            // reference does -- jacobian!(fun, J, y, state(z), control(z)) with control(z) = zeros (src/functionbase.jl:252-257, src/knotpoint.jl:67):
+            // d f / d u at u = 0, NOT zeroed (only ForwardAD / FiniteDifference differentiate through `!is_terminal(z) * u`)
+            for (int i = 0; i < NU; ++i) wu[i] = (NX + i == c && (!fr.term || RULE == RULE_CONTINUOUS)) ? T(1) : T(0);
             jvp(fn, fr.x, fr.u, fr.t, w, wu, d1);
             if constexpr (RULE == RULE_CONTINUOUS) {
 #pragma unroll
@@ -1598,7 +1607,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 #pragma unroll
                 for (int i = 0; i < NX; ++i) w[i] = (i == C) ? T(1) : T(0);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) wu[i] = (NX + i == C) ? (fr.term ? T(0) : T(1)) : T(0);
+                for (int i = 0; i < NU; ++i) wu[i] = (NX + i == C) ? ((fr.term && RULE != RULE_CONTINUOUS) ? T(0) : T(1)) : T(0);      // (see ChainBody: the continuous rule keeps d f / d u at a terminal knot)
                 CB::jvp(fn, fr.x, fr.u, fr.t, w, wu, d1);
                 if constexpr (RULE == RULE_CONTINUOUS) {
 #pragma unroll

@@ -47,10 +47,8 @@ template <class Fn, class T, class Plan> struct UserJacBody {
 #pragma unroll
         for (int e = 0; e < NY * NZ; ++e) J[e] = T(0);
         user_jac<Fn, T>(fn, fr.x, fr.u, fr.t, fr.h, J);
-        if (fr.term) {                                       // control columns of a terminal knot point are zero (`!is_terminal(z) * u`, src/knotpoint.jl:67)
-#pragma unroll
-            for (int e = NY * NX; e < NY * NZ; ++e) J[e] = T(0);
-        }
+        // (a terminal knot point: the user's function was called with control(z) = zeros -- read_knot -- and what it wrote is handed back as it is, like
+        // the reference's jacobian!(fun, J, y, state(z), control(z)), src/functionbase.jl:252-257; rounds 1-5 zeroed its control columns)
         if (fr.want_y) { T y[NY]; fn.eval(fr.x, fr.u, fr.t, fr.h, y); fr.put_value(NZ, y); }
     }
 };

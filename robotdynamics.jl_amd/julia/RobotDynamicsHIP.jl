@@ -1009,6 +1009,26 @@ function RobotDynamics.rollout!(::RD.FunctionSignature, fun::RD.DiscretizedDynam
     check(c, rc)
 end
 
+# rollout! on split arrays (rdhip_rollout_split): X n x K x M receives the simulated states (knot 1 = x0[:, j], or what X holds there), U m x (K-1) x M the
+# controls, t / dt K x M -- what `states(Z)` / `controls(Z)` / `gettimes(Z)` give for M trajectories (src/trajectories.jl:436-441).  time_major = true: the
+# arrays are n x M x K, m x M x (K-1), M x K.  Reads U, t, dt once and writes X once: a big batch moves half the bytes of the packed stack's rollout.
+function rollout_split!(::RD.FunctionSignature, fun::RD.DiscretizedDynamics, X::Dense{T,3}, U::Dense{T,3}, t::Dense{Float64,2}, dt::Dense{Float64,2},
+                        x0::Union{Nothing,Dense{T}}=nothing; time_major::Bool=false, ctx::Union{Nothing,Context}=nothing) where {T}
+    n, m = RD.state_dim(fun), RD.control_dim(fun)
+    K, M = time_major ? (size(X, 3), size(X, 2)) : (size(X, 2), size(X, 3))
+    size(X, 1) == n || throw(DimensionMismatch("X must be n x K x M"))
+    size(U) == (time_major ? (m, M, max(K - 1, 0)) : (m, max(K - 1, 0), M)) || throw(DimensionMismatch("U must be m x (K-1) x M"))
+    (size(t) == size(X)[2:3] && size(dt) == size(X)[2:3]) || throw(DimensionMismatch("t, dt: one entry per knot point of X"))
+    x0 === nothing || length(x0) == n * M || throw(DimensionMismatch("x0 must be n x M"))
+    sp, found = _where(X, U, t, dt, x0)
+    c = _ctx(ctx, found)
+    GC.@preserve X U t dt x0 begin
+        rc = ccall((:rdhip_rollout_split, librdhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Clonglong, Clonglong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                   c.ptr, handle(fun), rulecode(fun), dtypecode(T), K, M, Cint(time_major), _p(X), _p(U), _p(t), _p(dt), _p(x0), sp)
+    end
+    check(c, rc)
+end
+
 # rollout! followed by jacobian! at every simulated knot point, one call (the forward pass + linearisation of a shooting method)
 function rollout_jacobian!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.DiscretizedDynamics, J::Dense{T,3}, Zs::AbstractPackedTrajectory{n,m,T},
                            K::Integer, x0::Union{Nothing,Dense{T}}=nothing; time_major::Bool=false, ctx::Union{Nothing,Context}=nothing) where {n,m,T}

@@ -114,6 +114,7 @@ _SIGS = {
     "rdhip_ctx_last_rollout_jacobian_launches": (C.c_int, [_P, _IP]),
     "rdhip_rollout_jacobian_multi": (C.c_int, [_P, C.c_int, C.POINTER(_P), _IP, C.c_int, C.c_int, C.POINTER(_LL), C.POINTER(_LL), C.c_int,
                                                C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_int]),
+    "rdhip_rollout_split": (C.c_int, [_P, _P, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
     "rdhip_rollout_jacobian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _LL, _LL, C.c_int, _P, _P, _P, _P, _P, C.c_int]),
 }
 EXPORTS = tuple(_SIGS)

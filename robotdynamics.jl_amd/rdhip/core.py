@@ -1946,6 +1946,38 @@ def rollout_(sig, model, Z, x0=None, time_major=False):
     return None
 
 
+def rollout_split_(sig, model, X, U, t, dt, x0=None, time_major=False):
+    """rollout!(sig, model, Z, x0) with states and controls in arrays of their own (rdhip_rollout_split; src/trajectories.jl:436-441): X (M, K, n) receives
+    every simulated state (knot 0 = x0, or what X holds there when x0 is None), U (M, K-1, m) is read, t / dt (M, K); with time_major=True the arrays are
+    (K, M, n), (K-1, M, m), (K, M).  Same arithmetic as rollout_; a big batch moves its algorithmic bytes (the packed stack's rollout moves 1.9 x)."""
+    cm, rule = _model_rule(model)
+    if rule == L.CONTINUOUS:
+        raise TypeError("rollout! needs a DiscreteDynamics model")
+    n, m = state_dim(model), control_dim(model)
+    if X.ndim != 3 or U.ndim != 3 or X.shape[2] != n or U.shape[2] != m:
+        raise ValueError(f"X must be (.., .., {n}) and U (.., .., {m})")
+    K, M = (X.shape[0], X.shape[1]) if time_major else (X.shape[1], X.shape[0])
+    want_u = (max(K - 1, 0), M, m) if time_major else (M, max(K - 1, 0), m)
+    if tuple(U.shape) != want_u:
+        raise ValueError(f"U has shape {tuple(U.shape)}, expected {want_u}")
+    if tuple(t.shape) != tuple(X.shape[:2]) or tuple(dt.shape) != tuple(X.shape[:2]):
+        raise ValueError("t and dt must have one entry per knot point of X")
+    for a, name in ((X, "X"), (U, "U"), (t, "t"), (dt, "dt")):
+        if not (a.is_contiguous() if _is_torch(a) else a.flags["C_CONTIGUOUS"]):
+            raise ValueError(f"{name} must be contiguous")
+    x0a = x0
+    if x0a is not None and not _is_torch(x0a):
+        x0a = np.ascontiguousarray(np.asarray(x0a, dtype=X.dtype if isinstance(X, np.ndarray) else np.float64).reshape(M, -1))
+    if x0a is not None and tuple(x0a.shape) != (M, n):
+        raise ValueError("x0 has the wrong shape")
+    ax, au, at, adt, a0 = _Arg(X, "X"), _Arg(U, "U", None), _Arg(t, "t"), _Arg(dt, "dt"), _Arg(x0a, "x0")
+    if au.ptr is not None and au.dtype != ax.dtype or (a0.ptr is not None and a0.dtype != ax.dtype):
+        raise ValueError("X, U and x0 must share one dtype")
+    ctx, space = _resolve_ctx([ax, au, at, adt, a0])
+    L.check(L.lib().rdhip_rollout_split(ctx.handle, cm._handle, rule, ax.dtype, K, M, 1 if time_major else 0, ax.ptr, au.ptr, at.ptr, adt.ptr, a0.ptr, space), ctx.handle)
+    return None
+
+
 def rollout_jacobian_(sig, diff, model, J, Z, x0=None, time_major=False):
     """rollout!(sig, model, Z, x0) followed by jacobian!(sig, diff, model, J[k], y, Z[k]) at every knot point of the simulated
     trajectories, in ONE call (the forward pass + linearisation of a shooting method).  Z = {"data", "t", "dt"}: a stack of M
@@ -2041,6 +2073,18 @@ class PreparedRolloutJacobianMulti:
         rc = L.lib().rdhip_rollout_jacobian_multi(ctx.handle, *self._args)
         if rc:
             L.check(rc, ctx.handle)
+        self._last_ctx = ctx
+
+    @property
+    def launches(self):
+        """kernel launches the last call issued ON THE CONTEXT'S STREAM (rdhip_ctx_last_rollout_jacobian_launches): 1 = the whole call was one launch
+        (csrc/mixed.hpp, or the fused launch of the model that stayed on the context's stream while the others ran on internal streams)"""
+        ctx = getattr(self, "_last_ctx", None)
+        if ctx is None:
+            return 0
+        k = C.c_int(0)
+        L.check(L.lib().rdhip_ctx_last_rollout_jacobian_launches(ctx.handle, C.byref(k)), ctx.handle)
+        return k.value
 
 
 def rollout_jacobian_multi_(sig, diff, models, Js, Zs, x0s=None, time_major=False):

@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = 203                      # 3 full tiles + 11 knots
 MID = 8192 + 64 * 3 + 5         # 132 tiles: past the four-workgroups-per-tile form (at most 128 tiles on 256 CUs)
 BIG = 98304 + 64 + 7            # 1 538 tiles: >= 8 per workgroup of the dynamic schedule's 192-workgroup grid
+BIG_OF = {"liesat": 8 * 768 * 64 + 71}      # (its 45 KB tiles leave three workgroups per CU: the full grid of 768, 8 tiles each -- common.hpp dyn_grid)
 RULES = [None, RD.Euler, RD.RK2, RD.RK3, RD.RK4]
 ORULE = {None: O.CONTINUOUS, RD.Euler: O.EULER, RD.RK2: O.RK2, RD.RK3: O.RK3, RD.RK4: O.RK4}
 SIG = RD.StaticReturn()
@@ -229,7 +230,7 @@ def test_sweep_jacobian(name, dname):
             if dcode == O.FORWARD_AD:
                 combos += [(MID, True), (MID, False)]
             if not c.f32:
-                combos += [(BIG, True)]
+                combos += [(BIG_OF.get(name, BIG), True)]
             for N, aligned in combos:
                 J, Y = jac_buffers(c, fun, N, aligned)
                 what = f"{name}/{dname} jacobian rule {rule.__name__ if rule else 'continuous'} {type(diff).__name__} N={N} aligned={aligned}"
@@ -268,7 +269,7 @@ def test_sweep_jacobian_multi(name, dname):
         atol, rtol = c.tol(O.FORWARD_AD, ref[0])
         shapes = {"inline": [BASE, 64, 130], "table uniform": [70] * 40, "table ragged": [70 + (i % 3) for i in range(40)]}
         if not c.f32:
-            shapes["long"] = [24704] * 4                           # 4 x 386 tiles: the dynamic tile schedule (>= 8 tiles per workgroup, >= 16 per batch)
+            shapes["long"] = [BIG_OF.get(name, 98816) // 4] * 4    # 4 x 386 tiles: the dynamic tile schedule (>= 8 tiles per workgroup, >= 16 per batch)
         for tag, sizes in shapes.items():
             launches, Js, Ys = _multi(c, fun, RD.ForwardAD(), sizes)
             c.note()
@@ -304,7 +305,7 @@ def test_sweep_error_expansion_and_dynamics_error(name, dname):
         # consecutive pairs of a batch that repeats the base batch: pair k of the repetition = pair k of [base; base[0]] -- one more row for the oracle
         Zx, tx, dtx = (np.concatenate([a, a[:1]]) for a in (c.Z, c.t, c.dt))
         Eo, Yo = c.om.error_expansion(ORULE[rule], Zx, tx, dtx)
-        for N in (BASE, MID) + (() if c.f32 else (BIG,)):
+        for N in (BASE, MID) + (() if c.f32 else (BIG_OF.get(name, BIG),)):
             E = RD.alloc_error_expansions(fun, N, c.traj(BASE).data); E.fill_(float("nan"))
             Y = torch.full((N - 1, n), float("nan"), dtype=tdt, device="cuda")
             RD.error_expansion_(fun, E, Y, c.traj(N))
@@ -359,6 +360,21 @@ def test_sweep_rollout_and_rollout_jacobian(name, dname):
                 s = max(1.0, float(np.abs(Zr).max()))
                 atol, rtol = ((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0))     # (fp32: K - 1 steps of rounding)
                 assert_periodic(got, Zr, atol, rtol, f"{name}/{dname} rollout {rule.__name__} M={M} K={K} time_major={tm}")
+        # the same rollouts on split arrays (rdhip_rollout_split: X written, U read): one streaming kernel for both layouts and every size
+        for M, K, tm in ((70, 9, False), (70, 9, True), (333, 6, True)):
+            st, Zb, tb, dtb = _stack(c, M, K, tm)
+            Zr = c.om.rollout(ORULE[rule], Zb, tb, dtb)
+            X = torch.full(tuple(st["data"].shape[:2]) + (c.n,), float("nan"), dtype=st["data"].dtype, device="cuda")
+            if tm:
+                X[0] = st["data"][0, :, :c.n]
+            else:
+                X[:, 0] = st["data"][:, 0, :c.n]
+            U = (st["data"][:K - 1, :, c.n:] if tm else st["data"][:, :K - 1, c.n:]).contiguous()
+            RD.rollout_split_(SIG, fun, X, U, st["t"], st["dt"], time_major=tm); c.note()
+            got = X.transpose(0, 1) if tm else X
+            s = max(1.0, float(np.abs(Zr).max()))
+            atol, rtol = ((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0))
+            assert_periodic(got, Zr[:, :, :c.n], atol, rtol, f"{name}/{dname} rollout_split {rule.__name__} M={M} K={K} time_major={tm}")
         # an initial state of its own (x0) and the Jacobians along the rollout in the same call
         for tm in (False, True):
             M, K = 70, 9

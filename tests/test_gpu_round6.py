@@ -70,9 +70,13 @@ def test_state_diff_error_maps_model_states_large_batch_and_fp32(rot):
         np.testing.assert_allclose(got, exp, rtol=TOL, atol=TOL, err_msg=f"rot {rot} {name} fp64")
         exp32 = om.state_diff(Z.astype(np.float32).astype(np.float64), Z0.astype(np.float32).astype(np.float64), errmap=Map.code)
         got32 = host(RD.state_diff(model, tr(Z, np.float32), tr(Z0, np.float32), Map())).astype(np.float64)
-        # (relative to the size of the rotation error of the knot point: v / w and the shadow-set branches are unbounded near 180 degrees)
-        scale = np.maximum(1.0, np.abs(exp32).max(axis=1, keepdims=True))
-        assert np.max(np.abs(got32 - exp32) / scale) < 2e-4, f"rot {rot} {name} fp32"
+        # (v / w and the shadow-set branches are unbounded near 180 degrees and lose digits like 1 / w^2 there: fp32 is held to rel 2e-4 where the rotation
+        # error stays below 30, and to finiteness beyond)
+        big = np.abs(exp32).max(axis=1)
+        ok = big < 30.0
+        scale = np.maximum(1.0, big[ok, None])
+        assert ok.mean() > 0.9 and np.isfinite(got32).all()
+        assert np.max(np.abs(got32[ok] - exp32[ok]) / scale) < 2e-4, f"rot {rot} {name} fp32"
 
 
 def test_state_diff_error_maps_wide_leading_dimension_takes_the_elementwise_kernel():
@@ -89,3 +93,82 @@ def test_state_diff_error_maps_wide_leading_dimension_takes_the_elementwise_kern
         got = host(RD.state_diff(s, Xd, X0d, Map()))
         assert "state_diff_kernel" in RD.last_kernel_name()
         np.testing.assert_allclose(got, om.state_diff(W[:, :n], W0[:, :n], errmap=Map.code), rtol=TOL, atol=TOL, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# rdhip_rollout_split: states and controls in arrays of their own (src/trajectories.jl:436-441) -- against rdhip_rollout bit for bit and the oracle
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("tm", [False, True])
+@pytest.mark.parametrize("shape", [(70, 9), (1, 2), (64, 17), (3, 1), (130, 33), (4101, 5)])
+def test_rollout_split_equals_the_packed_rollout(shape, tm, dtype):
+    """Every model family, both layouts, ragged groups and chunk ends (K = c C + 1: the last chunk holds no step), K = 1 (nothing to simulate), with and
+    without x0: the simulated states equal those of rdhip_rollout's one-lane kernel on the packed stack BIT FOR BIT (the same step function; the kernel the
+    dispatcher picks for rigid bodies integrates block by block along the cascade and differs in the last place), which the oracle pins."""
+    M, K = shape
+    rng = np.random.default_rng(M * 1000 + K)
+    T = torch.float64 if dtype == np.float64 else torch.float32
+    for model, om in ((RD.Satellite(2.0, np.diag([2.0, 3.0, 1.0])), O.body()), (RD.Cartpole(), O.cartpole()), (RD.Quadrotor(bodyframe=True), O.quadrotor(frame=1)),
+                      (RD.SatellitePair(), O.satellite_pair()), (RD.Satellite(R=RD.MRP), O.satellite(rot=O.ROT_MRP)), (RD.DoubleIntegrator(2), O.double_integrator(2))):
+        n, m = RD.state_dim(model), RD.control_dim(model)
+        nz = n + m
+        data = rng.random((M, K, nz)) * 0.6
+        if n == 13:
+            q = rng.standard_normal((M, K, 4)); data[:, :, 3:7] = q / np.linalg.norm(q, axis=2, keepdims=True)
+        if isinstance(model, RD.SatellitePair):
+            for o in (0, 7):
+                q = rng.standard_normal((M, K, 4)); data[:, :, o:o + 4] = q / np.linalg.norm(q, axis=2, keepdims=True)
+        data = data.astype(dtype).astype(np.float64)
+        dts = np.tile(rng.uniform(0.01, 0.05, K), (M, 1)); tt = np.cumsum(dts, axis=1) - dts
+        if K > 4:
+            dts[:, 3] = 0.0                                           # a terminal time step inside the trajectory: zero control for that step (src/knotpoint.jl:67)
+        for rule, orule in ((RD.RK4, O.RK4), (RD.Euler, O.EULER)):
+            fun = RD.DiscretizedDynamics(model, rule)
+            for with_x0 in (False, True):
+                x0 = (data[:, 0, :n] * 0.9).astype(dtype).astype(np.float64) if with_x0 else None
+                if x0 is not None and n == 13:
+                    x0[:, 3:7] = data[:, 0, 3:7]
+                lay = (lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))) if tm else (lambda a: np.ascontiguousarray(a))
+                st = {"data": torch.as_tensor(lay(data).astype(dtype)).cuda(), "t": torch.as_tensor(lay(tt)).cuda(), "dt": torch.as_tensor(lay(dts)).cuda()}
+                x0d = None if x0 is None else torch.as_tensor(x0.astype(dtype)).cuda()
+                RD.tune("rollout=plain")                              # the one-lane kernel: the same step function the split kernel's compute lane calls
+                try:
+                    RD.rollout_(RD.StaticReturn(), fun, st, x0=x0d, time_major=tm)
+                finally:
+                    RD.tune("reset")
+                ref = st["data"][..., :n].contiguous()
+                st2 = {"data": torch.as_tensor(lay(data).astype(dtype)).cuda(), "t": st["t"], "dt": st["dt"]}
+                RD.rollout_(RD.StaticReturn(), fun, st2, x0=x0d, time_major=tm)         # the kernel the dispatcher picks (block by block along the cascade for rigid bodies: rounding-level differences)
+                torch.testing.assert_close(st2["data"][..., :n].contiguous(), ref, rtol=1e-12 if dtype == np.float64 else 2e-5, atol=1e-13 if dtype == np.float64 else 2e-6)
+                X = torch.full(lay(data[:, :, :n]).shape, float("nan"), dtype=T, device="cuda")
+                if x0 is None:                                        # knot 0 is what X holds there
+                    if tm:
+                        X[0] = torch.as_tensor(data[:, 0, :n].astype(dtype)).cuda()
+                    else:
+                        X[:, 0] = torch.as_tensor(data[:, 0, :n].astype(dtype)).cuda()
+                U = torch.as_tensor(lay(data[:, :K - 1, n:]).astype(dtype)).cuda().contiguous()
+                RD.rollout_split_(RD.StaticReturn(), fun, X, U, st["t"], st["dt"], x0=x0d, time_major=tm)
+                if K > 1:
+                    assert "rollout_split_kernel" in RD.last_kernel_name()
+                assert torch.equal(X, ref), f"{type(model).__name__} {rule.__name__} M={M} K={K} tm={tm} x0={with_x0}: max diff {float((X - ref).abs().max())}"
+                if M <= 130 and dtype == np.float64:
+                    Zr = om.rollout(orule, data, tt, dts, X0=x0)
+                    got = host(X).transpose(1, 0, 2) if tm else host(X)
+                    np.testing.assert_allclose(got, Zr[:, :, :n], rtol=0, atol=TOL * max(1.0, np.abs(Zr).max()))
+
+
+def test_rollout_split_host_arrays_and_errors():
+    model = RD.Satellite()
+    fun = RD.DiscretizedDynamics(model, RD.RK3)
+    rng = np.random.default_rng(8)
+    M, K = 5, 7
+    data = H.rand_rigid(rng, M * K, 6).reshape(M, K, 19)
+    tt = np.tile(np.arange(K) * 0.02, (M, 1)); dts = np.full((M, K), 0.02)
+    X = np.full((M, K, 13), np.nan); X[:, 0] = data[:, 0, :13]
+    U = np.ascontiguousarray(data[:, :K - 1, 13:])
+    RD.rollout_split_(RD.StaticReturn(), fun, X, U, tt, dts)         # host arrays: staged through the context's workspace
+    np.testing.assert_allclose(X, O.satellite().rollout(O.RK3, data, tt, dts)[:, :, :13], rtol=0, atol=TOL)
+    with pytest.raises(ValueError):
+        RD.rollout_split_(RD.StaticReturn(), fun, X, U[:, :-1], tt, dts)
+    with pytest.raises(NotImplementedError):
+        RD.rollout_split_(RD.StaticReturn(), RD.DiscretizedDynamics(model, RD.ImplicitMidpoint), X, U, tt, dts)

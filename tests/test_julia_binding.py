@@ -88,7 +88,7 @@ def test_every_batched_operator_has_a_device_path():
     entry point must be computed from the arrays (`sp`), i.e. DeviceArray arguments run in place on the GPU."""
     calls = jl_ccalls()
     compute = ["rdhip_dynamics", "rdhip_discrete_dynamics", "rdhip_jacobian", "rdhip_jacobian_multi", "rdhip_dynamics_error", "rdhip_dynamics_error_jacobian",
-               "rdhip_error_expansion", "rdhip_errstate_jacobian", "rdhip_state_diff", "rdhip_state_diff_map", "rdhip_nabla_errstate_jacobian", "rdhip_rollout", "rdhip_rollout_layout", "rdhip_rollout_jacobian",
+               "rdhip_error_expansion", "rdhip_errstate_jacobian", "rdhip_state_diff", "rdhip_state_diff_map", "rdhip_nabla_errstate_jacobian", "rdhip_rollout", "rdhip_rollout_layout", "rdhip_rollout_split", "rdhip_rollout_jacobian",
                "rdhip_rollout_jacobian_multi"]
     for name in compute:
         for _, _, tail in calls[name]:

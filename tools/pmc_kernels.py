@@ -45,11 +45,18 @@ for _ in range(REPS):
 torch.cuda.synchronize()
 NK = M * K
 report("c5_whole_one_call_fp32", {
-    # satellite: the rollout reads u, t, dt (24 + 16) and writes x (52); the Jacobian role reads z, t, dt (76 + 16) and writes J (988)
+    # round 6: ONE launch (mixed.hpp).  satellite: the rollout reads u, t, dt (24 + 16) and writes x (52), the Jacobian role reads z, t, dt (76 + 16) and writes
+    # J (988); cartpole: the rollout reads u, t, dt (4 + 16) and writes x (16), the Jacobians read z, t, dt (20 + 16) and write J (80)
+    "rollout_jac_mixed_kernel": NK * (24 + 16 + 52 + 76 + 16 + 988) + NK * (4 + 16 + 16 + 20 + 16 + 80)}, "both models in one launch")
+RD.tune("mixed=0")                                       # round 5's form of the same call: the satellite's fused launch + the cartpole in four pipelined pieces
+for _ in range(REPS):
+    call()
+torch.cuda.synchronize()
+RD.tune("reset")
+report("c5_whole_streams_fp32", {
     "rollout_jac_fused_kernel": NK * (24 + 16 + 52 + 76 + 16 + 988),
-    # cartpole, four pieces each: the rollout reads u, t, dt (4 + 16) and writes x (16); the Jacobians read z, t, dt (20 + 16) and write J (80)
     "rollout_kernel": NK * (4 + 16 + 16) // 4,
-    "jac_ad_small_kernel": NK * (20 + 16 + 80) // 4}, "cartpole kernels: per piece (a quarter of the stack)")
+    "jac_ad_small_kernel": NK * (20 + 16 + 80) // 4}, "RDHIP_TUNE mixed=0; cartpole kernels: per piece (a quarter of the stack)")
 del stacks, Js, call
 torch.cuda.empty_cache()
 
@@ -105,3 +112,18 @@ for _ in range(REPS):
 torch.cuda.synchronize()
 report("rollout_stream_32768x32", {"rollout_stream_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104},
        "algorithmic: per step read u, t, dt (64 B) and write x (104 B); the kernel moves whole knot points (152 B lines in and out)")
+
+# 5b. the same rollout on split arrays (rollout_split.hpp): U, t, dt read once, X written once
+X = torch.empty((K, M, 13), dtype=torch.float64, device="cuda"); X[0] = st["data"][0, :, :13]
+U = st["data"][:K - 1, :, 13:].contiguous()
+for _ in range(REPS):
+    RD.rollout_split_(sig, dsat, X, U, st["t"], st["dt"], time_major=True)
+torch.cuda.synchronize()
+report("rollout_split_32768x32", {"rollout_split_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "time-major")
+Xj = torch.empty((M, K, 13), dtype=torch.float64, device="cuda"); Xj[:, 0] = st["data"][0, :, :13]
+Uj = st["data"][:K - 1, :, 13:].transpose(0, 1).contiguous()
+tj, dj = st["t"].t().contiguous(), st["dt"].t().contiguous()
+for _ in range(REPS + 1):                                  # (one more launch than the time-major case: the script tells the two apart by their launch counts)
+    RD.rollout_split_(sig, dsat, Xj, Uj, tj, dj)
+torch.cuda.synchronize()
+report("rollout_split_32768x32_trajectory_major", {"rollout_split_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "trajectory-major: a trajectory's 4-knot runs start and end inside 128-byte lines")
