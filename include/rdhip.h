@@ -120,7 +120,9 @@ int rdhip_tune(const char* pairs);
 const char* rdhip_last_error(rdhip_ctx* ctx);
 /* Name (demangled, NUL-terminated, truncated to `capacity`) of the kernel the CALLING HOST THREAD launched last through the library: which
  * specialisation a call such as jacobian!(sig, diff, fun, J, y, z) (src/functionbase.jl:242) was dispatched to -- the reference resolves that by
- * Julia method dispatch (`@which`); here a benchmark or a test asks instead of assuming (bench.py's roofline.kernel).  Empty before the first launch. */
+ * Julia method dispatch (`@which`); here a benchmark or a test asks instead of assuming (bench.py's roofline.kernel).  Empty before the first launch.
+ * A launch that was handed the counter words of the dynamic tile schedule has " [dynamic tile schedule]" appended (most kernels carry the schedule in their one
+ * instantiation and take it at run time: the name alone does not say). */
 int rdhip_last_kernel_name(char* buf, int capacity);
 /* HIP-event stopwatch on the context's stream (for hosts without their own event API) */
 int rdhip_timer_start(rdhip_ctx* ctx);
@@ -280,10 +282,12 @@ int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff,
  * points cost what one 65 536-knot batch costs, and 1 024 trajectories of 101 knot points (examples/cartpole.jl:46) are one bandwidth-regime launch.
  * The tables N / Z / t / dt / J / Y themselves are HOST arrays of nbatch entries (not retained); memspace describes the data pointers inside them.
  * Up to 32 non-empty batches travel in the kernel arguments; more are copied into a device table owned by the context (a binary search per tile,
- * none when all batches have the same length).  Fused -- ONE launch -- for every explicit rule and diff method (ForwardAD, FiniteDifference,
- * UserDefined) of the compiled-in and the custom (hipRTC) models with device pointers, aligned or not; RDHIP_IMPLICIT_MIDPOINT (three passes per batch)
- * and host arrays run the batches one rdhip_jacobian call at a time with the same results, and so does a capturing stream with more than 32 batches
- * in groups of 32 launches (no allocation inside a capture).  rdhip_ctx_last_multi_launches tells which happened; RDHIP_VERBOSE=1 logs the fallback.
+ * none when all batches have the same length).  Fused -- ONE launch -- for RDHIP_FORWARD_AD (the reference's default diff method of a DiscretizedDynamics,
+ * src/discretized_dynamics.jl:190) under every explicit rule, compiled-in models with device pointers whose J / Y start on 16-byte boundaries (custom
+ * hipRTC models: every diff method, aligned or not -- their kernels are compiled on demand).  RDHIP_FINITE_DIFF, RDHIP_USER_DEFINED, unaligned outputs,
+ * RDHIP_IMPLICIT_MIDPOINT (three passes per batch) and host arrays run the batches one rdhip_jacobian call at a time with the same results (round 6: the
+ * batch-table instantiations of those bodies were half of the library's device code and nothing exercised them), and so does a capturing stream with
+ * more than 32 batches in groups of 32 launches (no allocation inside a capture).  rdhip_ctx_last_multi_launches tells which happened; RDHIP_VERBOSE=1 logs the fallback.
  * Batches must not overlap. */
 int rdhip_jacobian_multi(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, int nbatch, const long long* N,
                          const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace);
@@ -384,9 +388,10 @@ int rdhip_model_wrench_sparsity(const rdhip_model* model, int js[10]);
  * rdhip_rollout(x0, U, ... -> X)): X n x K x M receives every simulated state (knot 0 = X0[:, j], or what X holds there when X0 is NULL), U m x (K-1) x M is
  * read; t, dt: K x M as for rdhip_rollout_layout (dt of a trajectory's last knot is not used).  layout RDHIP_TRAJECTORY_MAJOR: state k of trajectory j at
  * X + (j K + k) n, control k at U + (j (K-1) + k) m; RDHIP_TIME_MAJOR: X + (k M + j) n, U + (k M + j) m.  Same arithmetic as rdhip_rollout.
- * Why it exists: a packed stack interleaves x and u, and an in-place rollout that writes whole lines has to write the controls back with the states --
- * rdhip_rollout's streaming kernel moves 1.93 x the algorithmic bytes of a big batch (32 768 x 32 fp64 satellite knots); here U, t, dt are read once and X
- * is written once (168 instead of 320 bytes per satellite knot point).  Explicit rules, compiled-in models; no alignment requirement.  src/trajectories.jl:436-441. */
+ * Why it exists: a packed stack interleaves x and u, and an in-place rollout either writes the controls back with the states (rdhip_rollout's streaming
+ * kernel: 1.93 x the algorithmic bytes of a 32 768 x 32 fp64 satellite batch) or stores partial lines; here U, t, dt are read once and X is written once
+ * (168 instead of 320 bytes per satellite knot point; time-major 32 768 x 32: 42 us against 66 us for the packed stack).  Explicit rules, compiled-in
+ * models; no alignment requirement; the same bits as rdhip_rollout's one-lane kernel.  src/trajectories.jl:436-441. */
 int rdhip_rollout_split(rdhip_ctx* ctx, const rdhip_model* model, int rule, int dtype, long long K, long long M, int layout,
                         void* X, const void* U, const double* t, const double* dt, const void* X0, int memspace);
 /* rdhip_rollout for either layout of the stack (rdhip_rollout = RDHIP_TRAJECTORY_MAJOR, the reference's "vector of trajectories").  Big batches

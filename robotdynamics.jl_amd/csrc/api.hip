@@ -297,7 +297,7 @@ int rdhip_last_kernel_name(char* buf, int capacity) {
     if (!raw) { (void)hipGetLastError(); return RDHIP_OK; }     // nothing launched on this thread yet
     int st = 0;
     char* dem = abi::__cxa_demangle(raw, nullptr, nullptr, &st);
-    std::snprintf(buf, (size_t)capacity, "%s", (st == 0 && dem) ? dem : raw);
+    std::snprintf(buf, (size_t)capacity, "%s%s", (st == 0 && dem) ? dem : raw, k.dyn ? " [dynamic tile schedule]" : "");
     std::free(dem);
     return RDHIP_OK;
 }
@@ -923,8 +923,9 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     rc = check_rotation(c, M, 0); if (rc) return rc;
     if (live.empty()) return RDHIP_OK;
     const ModelDesc& d = M->d;
-    // fused: explicit rules on device pointers (compiled-in and custom models, every diff method, aligned or not).  Implicit rules (a Newton
-    // pass, the Jacobian pass and a gated exact pass per batch) and host arrays run the batches one rdhip_jacobian call at a time.
+    // fused: explicit rules on device pointers -- ForwardAD on aligned outputs for the compiled-in models (dispatch.hpp launch_jacobian_multi says
+    // RDHIP_ERR_UNSUPPORTED for the rest before anything is launched), everything for custom models.  Implicit rules (a Newton pass, the Jacobian pass
+    // and a gated exact pass per batch) and host arrays run the batches one rdhip_jacobian call at a time.
     bool fused = memspace == RDHIP_DEVICE && rule != RDHIP_IMPLICIT_MIDPOINT;
     if (fused) {
         const int nl = (int)live.size();

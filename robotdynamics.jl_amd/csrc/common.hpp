@@ -30,12 +30,12 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t lds) {
 
 // the kernel the calling host thread launched last through the library (rdhip_last_kernel_name: a benchmark or a test names the kernel a call was
 // dispatched to instead of assuming it); compiled-in kernels by their host stub, hipRTC kernels by their module function
-struct LastKernel { const void* host_fn; hipFunction_t mod_fn; };
+struct LastKernel { const void* host_fn; hipFunction_t mod_fn; bool dyn = false; };      // dyn: the launch was handed the counter words of the dynamic tile schedule
 inline LastKernel& last_kernel() { static thread_local LastKernel k{nullptr, nullptr}; return k; }
 #define RD_LAUNCH(kern, grid, block, lds, stream, ...)                                                    \
     do {                                                                                                  \
         auto rd_kern_ = (kern);                                                                           \
-        rd::last_kernel() = rd::LastKernel{reinterpret_cast<const void*>(rd_kern_), nullptr};             \
+        rd::last_kernel() = rd::LastKernel{reinterpret_cast<const void*>(rd_kern_), nullptr, false};      \
         hipLaunchKernelGGL(rd_kern_, grid, block, lds, stream, __VA_ARGS__);                              \
     } while (0)
 

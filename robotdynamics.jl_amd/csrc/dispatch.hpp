@@ -49,15 +49,14 @@ template <class Fn> int launch_eval(const Fn& fn, const LaunchArgs& a) {
     RD_LAUNCH((eval_kernel<Fn, T>), dim3(grid), dim3(256), 0, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y);
     return hip_status(hipGetLastError());
 }
-// rollout! on split arrays (rdhip_rollout_split): one streaming kernel for every batch size and both layouts
+// rollout! on split arrays (rdhip_rollout_split): one lane per trajectory, both layouts by strides (rollout_split.hpp)
 template <class Fn> int launch_rollout_split(const Fn& fn, const LaunchArgs& a) {
     using T = typename Fn::T;
-    using L = SplitRollCfg<Fn, T>;
-    static_assert(L::BYTES <= 160 * 1024, "chunk does not fit the LDS of a CU");
     if (a.N == 0 || a.K < 2) return RDHIP_OK;                           // (K < 2: nothing to simulate; api.hip copies the initial state)
-    auto kern = rollout_split_kernel<Fn, T>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
-    RD_LAUNCH(kern, dim3((unsigned)((a.N + TILE - 1) / TILE)), dim3(SPLIT_THREADS), L::BYTES, a.stream, fn, a.K, a.N, a.time_major ? 1 : 0, (T*)a.Z, (const T*)a.U, a.t, a.dt, (const T*)a.X0);
+    const long long K = a.K, M = a.N;
+    const bool tm = a.time_major != 0;
+    RD_LAUNCH((rollout_split_lane_kernel<Fn, T>), dim3((unsigned)((M + 63) / 64)), dim3(64), 0, a.stream, fn, K, M, tm ? 1LL : K, tm ? M : 1LL, tm ? 1LL : K - 1, tm ? M : 1LL,
+              tm ? 1LL : K, tm ? M : 1LL, (T*)a.Z, (const T*)a.U, a.t, a.dt, (const T*)a.X0);
     return hip_status(hipGetLastError());
 }
 template <class Fn> int launch_rollout(const Fn& fn, const LaunchArgs& a) {
@@ -162,6 +161,7 @@ template <class Fn, class T, class Plan, int NC, class K, class KD> int launch_s
             if (ntiles >= 8LL * gd) {
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel_dyn), lds) != hipSuccess) return RDHIP_ERR_HIP;
                 RD_LAUNCH(kernel_dyn, dim3(gd), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
+                last_kernel().dyn = true;
                 return hip_status(hipGetLastError());
             }
         }
@@ -189,6 +189,7 @@ template <class Fn, class T, class Plan, int NC, class KD> int launch_split_kern
         const unsigned gd = dyn_grid(full);
         if (ntiles >= 8LL * gd) {
             RD_LAUNCH(kernel_dyn, dim3(gd), dim3(threads), lds, a.stream, fn, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.J, (T*)a.Y, a.sched);
+                last_kernel().dyn = true;
             return hip_status(hipGetLastError());
         }
     }
@@ -229,6 +230,7 @@ template <class Fn, class T, class Plan, int NC, class Body, int MINB = 1> int l
         const unsigned gd = dyn_grid(full);
         if (a.multi->pod.total >= 8LL * gd) {
             RD_LAUNCH(kern, dim3(gd), dim3(threads), lds, a.stream, fn, to_multi_batch<T>(*a.multi), a.sched);
+                last_kernel().dyn = true;
             return hip_status(hipGetLastError());
         }
     }

@@ -493,7 +493,7 @@ static void pack_params(const JitModel& M, int dtype, std::vector<unsigned char>
     else { buf.resize(np * 4); std::vector<float> p(np, 0.0f); for (int i = 0; i < M.np; ++i) p[i] = (float)M.params[i]; std::memcpy(buf.data(), p.data(), np * 4); }
 }
 static int launch(JitModel& M, JitKernel* k, unsigned grid, hipStream_t s, void** args) {
-    rd::last_kernel() = rd::LastKernel{nullptr, k->fn};
+    rd::last_kernel() = rd::LastKernel{nullptr, k->fn, false};
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, k->block, 1, 1, (unsigned)k->lds, s, args, nullptr) != hipSuccess) { M.err = "hipModuleLaunchKernel failed"; return RDHIP_ERR_HIP; }
     return RDHIP_OK;
 }

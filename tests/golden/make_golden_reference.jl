@@ -295,6 +295,31 @@ function err_case(tag)
     npzwrite(joinpath(HERE, "ref_err_$tag.npz"), out)
 end
 
+# ------------------------------------------------------------------------------------------------ errmap_* : state_diff(model, x, x0, errmap) (src/liestate.jl:26-32,216-217)
+# tests/golden/make_golden_round6.py's inputs; keys dX_cayley, dX_exponential, dX_mrp, dX_quatvec, dX_identity (NaN where the reference throws: IdentityMap of a
+# QuatRotation state does not fit a three-element RotationError)
+function errmap_case(tag)
+    d = npzread(joinpath(HERE, "errmap_$tag.npz"))
+    P = Tuple(Int.(d["P"]))
+    model = LG{rot_type(d),P}()
+    X, X0 = d["X"], d["X0"]
+    N, n = size(X); e = RD.errstate_dim(model)
+    out = Dict{String,Any}("X" => X, "X0" => X0, "P" => d["P"], "rot" => d["rot"])
+    for (key, emap) in (("cayley", Rotations.CayleyMap()), ("exponential", Rotations.ExponentialMap()), ("mrp", Rotations.MRPMap()), ("quatvec", Rotations.QuatVecMap()),
+                        ("identity", Rotations.IdentityMap()))
+        dX = fill(NaN, N, e)
+        try
+            for k = 1:N
+                dX[k, :] = RD.state_diff(model, SVector{n}(X[k, :]), SVector{n}(X0[k, :]), emap)
+            end
+        catch err
+            dX .= NaN
+        end
+        out["dX_$key"] = dX
+    end
+    npzwrite(joinpath(HERE, "ref_errmap_$tag.npz"), out)
+end
+
 # ------------------------------------------------------------------------------------------------ nab_* : ∇errstate_jacobian! of LieState{MRP | RodriguesParam, P} (src/liestate.jl:300-320)
 function nab_case(tag)
     d = npzread(joinpath(HERE, "nab_$tag.npz"))
@@ -521,6 +546,7 @@ function main()
     foreach(exp_case, [replace(basename(f), r"^exp_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "exp_") && endswith(f, ".npz")])
     foreach(err_case, [replace(basename(f), r"^err_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "err_") && endswith(f, ".npz")])
     foreach(nab_case, [replace(basename(f), r"^nab_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "nab_") && endswith(f, ".npz")])
+    foreach(errmap_case, [replace(basename(f), r"^errmap_|\.npz$" => "") for f in readdir(HERE) if startswith(f, "errmap_") && endswith(f, ".npz")])
     three_param_case(MRP{Float64}, "mrp")
     three_param_case(RodriguesParam{Float64}, "rp")
     foreach(implicit_case, ["cartpole", "satellite_world", "quadrotor_world", "di2"])

@@ -149,7 +149,7 @@ def test_rollout_split_equals_the_packed_rollout(shape, tm, dtype):
                 U = torch.as_tensor(lay(data[:, :K - 1, n:]).astype(dtype)).cuda().contiguous()
                 RD.rollout_split_(RD.StaticReturn(), fun, X, U, st["t"], st["dt"], x0=x0d, time_major=tm)
                 if K > 1:
-                    assert "rollout_split_kernel" in RD.last_kernel_name()
+                    assert "rollout_split_lane_kernel" in RD.last_kernel_name()
                 assert torch.equal(X, ref), f"{type(model).__name__} {rule.__name__} M={M} K={K} tm={tm} x0={with_x0}: max diff {float((X - ref).abs().max())}"
                 if M <= 130 and dtype == np.float64:
                     Zr = om.rollout(orule, data, tt, dts, X0=x0)

@@ -221,6 +221,29 @@ def rollout_case(name, model, M, K, rule, dtype, reps, rng, tm=False):
     emit(name + (" (time-major)" if tm else ""), M * K, "f64" if T == 8 else "f32", us, M * K * ((n + m) * T + 16 + n * T), {"trajectories": M, "knots": K})
 
 
+def rollout_split_case(name, model, M, K, rule, dtype, reps, rng, tm=True):
+    """rdhip_rollout_split (states and controls in arrays of their own) beside rdhip_rollout on the packed stack, same inputs, same box: algorithmic bytes =
+    read u, t, dt; write x"""
+    n, m = RD.state_dim(model), RD.control_dim(model)
+    T = 8 if dtype == np.float64 else 4
+    Zn = (rigid_inputs(M * K, m, rng) if n == 13 else rng.random((M * K, n + m))).astype(dtype)
+    shape = (K, M) if tm else (M, K)
+    data = torch.from_numpy(Zn.reshape(*shape, n + m)).to(DEV)
+    tk = np.arange(K) * 0.01
+    t = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tk[:, None] if tm else tk[None, :], shape))).to(DEV)
+    dt = torch.full(shape, 0.01, dtype=torch.float64, device=DEV)
+    fun = RD.DiscretizedDynamics(model, rule)
+    X = torch.empty(shape + (n,), dtype=data.dtype, device=DEV)
+    x0 = (data[0, :, :n] if tm else data[:, 0, :n]).contiguous()
+    U = (data[:K - 1, :, n:] if tm else data[:, :K - 1, n:]).contiguous()
+    alg = M * (K - 1) * (m * T + 16 + n * T) + M * n * T
+    us = timed(lambda i: RD.rollout_split_(RD.StaticReturn(), fun, X, U, t, dt, x0=x0, time_major=tm), reps, warm=2)
+    emit(name + " rollout_split" + (" (time-major)" if tm else " (trajectory-major)"), M * K, "f64" if T == 8 else "f32", us, alg, {"trajectories": M, "knots": K, "entry_point": "rdhip_rollout_split"})
+    us = timed(lambda i: RD.rollout_(RD.StaticReturn(), fun, {"data": data, "t": t, "dt": dt}, time_major=tm), reps, warm=2)
+    emit(name + " rollout on the packed stack, same algorithmic bytes" + (" (time-major)" if tm else " (trajectory-major)"), M * K, "f64" if T == 8 else "f32", us, alg,
+         {"trajectories": M, "knots": K, "entry_point": "rdhip_rollout_layout"})
+
+
 def rollout_jacobian_case(name, model, M, K, rule, dtype, reps, rng):
     """forward pass + linearisation: (a) rollout_ then jacobian_ (two calls), (b) rollout_jacobian_ (one call), trajectory- and time-major"""
     n, m = RD.state_dim(model), RD.control_dim(model)
@@ -398,6 +421,14 @@ def main():
         rollout_case("cartpole RK4 rollout fp64 262144 traj x 32 knots", cart, 262144, 32, RD.RK4, f64, 5, rng, tm=True)
         rollout_jacobian_case("satellite RK4 4096 traj x 101 knots", sat, 4096, 101, RD.RK4, f64, 10, rng)
         rollout_jacobian_case("C5 satellite fp32 512 traj x 256 knots", sat, 512, 256, RD.RK4, f32, 10, rng)
+        return
+    if a.only == "split":
+        for tm in (True, False):
+            rollout_split_case("satellite RK4 fp64 32768 traj x 32 knots", sat, 32768, 32, RD.RK4, f64, 20, rng, tm=tm)
+            rollout_split_case("satellite RK4 fp64 262144 traj x 16 knots", sat, 262144, 16, RD.RK4, f64, 10, rng, tm=tm)
+            rollout_split_case("cartpole RK4 fp64 262144 traj x 32 knots", cart, 262144, 32, RD.RK4, f64, 10, rng, tm=tm)
+            rollout_split_case("satellite RK4 fp32 65536 traj x 32 knots", sat, 65536, 32, RD.RK4, f32, 10, rng, tm=tm)
+        rollout_split_case("satellite RK4 fp64 4096 traj x 101 knots (a latency-sized batch)", sat, 4096, 101, RD.RK4, f64, 10, rng, tm=True)
         return
     if a.only == "c5full":
         c5_case(10, rng, M=4096)

@@ -6,7 +6,8 @@ compiler-only barrier, then agent-scope loads; relies on in-order load issue per
 exercise that for a few hundred launches; this runs it for `launches` (default 100 000) over the shapes whose tiles SHARE 128-byte lines (M = 66 / 130 /
 4 094 trajectories, K = 37 / 101 knots), fp32 and fp64, both layouts, with 3 .. 192 Jacobian workgroups (RDHIP_TUNE fused_jac_workgroups), and checks
 EVERY launch on the device:
-  * the simulated states equal rdhip_rollout's bit for bit,
+  * the simulated states equal rdhip_rollout's bit for bit in the one-launch form (to rounding, and bit for bit from launch to launch, where the call runs as
+    two launches or in pipelined pieces),
   * the Jacobians equal the FIRST launch's bit for bit (a stale read of any state changes bits) -- and that first result is held to rdhip_jacobian's on
     the simulated states at 1e-14 (fp64) / 2e-6 (fp32) relative, the tolerance of tests/test_gpu_round4.py.
 Before every launch the states of knots 2 .. K are overwritten with NaN, so a consumer that reads a state too early cannot find last launch's value.
@@ -46,7 +47,7 @@ def run(M, K, dtype, tm, launches, rng):
     else:
         init[:, 1:, :n] = float("nan")
     st = {"data": init.clone(), "t": torch.as_tensor(lay(tk)).cuda(), "dt": torch.as_tensor(lay(dk)).cuda()}
-    RD.rollout_(sig, fun, st, time_major=tm)
+    RD.rollout_(sig, fun, st, time_major=tm)                 # (64 groups and fewer: the fused kernel's own rollout role -- the same waves, the same bits)
     ref_states = st["data"].clone()
     flat = RD.PackedTrajectory(n, m, ref_states.reshape(M * K, n + m), st["t"].reshape(-1), st["dt"].reshape(-1))
     Jref = RD.alloc_jacobians(fun, M * K, init)
@@ -61,14 +62,21 @@ def run(M, K, dtype, tm, launches, rng):
         J.fill_(float("nan"))
         k = RD.rollout_jacobian_(sig, AD, fun, J, st, None, time_major=tm)
         fused += 1 if k == 1 else 0
-        if not torch.equal(st["data"], ref_states):
+        if k == 1 and not torch.equal(st["data"], ref_states):            # the one-launch form: the same rollout waves as rdhip_rollout, the same bits
             return {"M": M, "K": K, "dtype": str(np.dtype(dtype)), "time_major": tm, "launch": it, "error": "states differ from rdhip_rollout",
                     "max_diff": float((st["data"] - ref_states).abs().nan_to_num(nan=1e30).max())}
         if first is None:
+            first_states = st["data"].clone()
+            # (two launches / pipelined pieces: a piece boundary moves steps between the cascade kernel's chunk loop and its tail, two compilations of the
+            # same step -- rounding-level differences from rdhip_rollout, identical from launch to launch)
+            if not torch.allclose(first_states, ref_states, rtol=1e-12 if dtype == np.float64 else 1e-5, atol=1e-13 if dtype == np.float64 else 1e-6, equal_nan=False):
+                return {"M": M, "K": K, "dtype": str(np.dtype(dtype)), "time_major": tm, "launch": it, "error": "states differ from rdhip_rollout beyond rounding"}
             first = J.clone()
             rel = float(((first - Jref).abs().max() / Jref.abs().max()).item())
             if not rel <= (1e-14 if dtype == np.float64 else 2e-6):
                 return {"M": M, "K": K, "dtype": str(np.dtype(dtype)), "time_major": tm, "launch": it, "error": "Jacobians differ from rdhip_jacobian", "rel": rel}
+        elif not torch.equal(st["data"], first_states):
+            return {"M": M, "K": K, "dtype": str(np.dtype(dtype)), "time_major": tm, "launch": it, "error": "states differ from the first launch"}
         elif not torch.equal(J, first):
             bad = (J != first) | torch.isnan(J)
             return {"M": M, "K": K, "dtype": str(np.dtype(dtype)), "time_major": tm, "launch": it, "error": "Jacobians differ from the first launch", "entries": int(bad.sum())}
