@@ -511,15 +511,28 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
     // one flag word per 64-knot tile when the context has enough of them (written unconditionally by the register kernel: no memset)
     const int tile_flags = (mode != 3 && (long long)gridr <= IMPLICIT_FLAG_WORDS) ? (1 | (a.epoch << 8)) : 0;
     constexpr size_t lds_reg = ImplicitRegOps<Mdl, T>::LDS_BYTES;
-    if (a.flag && !reg_is_exact) {
-        if (!tile_flags && hipMemsetAsync(a.flag, 0, sizeof(int), a.stream) != hipSuccess) return RDHIP_ERR_HIP;
-        gate = a.flag;
-    }
+    if (!a.flag) return RDHIP_ERR_INVALID_ARG;                       // (api.hip hands the context's flag words to every Newton call)
+    if constexpr (reg_is_exact) {
+        // small models: the register kernel exchanges rows for real, so there is no LDS pass behind it (round 6: the 42 instantiations of the LDS
+        // kernels these models carried were never launched -- profiles/r06/kernel_reach.txt -- and are no longer built)
+        if (mode == 3) {
+            if (a.K == 0) return RDHIP_OK;
+            RD_LAUNCH((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
+        } else if (mode == 1) {
+            RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
+        } else {
+            RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
+        }
+        (void)gate; (void)gridn; (void)nblk;
+        return hip_status(hipGetLastError());
+    } else {
+    if (!tile_flags && hipMemsetAsync(a.flag, 0, sizeof(int), a.stream) != hipSuccess) return RDHIP_ERR_HIP;
+    gate = a.flag;
     if (mode == 3) {          // rollout: a.N trajectories of a.K knot points
         if (a.K == 0) return RDHIP_OK;
         if constexpr (Cascade<Mdl>::NB > 1) {
             // one wavefront per cascade block + the IO wavefront, every wave solving its block of the implicit equation per step (ImplicitRollFun)
-            if (a.flag && tune_knobs().rollout != 'p' && a.K < (1LL << 26) && a.N < (1LL << 26)) {      // (tuning switch rollout=plain keeps one lane per trajectory)
+            if (tune_knobs().rollout != 'p' && a.K < (1LL << 26) && a.N < (1LL << 26)) {      // (tuning switch rollout=plain keeps one lane per trajectory)
                 using RFn = ImplicitRollFun<Mdl>;
                 using Cas = Cascade<Mdl>;
                 constexpr size_t ldsr = CascadeLds<RFn, Cas, 4>::BYTES;
@@ -533,8 +546,7 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 return hip_status(hipGetLastError());
             }
         }
-        if (a.flag) RD_LAUNCH((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
-        if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
+        RD_LAUNCH((implicit_rollout_reg_kernel<Mdl, T>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, a.flag);
         auto kern = implicit_rollout_kernel<Mdl, T>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
         RD_LAUNCH(kern, dim3((unsigned)nblk), dim3(TILE), lds, a.stream, m, a.K, a.N, (T*)a.Z, a.t, a.dt, (const T*)a.X0, a.newton_iters, a.newton_tol, gate);
@@ -546,9 +558,9 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
         constexpr int NZ = Mdl::NX + Mdl::NU;
         using IFn = IftFun<Mdl>;
         using IPlan = typename IftPlanOf<Mdl>::Plan;
-        if constexpr (!reg_is_exact && NZ > 10 && SplitLds<IFn, T, IPlan, 4>::BYTES <= 160 * 1024) {
+        if constexpr (NZ > 10 && SplitLds<IFn, T, IPlan, 4>::BYTES <= 160 * 1024) {
             const char ift_mode = tune_knobs().ift;                        // tuning switches: 'r' = the one-kernel register path, '3' = Newton kernel + tile kernel + gated exact kernel (round 2)
-            if (a.flag && aligned16(a.J) && ift_mode != 'r') {
+            if (aligned16(a.J) && ift_mode != 'r') {
                 // ONE launch: the tile kernel's compute waves run the Newton solve themselves, x_next leaves through the tile loop's f(z) slab, and the
                 // tiles that need the exact solve are redone by their own workgroup behind the loop (implicit.hpp IftBody)
                 if (aligned16(a.Y) && (long long)gridr <= IMPLICIT_FLAG_WORDS && ift_mode != '3')
@@ -565,19 +577,18 @@ template <class Mdl> int launch_implicit(const Mdl& m, int mode, const LaunchArg
                 return hip_status(hipGetLastError());
             }
         }
-        if (a.flag) RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
-        if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
+        RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, true>), dim3(gridr), dim3(TILE), lds_reg, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         auto kern = implicit_midpoint_kernel<Mdl, T, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
         RD_LAUNCH(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)a.J, a.newton_iters, a.newton_tol, gate, tile_flags);
     } else {
-        if (a.flag) RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
-        if (a.flag && reg_is_exact) return hip_status(hipGetLastError());
+        RD_LAUNCH((implicit_midpoint_reg_kernel<Mdl, T, false>), dim3(gridr), dim3(TILE), 0, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, a.flag, tile_flags);
         auto kern = implicit_midpoint_kernel<Mdl, T, false>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
         RD_LAUNCH(kern, dim3(gridn), dim3(TILE), lds, a.stream, m, a.N, (const T*)a.Z, a.t, a.dt, (T*)a.Y, (T*)nullptr, a.newton_iters, a.newton_tol, gate, tile_flags);
     }
     return hip_status(hipGetLastError());
+    }
 }
 template <template <class> class MT> int dispatch_implicit(const ModelDesc& md, int mode, int dtype, const LaunchArgs& a) {
     if (dtype == RDHIP_F64) return launch_implicit(MT<double>::make(md.params), mode, a);

@@ -1502,7 +1502,16 @@ def test_streaming_rollout_of_big_batches(case):
             got = host(stack["data"]).astype(np.float64)
             got = got.transpose(order) if tm else got
             if f32:
-                np.testing.assert_allclose(got[:, :, :n], ref[:, :, :n], rtol=2e-4, atol=2e-4)
+                if not np.allclose(got[:, :, :n], ref[:, :, :n], rtol=2e-4, atol=2e-4):
+                    # (round 6: this comparison failed ONCE, under rocprofv3, and 1 600 launches of the same case did not reproduce it
+                    # -- tools/repro_rollout_flake.py; say where it differs and whether a second read of the device memory differs too)
+                    bad = ~np.isclose(got[:, :, :n], ref[:, :, :n], rtol=2e-4, atol=2e-4)
+                    again = host(stack["data"]).astype(np.float64)
+                    again = again.transpose(order) if tm else again
+                    pytest.fail(f"time_major={tm} x0={with_x0}: {int(bad.sum())} values differ in trajectories {sorted(set(np.nonzero(bad)[0].tolist()))[:40]}, "
+                                f"knots {sorted(set(np.nonzero(bad)[1].tolist()))}; exact zeros among them: {int((got[:, :, :n][bad] == 0).sum())}; a second read of the "
+                                f"device memory differs from the oracle in {int((~np.isclose(again[:, :, :n], ref[:, :, :n], rtol=2e-4, atol=2e-4)).sum())} values; "
+                                f"kernel {RD.last_kernel_name()}")
                 np.testing.assert_array_equal(got[:, :, n:], cast(data[:, :, n:]).astype(np.float64))
             else:
                 np.testing.assert_allclose(got[:, :, :n], ref[:, :, :n], rtol=0, atol=TOL)
@@ -1707,7 +1716,8 @@ def test_mixed_model_rollouts_and_jacobians_in_one_call(prec):
             assert abs(sums[p] - float(J1.double().sum())) <= 1e-9 * max(1.0, abs(sums[p]))
 
 
-@pytest.mark.parametrize("variant", ["satellite_quat", "quadrotor_quat", "satellite_mrp", "quadrotor_rp", "satellite_quat_f32"])
+@pytest.mark.parametrize("variant", ["satellite_quat", "quadrotor_quat", "satellite_mrp", "quadrotor_rp", "satellite_quat_f32", "quadrotor_quat_f32", "satellite_mrp_f32",
+                                     "quadrotor_rp_f32"])
 def test_wrenches_and_wrench_jacobian(variant):
     """wrenches(model, x, u, t) = [forces; moments] and d wrenches / d z (src/rigidbody.jl:244-248; wrench_jacobian!, :315-320) for every knot point
     of a batch against the oracle's forward duals (which tests/test_oracle_kat.py holds to test/rigidbody_test.jl:26-46's closed form): ragged

@@ -377,15 +377,15 @@ def test_sweep_rollout_and_rollout_jacobian(name, dname):
             assert_periodic(got, Zr[:, :, :c.n], atol, rtol, f"{name}/{dname} rollout_split {rule.__name__} M={M} K={K} time_major={tm}")
         # an initial state of its own (x0) and the Jacobians along the rollout in the same call
         for tm in (False, True):
-            M, K = 70, 9
+            M, K = 72, 9                                              # (a multiple of 4: the fp32 time-major one-launch form wants 16-byte aligned rows of tiles)
             st, Zb, tb, dtb = _stack(c, M, K, tm, seed=11)
-            x0 = Zb[:, 0, :c.n] * 0.5 + 0.25 * Zb[:, 1, :c.n]
+            x0 = tile_rows(Zb[:, 0, :c.n] * 0.5 + 0.25 * Zb[:, 1, :c.n], M)
             if name.startswith(("sat_", "quad_")) and ROTCODE[c.model.rotation] == 0:
                 x0[:, 3:7] /= np.linalg.norm(x0[:, 3:7], axis=1, keepdims=True)
             x0 = x0.astype(c.T).astype(np.float64)
-            Zr = c.om.rollout(ORULE[rule], Zb, tb, dtb, X0=x0)
-            Jo, _ = c.om.jacobian(ORULE[rule], O.FORWARD_AD, Zr.reshape(M * K, nz), tb.reshape(-1), dtb.reshape(-1))
-            Jo = Jo.reshape(M, K, c.n, nz)
+            Zr = c.om.rollout(ORULE[rule], Zb, tb, dtb, X0=x0[:Zb.shape[0]])
+            Jo, _ = c.om.jacobian(ORULE[rule], O.FORWARD_AD, Zr.reshape(-1, nz), tb.reshape(-1), dtb.reshape(-1))
+            Jo = Jo.reshape(Zb.shape[0], K, c.n, nz)
             J = RD.alloc_jacobians(fun, M * K, st["data"]); J.fill_(float("nan"))
             launches = RD.rollout_jacobian_(SIG, RD.ForwardAD(), fun, J, st, x0=torch.as_tensor(x0.astype(c.T)).cuda(), time_major=tm); c.note()
             assert launches >= 1
@@ -443,3 +443,89 @@ def test_sweep_implicit_midpoint(name, dname):
         RD.rollout_(SIG, fun, st); c.note()
         s = max(1.0, float(np.abs(Zr).max()))
         assert_periodic(st["data"], Zr, *((5e-4 * s, 5e-4) if c.f32 else (1e-8 * s, 0.0)), f"{name}/{dname} implicit rollout M={M}")
+        if M == 70:
+            # the one-lane-per-trajectory form (RDHIP_TUNE rollout=plain; what stacks of 2^26 knots and more take): for the rigid bodies a different
+            # pair of kernels from the cascade form above
+            st2, _, _, _ = _stack(c, M, K, False, seed=17)
+            RD.tune("rollout=plain")
+            try:
+                RD.rollout_(SIG, fun, st2); c.note()
+            finally:
+                RD.tune("reset")
+            assert_periodic(st2["data"], Zr, *((5e-4 * s, 5e-4) if c.f32 else (1e-8 * s, 0.0)), f"{name}/{dname} implicit rollout, rollout=plain, M={M}")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the mixed-model batch as ONE launch (csrc/mixed.hpp): satellite + cartpole under RK3 / RK4, fp32 / fp64, both placements of the cartpole's rollout
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dname", ["f64", "f32"])
+@pytest.mark.parametrize("rule", [RD.RK3, RD.RK4])
+def test_sweep_mixed_model_call_in_one_launch(rule, dname):
+    ca, cb = case_of("sat_wd", dname), case_of("cartpole", dname)
+    for idle in (0, 1):
+        for MA, MB, K in ((132, 200, 9), (64, 64, 5)):
+            RD.tune(f"mixed_idle={idle}")
+            try:
+                sa, Za, ta, da = _stack(ca, MA, K, True, seed=23)
+                sb, Zb, tb, db = _stack(cb, MB, K, True, seed=29)
+                funs = [RD.DiscretizedDynamics(ca.model, rule), RD.DiscretizedDynamics(cb.model, rule)]
+                Js = [RD.alloc_jacobians(funs[0], MA * K, sa["data"]).fill_(float("nan")), RD.alloc_jacobians(funs[1], MB * K, sb["data"]).fill_(float("nan"))]
+                call = RD.PreparedRolloutJacobianMulti(SIG, RD.ForwardAD(), funs, Js, [sa, sb], None, time_major=True)
+                call()
+                assert call.launches == 1 and "rollout_jac_mixed_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
+                ca.note()
+            finally:
+                RD.tune("reset")
+            for c, st, Zbase, tbase, dbase, J, M in ((ca, sa, Za, ta, da, Js[0], MA), (cb, sb, Zb, tb, db, Js[1], MB)):
+                nz = c.n + c.m
+                Zr = c.om.rollout(ORULE[rule], Zbase, tbase, dbase)
+                s = max(1.0, float(np.abs(Zr).max()))
+                assert_periodic(st["data"].transpose(0, 1), Zr, *((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0)), f"mixed {c.name}/{dname} states {rule.__name__} idle={idle} M={M}")
+                Jo, _ = c.om.jacobian(ORULE[rule], O.FORWARD_AD, Zr.reshape(-1, nz), tbase.reshape(-1), dbase.reshape(-1))
+                Jo = Jo.reshape(Zbase.shape[0], K, c.n, nz)
+                sj = max(1.0, float(np.abs(Jo).max()))
+                assert_periodic(J.reshape(K, M, c.n, nz).transpose(0, 1), Jo, *((1e-3 * sj, 1e-3) if c.f32 else (1e-10 * sj, 0.0)), f"mixed {c.name}/{dname} Jacobians {rule.__name__} idle={idle} M={M}")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the error-state kernels in fp32 (csrc/errstate.hip): every branch of rdhip_errstate_jacobian / rdhip_state_diff / rdhip_nabla_errstate_jacobian
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["sat_wd", "quad_mrp_b", "sat_rp_b", "cartpole"])
+def test_sweep_error_state_kernels_fp32(name):
+    c = case_of(name, "f32")
+    n, e, N = c.n, RD.errstate_dim(c.model), 203
+    X = c.Z[:, :n].astype(np.float32)
+    Xd = torch.as_tensor(X).cuda()
+    Go = c.om.errstate_jacobian(X.astype(np.float64))
+    pattern = Go != 0
+    for aligned in (True, False):                               # (an output that does not start on a 16-byte boundary takes the per-entry kernels)
+        for clear in (True, False):
+            buf = torch.full((N * n * e + 1,), 7.0, dtype=torch.float32, device="cuda")
+            G = buf[(0 if aligned else 1):][:N * n * e].view(N, e, n).transpose(1, 2)
+            RD.errstate_jacobian_(c.model, G, Xd, clear=clear); c.note()
+            Gh = G.cpu().numpy().astype(np.float64)
+            if clear or name == "cartpole":                     # (EuclideanState: always the whole identity, src/statevectortype.jl:149-155)
+                np.testing.assert_allclose(Gh, Go, rtol=0, atol=2e-6, err_msg=f"{name} errstate_jacobian clear aligned={aligned}")
+            else:
+                np.testing.assert_allclose(Gh[pattern], Go[pattern], rtol=0, atol=2e-6, err_msg=f"{name} errstate_jacobian pattern aligned={aligned}")
+                if name == "sat_wd":                            # the quaternion pattern kernel touches nothing else
+                    assert np.all(Gh[~pattern] == 7.0)
+    if name == "cartpole":
+        return
+    X0 = np.roll(X, 1, axis=0)
+    # state_diff: contiguous states (the tile kernel) and states that are columns of a wide array (leading dimension 40: the per-entry kernel)
+    do = c.om.state_diff(X.astype(np.float64), X0.astype(np.float64))
+    ok = np.abs(do).max(axis=1) < 30.0                          # (Cayley v / w near w = 0: ill-conditioned in fp32, tests/test_gpu_round6.py)
+    got = RD.state_diff(c.model, Xd, torch.as_tensor(X0).cuda()); c.note()
+    np.testing.assert_allclose(got.cpu().numpy().astype(np.float64)[ok], do[ok], rtol=2e-4, atol=2e-5)
+    wide, wide0 = torch.zeros((N, 40), dtype=torch.float32, device="cuda"), torch.zeros((N, 40), dtype=torch.float32, device="cuda")
+    wide[:, :n] = Xd; wide0[:, :n] = torch.as_tensor(X0).cuda()
+    got = RD.state_diff(c.model, wide[:, :n], wide0[:, :n]); c.note()
+    np.testing.assert_allclose(got.cpu().numpy().astype(np.float64)[ok], do[ok], rtol=2e-4, atol=2e-5)
+    # nabla errstate Jacobian
+    Xb = np.roll(X, 2, axis=0)
+    Ho = c.om.nabla_errstate_jacobian(X.astype(np.float64), Xb.astype(np.float64))
+    for clear in (True, False):
+        dG = torch.zeros((N, e, e), dtype=torch.float32, device="cuda").transpose(1, 2)
+        RD.nabla_errstate_jacobian_(c.model, dG, Xd, torch.as_tensor(Xb).cuda(), clear=clear); c.note()
+        np.testing.assert_allclose(dG.cpu().numpy().astype(np.float64), Ho, rtol=2e-5, atol=2e-5, err_msg=f"{name} nabla clear={clear}")
