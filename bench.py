@@ -268,7 +268,7 @@ def secondary_metrics(dev, reps):
         try:                                                      # round 5's form of the same call (the satellite's fused launch + the cartpole in four pipelined pieces on a second stream), same process
             RD.tune("mixed=0")
             us5 = _timed_us(lambda i: c5(), 20, warm=2)
-            res["streams_form_round5"] = {"us_per_call": us5, "frac_of_hbm_peak": alg / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_launches_per_call": c5.launches, "how": "RDHIP_TUNE mixed=0"}
+            res["streams_form_round5"] = {"us_per_call": us5, "frac_of_hbm_peak": alg / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_launches_per_call": 9, "launches_counted_in": "profiles/r05/c5_whole_timeline.txt (1 on the context's stream, 8 on the internal one)", "how": "RDHIP_TUNE mixed=0"}
         finally:
             RD.tune("reset")
         pr = _pmc_rows("c5_whole_one_call_fp32") if Mc == 4096 else {}

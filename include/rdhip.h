@@ -111,6 +111,7 @@ void* rdhip_ctx_stream(rdhip_ctx* ctx);
  *   rollout=plain|cascade|stream   force a rollout kernel where it applies
  *   rolljac=split            rdhip_rollout_jacobian always as two launches
  *   fused_ratio=x, fused_jac_workgroups=N, fused_tj_max_knots=N, rolljac_pipe_min_knots=N, multi_main=i     shape of the one-launch rollout -> Jacobians forms
+ *   fused_two_per_cu=0       the fp32 one-launch forms keep one workgroup per compute unit (the form of rounds 4-5; default: two where the Jacobians bound the launch)
  *   mixed=0, mixed_idle=0|1  rdhip_rollout_jacobian_multi: never the one-launch form of a (satellite, cartpole) pair / where the cartpole's rollout runs in it
  *   ift=reg|3                ImplicitMidpoint Jacobians: the one-kernel register path / the three-launch path of round 2
  * Not tuning, and still their own environment variables: RDHIP_DRY_RUN (contexts without a device: queries only), RDHIP_VERBOSE (reports fall-backs on

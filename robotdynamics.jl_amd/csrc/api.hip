@@ -155,6 +155,7 @@ static int parse_tune(rd::TuneKnobs& k, const char* s, std::string* bad) {
         else if (key == "multi_main") k.multi_main = val.empty() ? -1 : (int)iv;
         else if (key == "ift") k.ift = val.empty() ? 0 : val[0];
         else if (key == "mixed") k.mixed = !(val == "0");
+        else if (key == "fused_two_per_cu") k.fused_two_per_cu = !(val == "0");
         else if (key == "mixed_idle") k.mixed_idle = val.empty() ? -1 : (int)iv;
         else { if (bad) *bad = key; return RDHIP_ERR_INVALID_ARG; }
     }
@@ -658,25 +659,38 @@ static int family_rolljac(const ModelDesc& d, int rule, int diff, int dtype, con
 // model per call (the others run their two launches, whose workgroups wait for nobody, beside it).  Not covered: launches replayed from captured
 // graphs and other processes on the same GPU (rdhip.h says so).
 static std::mutex g_fused_mu;
-// Per device: an event recorded BEHIND the last fused launch on the stream that issued it -- at launch time, when that stream is alive by construction --
-// and who issued it (context serial + stream handle, compared only, never used).  The next fused launch from anybody else waits for the event; the same
-// issuer's next launch follows in stream order and waits for nothing.  Round 5 kept the raw stream instead and recorded on it LATER, from the next
+// Per device: who issued the last fused launch (context serial + stream handle, compared only, never used) and an event recorded BEHIND it on the
+// stream that issued it -- at launch time, when that stream is alive by construction.  The next fused launch from anybody else waits for the event; the
+// same issuer's next launch follows in stream order and waits for nothing.  Round 5 kept the raw stream instead and recorded on it LATER, from the next
 // launcher's call: a borrowed stream destroyed in between was undefined behaviour that rdhip.h could only forbid.  An event outlives
-// the stream it was recorded on.  (Cost: one marker packet behind a launch of 100 us and more; handle reuse -- a new stream at a destroyed one's address --
-// is why the context's serial is part of the identity.)
+// the stream it was recorded on.  (Handle reuse -- a new stream at a destroyed one's address -- is why the context's serial is part of the identity.)
+// The marker packet costs a stream of back-to-back fused launches 4 us per launch (profiles/r06/c5_whole_timeline.txt: 5.8 us from the end of one 250-us
+// launch to the start of the next, 1.4 us without), so an issuer that has had the device to itself for FUSED_EVENT_RUN launches stops recording; if
+// somebody else then turns up, that launch finds no event to wait for and waits for the whole device instead, once (hipDeviceSynchronize -- every stream,
+// alive or destroyed), and events are recorded again for the next FUSED_EVENT_RUN launches.  A process with one context and one stream, the usual case,
+// pays for 8 markers; two issuers that alternate (rdhip_ctx_set_overlap) keep their events.
+constexpr int FUSED_EVENT_RUN = 8;
 static hipEvent_t g_fused_done[64] = {};
 static hipStream_t g_fused_stream[64] = {};
 static unsigned long long g_fused_serial[64] = {};
+static int g_fused_run[64] = {};              // launches in a row by the current issuer
+static bool g_fused_has_event[64] = {};       // the last launch was followed by an event
 static int spin_launch(rdhip_ctx* c, hipStream_t stream, bool capturing, const std::function<int()>& launch) {
     std::lock_guard<std::mutex> g(g_fused_mu);
     const int slot = c->device & 63;
-    if (!capturing && g_fused_serial[slot] && !(g_fused_serial[slot] == c->serial && g_fused_stream[slot] == stream)) {
-        if (hipStreamWaitEvent(stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP;
+    const bool same = g_fused_serial[slot] == c->serial && g_fused_stream[slot] == stream;
+    if (!capturing && g_fused_serial[slot] && !same) {
+        if (g_fused_has_event[slot]) { if (hipStreamWaitEvent(stream, g_fused_done[slot], 0) != hipSuccess) return RDHIP_ERR_HIP; }
+        else if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RDHIP_ERR_HIP;
     }
     const int k = launch();
     if (k == RDHIP_OK && !capturing) {
-        if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
-        if (hipEventRecord(g_fused_done[slot], stream) != hipSuccess) return RDHIP_ERR_HIP;
+        g_fused_run[slot] = same ? g_fused_run[slot] + 1 : 0;
+        g_fused_has_event[slot] = g_fused_run[slot] < FUSED_EVENT_RUN;
+        if (g_fused_has_event[slot]) {
+            if (!g_fused_done[slot] && hipEventCreateWithFlags(&g_fused_done[slot], hipEventDisableTiming) != hipSuccess) return RDHIP_ERR_HIP;
+            if (hipEventRecord(g_fused_done[slot], stream) != hipSuccess) return RDHIP_ERR_HIP;
+        }
         g_fused_stream[slot] = stream; g_fused_serial[slot] = c->serial;
     }
     return k;

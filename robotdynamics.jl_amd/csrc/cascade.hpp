@@ -28,11 +28,16 @@
 
 namespace rd {
 
+constexpr int CASCADE_COMPACT = 64;   // flag in the ring-depth template argument, see CascadeLds
 constexpr int CASCADE_CHUNK = 4;      // S: steps per IO chunk (even: the two upstream-stage buffers rotate inside a chunk)
 
 template <class Fn, class Cas, int R_> struct CascadeLds {
     using T = typename Fn::T;
-    static constexpr int NX = Fn::NX, NU = Fn::NU, NB = Cas::NB, NS = rule_stages<Fn::RULE_ID>(), R = R_, S = CASCADE_CHUNK;
+    // R_ = ring depth (+ CASCADE_COMPACT: the ring always [stage][component][lane] -- 28 instead of 48 KB for an fp32 rigid body, which is what lets
+    // TWO workgroups of the fused rollout -> Jacobians kernel share a compute unit, fused.hpp; the hand-off costs 3 % of the chain: 123 against 119.5 us
+    // for 4 096 x 256 satellite steps)
+    static constexpr int NX = Fn::NX, NU = Fn::NU, NB = Cas::NB, NS = rule_stages<Fn::RULE_ID>(), R = R_ & 63, S = CASCADE_CHUNK;
+    static constexpr bool COMPACT = (R_ & 64) != 0;
     static constexpr bool published(int i) { return Cas::block_of(i) < NB - 1; }
     static constexpr int pub_index(int i) { int p = 0; for (int j = 0; j < i; ++j) p += published(j) ? 1 : 0; return p; }
     static constexpr int NPUB = pub_index(NX);
@@ -47,7 +52,7 @@ template <class Fn, class Cas, int R_> struct CascadeLds {
     static constexpr size_t bytes_with(size_t ring_slot) {
         return a16_(R * ring_slot * sizeof(T)) + a16_(2 * (size_t)S * TILE * (NU | 1) * sizeof(T)) + 2 * (size_t)2 * S * TILE * sizeof(double) + a16_(2 * (size_t)S * TILE * (NX | 1) * sizeof(T)) + 64;
     }
-    static constexpr bool LANE_MAJOR = NPUB > 0 && bytes_with((size_t)NS * TILE * npp()) <= 160 * 1024;
+    static constexpr bool LANE_MAJOR = NPUB > 0 && !COMPACT && bytes_with((size_t)NS * TILE * npp()) <= 160 * 1024;
     static constexpr int NPP = LANE_MAJOR ? npp() : NPUB;
     static constexpr size_t RING_SLOT = (size_t)NS * TILE * NPP;             // elements per ring slot
     // element index of (stage s, published component p, lane l) inside a slot
@@ -62,7 +67,7 @@ template <class Fn, class Cas, int R_> struct CascadeLds {
     static_assert((R & (R - 1)) == 0, "ring depth must be a power of two");
     static_assert(S == 4 && NU <= 8 && NX <= 16, "IO lane groups: 8 lanes per control row, 16 per state row, 4 steps per chunk");
 };
-template <class Fn, class Cas, int B> struct CascadeHook {
+template <class Fn, class Cas, int B, int RC = 4> struct CascadeHook {
     using T = typename Fn::T;
     static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
     static constexpr int NB = Cas::NB;
@@ -70,7 +75,7 @@ template <class Fn, class Cas, int B> struct CascadeHook {
     static constexpr int pub_index(int i) { int p = 0; for (int j = 0; j < i; ++j) p += published(j) ? 1 : 0; return p; }
     static constexpr int NPUB = pub_index(NX);
     const T (&U)[NS][NX];                             // stage points of the upstream blocks (entries of other blocks are never touched)
-    using LL = CascadeLds<Fn, Cas, 4>;
+    using LL = CascadeLds<Fn, Cas, RC>;
     T __attribute__((address_space(3)))* slot;        // ring slot of this step, already offset by the lane (CascadeLds::ring_index / lane_offset)
     // this block's stage points go to the ring AS THEY ARE FORMED: the LDS writes (~29 cycles of LDS pipe per 16 B/lane instruction, measured)
     // then drain under the remaining arithmetic instead of queueing up behind it
@@ -135,7 +140,7 @@ RD_DEV void cascade_compute_wave_body(const Fn& fn, long long K, long long M, lo
     if constexpr (PUB) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): knot 0 is announced together with the first chunk (cascade_io_wave)
     if (K < 2) return;
     auto read_slot = [&](int step, T (&dst)[NS][NX]) {
-        LdsT slot = ring + (size_t)(step & (R - 1)) * L::RING_SLOT;
+        LdsT slot = ring + (size_t)(step & (L::R - 1)) * L::RING_SLOT;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -163,15 +168,15 @@ RD_DEV void cascade_compute_wave_body(const Fn& fn, long long K, long long M, lo
         int fl = 0;
         if constexpr (B < NB - 1) {
             // ring slot k mod R is free once the last wave holds step k - R: checked with the value of `cons` requested a step ago
-            if (__builtin_amdgcn_readfirstlane(cfc) < k - R + 1) {
-                do { __builtin_amdgcn_s_sleep(1); cfc = *cons; RD_LDS_DRAIN(); } while (__builtin_amdgcn_readfirstlane(cfc) < k - R + 1);
+            if (__builtin_amdgcn_readfirstlane(cfc) < k - L::R + 1) {
+                do { __builtin_amdgcn_s_sleep(1); cfc = *cons; RD_LDS_DRAIN(); } while (__builtin_amdgcn_readfirstlane(cfc) < k - L::R + 1);
             }
             RD_LDS_ORDER();
         }
         if constexpr (B > 0) { if (more) { fl = prod[B - 1]; RD_LDS_ORDER(); read_slot(k + 1, Un); } }
         if constexpr (B < NB - 1) cfc = *cons;
         __builtin_amdgcn_sched_barrier(0);                    // keep the requests above the arithmetic
-        CascadeHook<Fn, Cas, B> hk{Uc, ring + (size_t)(k & (R - 1)) * L::RING_SLOT + L::lane_offset(lane)};
+        CascadeHook<Fn, Cas, B, R> hk{Uc, ring + (size_t)(k & (L::R - 1)) * L::RING_SLOT + L::lane_offset(lane)};
         if constexpr (Fn::RULE_ID == RULE_IMPLICIT_MIDPOINT) fn.template block_step<Cas, B>(x, u, tk, (T)h, y, hk);      // implicit.hpp ImplicitRollFun
         else rk_hooked<Fn::RULE_ID>(fn.m, x, u, tk, (T)h, y, hk);
         // next step's upstream flag is LOOKED AT here, before the last writes -- lgkmcnt is a 4-bit counter: behind ~20 LDS instructions the

@@ -80,6 +80,7 @@ struct TuneKnobs {
     int multi_main = -1;                  // rdhip_rollout_jacobian_multi: the model that gets the fused launch (-1: the one with most Jacobian bytes)
     int mixed_idle = -1;                  // mixed_idle=0/1: the small model's rollout on workgroups of its own / on the idle waves of the other model's rollout workgroups (-1: by size)
     bool mixed = true;                    // mixed=0: rdhip_rollout_jacobian_multi never takes the one-launch form of a (satellite, cartpole) pair (mixed.hpp)
+    bool fused_two_per_cu = true;         // fused_two_per_cu=0: the fp32 one-launch forms never take their two-workgroups-per-CU kernel (fused.hpp fused_min_waves)
     char ift = 0;                         // ift=reg: the one-kernel register path; ift=3: Newton kernel + tile kernel + gated exact kernel (round 2)
 };
 TuneKnobs& tune_knobs_mut();              // api.hip

@@ -396,6 +396,24 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
                 long long sp = (long long)A; sp -= sp % G;
                 return sp < G ? 0 : sp;
             };
+            // fp32, a launch bound by its Jacobian workgroups (what the second part of the walk was built for): TWO workgroups per CU instead -- the kernel
+            // under 128 registers with the rollout role's ring in its compact layout (fused.hpp fused_min_waves, cascade.hpp CASCADE_COMPACT), G + (2 cus - G)
+            // workgroups, no second part.  4 096 x 256 satellite knots: 221-226 us with the best split -> 199-201 us.  Smaller launches, whose rollout chain
+            // is the critical path, keep the 256-register kernel (its chain is 3 % shorter).
+            if constexpr (sizeof(T) == 4 && (RULE == RULE_RK3 || RULE == RULE_RK4)) {         // (the rules the reference's users roll out with; Euler and RK2 keep the one form)
+                constexpr int RC = R | CASCADE_COMPACT;
+                using FL2 = FusedLds<Fn, T, Cas, RC, Plan, NC>;
+                static_assert(2 * FL2::BYTES <= 160 * 1024, "two workgroups of the compact fused kernel per CU");
+                // (time-major stacks only: a trajectory-major stack this large runs as pipelined pieces anyway, fused_tj_max_knots)
+                if (a.time_major && tune_knobs().fused_two_per_cu && !(ratio_env > 0) && nj_env < 1 && split_of(K * G, cus - G) > 0) {
+                    const long long nj = 2 * cus - G;
+                    auto kern = rollout_jac_fused_kernel<Fn, T, Cas, RC, Plan, NC, true>;
+                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+                    RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), FL2::BYTES, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                       a.progress, a.pbase, 0LL);
+                    return hip_status(hipGetLastError());
+                }
+            }
             if (a.time_major) {
                 auto kern = rollout_jac_fused_kernel<Fn, T, Cas, R, Plan, NC, true>;
                 if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;

@@ -33,10 +33,24 @@ template <class T, int RULE> static int launch_mixed(const ModelDesc& da, const 
     if ((GA + 1) * FUSED_PROGRESS_STRIDE > a.progress_words || 2 * (GA + GB) > cus) return RDHIP_ERR_UNSUPPORTED;
     if (KA * GA + 4 * cus >= (1LL << 32) || (KB * MBt + TILE - 1) / TILE >= (1LL << 31)) return RDHIP_ERR_UNSUPPORTED;
     if (a.probe) return RDHIP_OK;
-    auto kern = rollout_jac_mixed_kernel<FnA, T, Cas, R, Plan, NC, FnB>;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
     const long long ntiles = KA * GA;
     const long long nj = cus - GA - GB;
+    // fp32, a launch bound by A's Jacobian tiles: the two-per-CU form of the kernel (dispatch.hpp launch_rollout_jacobian_fused), 2 cus workgroups, no second part
+    if constexpr (sizeof(T) == 4) {
+        constexpr int RC = R | CASCADE_COMPACT;
+        using FL2 = FusedLds<FnA, T, Cas, RC, Plan, NC>;
+        static_assert(2 * FL2::BYTES <= 160 * 1024 && (FUSED_THREADS / TILE) * SmallLds<FnB, T>::WAVE_BYTES <= FL2::BYTES, "two workgroups of the compact mixed kernel per CU");
+        const double A2 = (double)nj * (double)(KA - 1) / 5.9;
+        if (tune_knobs().fused_two_per_cu && !(tune_knobs().fused_ratio > 0) && GA >= 8 && A2 < 0.85 * (double)ntiles) {
+            auto k2 = rollout_jac_mixed_kernel<FnA, T, Cas, RC, Plan, NC, FnB>;
+            if (ensure_dynamic_lds(reinterpret_cast<const void*>(k2), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+            RD_LAUNCH(k2, dim3((unsigned)(2 * cus)), dim3(FUSED_THREADS), FL2::BYTES, a.stream, FnA{MA::make(da.params)}, KA, MAt, (int)GA, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                      FnB{MB::make(db.params)}, KB, MBt, (int)GB, (T*)b.Z, b.t, b.dt, (const T*)b.X0, (T*)b.J, a.progress, a.pbase, 0LL);
+            return hip_status(hipGetLastError());
+        }
+    }
+    auto kern = rollout_jac_mixed_kernel<FnA, T, Cas, R, Plan, NC, FnB>;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return RDHIP_ERR_HIP;
     // the second part of the walk, sized as in launch_rollout_jacobian_fused (fp32: ratio 5.9 of rollout step to tile time; fp64: none)
     long long split = 0;
     {

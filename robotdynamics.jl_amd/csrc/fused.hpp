@@ -145,6 +145,11 @@ constexpr int FUSED_THREADS = 8 * TILE;
 // or 168 (3) -- it was 218 while the tile loop sat inside a two-trip loop over the two parts of the walk; its two roles need 130 (rollout) and 146
 // (Jacobian tile loop) on their own.  2 rather than 1: the hint also steers the scheduler, and the consumer role alone measured 4-5 us of 233 faster
 // with it (tune/tune_c5.hip shell_plain<1> / <2>).
+// (R carries CASCADE_COMPACT: the TWO-PER-CU form of the fp32 kernel -- 128 registers, the rollout role's ring in its compact layout, 78 KB of LDS.  Round 6:
+// a launch bound by its Jacobian workgroups (4 096 x 256: 64 rollout groups produce tiles twice as fast as 192 workgroups consume them) runs 64 + 448
+// workgroups instead of 64 + 192 -- every CU holds two tile loops, or one next to a rollout group whose chain leaves the CU idle most of the time -- and
+// needs no second part of the walk: 221 -> 199-201 us for the satellite half of BASELINE config 5, tune/tune_c5.hip -DRD_FUSED_F32_MINW=4.)
+template <class T, int R> constexpr int fused_min_waves() { return sizeof(T) == 4 ? ((R & CASCADE_COMPACT) ? 4 : Tune::FUSED_F32_MINW) : 1; }
 template <class Fn, class T, class Cas, int R, class Plan, int NC> struct FusedLds {
     static constexpr size_t ROLL = CascadeLds<Fn, Cas, R>::BYTES, JAC = SplitLds<Fn, T, Plan, NC>::BYTES + SPLIT_GATHER_EXTRA;
     static constexpr size_t BYTES = ROLL > JAC ? ROLL : JAC;
@@ -173,7 +178,7 @@ RD_DEV void fused_rollout_role(const Fn& fn, long long K, long long M, long long
     Tune::fused_stamp(1024 + blockIdx.x);
 }
 template <class Fn, class T, class Cas, int R, class Plan, int NC, bool TM = true>
-__global__ void __launch_bounds__(FUSED_THREADS, (sizeof(T) == 4 ? Tune::FUSED_F32_MINW : 1)) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
+__global__ void __launch_bounds__(FUSED_THREADS, (fused_min_waves<T, R>())) rollout_jac_fused_kernel(Fn fn, long long K, long long M, int G, long long sj, long long sk, T* __restrict__ Z,
                                                                             const double* __restrict__ tt, const double* __restrict__ dtt, const T* __restrict__ X0,
                                                                             T* __restrict__ J, unsigned long long* __restrict__ progress, unsigned long long pbase, long long split) {
     if ((int)blockIdx.x < G) {

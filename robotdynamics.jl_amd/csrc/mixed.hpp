@@ -136,7 +136,7 @@ RD_DEV void mixed_rollout_role(const FnA& fa, long long KA, long long MA, T* __r
 }
 
 template <class FnA, class T, class Cas, int R, class Plan, int NC, class FnB>
-__global__ void __launch_bounds__(FUSED_THREADS, (sizeof(T) == 4 ? Tune::FUSED_F32_MINW : 1))
+__global__ void __launch_bounds__(FUSED_THREADS, (fused_min_waves<T, R>()))
 rollout_jac_mixed_kernel(FnA fa, long long KA, long long MA, int GA, T* __restrict__ ZA, const double* __restrict__ tA, const double* __restrict__ dtA, const T* __restrict__ X0A,
                          T* __restrict__ JA, FnB fb, long long KB, long long MB, int GB, T* __restrict__ ZB, const double* __restrict__ tB, const double* __restrict__ dtB,
                          const T* __restrict__ X0B, T* __restrict__ JB, unsigned long long* __restrict__ progress, unsigned long long pbase, long long split) {

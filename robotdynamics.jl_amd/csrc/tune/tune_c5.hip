@@ -13,6 +13,9 @@ using namespace rd;
 #ifndef TT
 #define TT float
 #endif
+#ifndef FR                  // ring depth of the rollout role (cascade.hpp): 4 = 98 KB of LDS in fp32, 2 = 73 KB (two workgroups per CU)
+#define FR 4
+#endif
 #ifndef FNC                 // copy waves of the fused kernel: 4 = 512 threads, one workgroup per CU; 2 (fp32) = 384 threads, two per CU
 #define FNC 4
 #endif
@@ -61,10 +64,10 @@ int main(int argc, char** argv) {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int G = (int)((M + 63) / 64);
-        using FL = FusedLds<Fn, TT, Cas, 4, SatPlan, FNC>;
+        using FL = FusedLds<Fn, TT, Cas, FR, SatPlan, FNC>;
     const int GW = G;
     constexpr int FT = FUSED_THREADS;
-        auto kf = rollout_jac_fused_kernel<Fn, TT, Cas, 4, SatPlan, FNC, true>;
+        auto kf = rollout_jac_fused_kernel<Fn, TT, Cas, FR, SatPlan, FNC, true>;
     CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
     auto kj = jac_ad_split_kernel<Fn, TT, SatPlan, 4>;
     constexpr size_t ldsj = SplitLds<Fn, TT, SatPlan, 4>::BYTES;

@@ -376,8 +376,10 @@ def test_sweep_rollout_and_rollout_jacobian(name, dname):
             atol, rtol = ((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0))
             assert_periodic(got, Zr[:, :, :c.n], atol, rtol, f"{name}/{dname} rollout_split {rule.__name__} M={M} K={K} time_major={tm}")
         # an initial state of its own (x0) and the Jacobians along the rollout in the same call
-        for tm in (False, True):
-            M, K = 72, 9                                              # (a multiple of 4: the fp32 time-major one-launch form wants 16-byte aligned rows of tiles)
+        shapes = [(72, 9, False), (72, 9, True)]                      # (a multiple of 4: the fp32 time-major one-launch form wants 16-byte aligned rows of tiles)
+        if c.f32 and rule in (RD.RK3, RD.RK4) and name.startswith(("sat_", "quad_")):
+            shapes.append((4096, 5, True))                            # 64 rollout groups, bound by the Jacobian workgroups: the two-workgroups-per-CU form (fused.hpp)
+        for M, K, tm in shapes:
             st, Zb, tb, dtb = _stack(c, M, K, tm, seed=11)
             x0 = tile_rows(Zb[:, 0, :c.n] * 0.5 + 0.25 * Zb[:, 1, :c.n], M)
             if name.startswith(("sat_", "quad_")) and ROTCODE[c.model.rotation] == 0:
@@ -463,7 +465,7 @@ def test_sweep_implicit_midpoint(name, dname):
 def test_sweep_mixed_model_call_in_one_launch(rule, dname):
     ca, cb = case_of("sat_wd", dname), case_of("cartpole", dname)
     for idle in (0, 1):
-        for MA, MB, K in ((132, 200, 9), (64, 64, 5)):
+        for MA, MB, K in ((132, 200, 9), (64, 64, 5)) + (((4096, 4096, 5),) if dname == "f32" and idle == 1 else ()):      # (the last: the two-per-CU form)
             RD.tune(f"mixed_idle={idle}")
             try:
                 sa, Za, ta, da = _stack(ca, MA, K, True, seed=23)

@@ -28,7 +28,7 @@ import rdhip as RD  # noqa: E402
 from bench_configs import rigid_inputs  # noqa: E402
 
 TOTAL = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-SHAPES = [(66, 37), (130, 37), (66, 101), (130, 101), (4094, 37), (4094, 101)]
+SHAPES = [(66, 37), (130, 37), (66, 101), (130, 101), (4094, 37), (4094, 101), (4096, 37)]      # (the last: fp32 time-major takes the two-workgroups-per-CU kernel)
 NJS = [3, 16, 64, 192, 0]          # Jacobian workgroups (0: every CU the rollout groups leave)
 sig, AD = RD.StaticReturn(), RD.ForwardAD()
 
