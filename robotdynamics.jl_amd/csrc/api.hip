@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "common.hpp"
@@ -34,6 +35,7 @@ struct rdhip_ctx {
     // grow-only device workspace slots for RDHIP_HOST staging
     void* ws[8];
     size_t ws_bytes[8];
+    void* mws = nullptr; size_t mws_bytes = 0;        // rdhip_jacobian_multi's gather / scatter staging (grow-only; see multi_staged)
     // batch tables of rdhip_jacobian_multi calls with more batches than fit the kernel arguments: pinned host image + device copy, a ring of
     // slots so that a call never overwrites a table a kernel of an earlier call may still be reading (the slot's event says when it is free)
     // A solver re-issues the same call on the same arrays every iteration: a slot whose image equals the new table is reused without a copy.
@@ -54,6 +56,7 @@ struct rdhip_ctx {
     unsigned sched_next[2] = {0, 0};
     int last_rolljac_launches = 0;        // kernel launches of the last rdhip_rollout_jacobian call (1 = fused)
     bool allow_fused = true;              // rdhip_rollout_jacobian_multi lets ONE model of a call take the fused (spin-waiting) launch
+    bool fused_beside = false;            // ... and says that the other models' launches run BESIDE it: the fused launch must not fill every workgroup slot of the chip (LaunchArgs::beside)
     // Launch overlap (rdhip_ctx_set_overlap): consecutive rdhip_jacobian calls on device arrays alternate between the context's stream and one
     // internal stream, with an event edge only where a call touches memory a call still in flight on the OTHER stream touches; everything else
     // joins first (side_join).  A launch's prologue then runs under its predecessor's tail, which one stream cannot do.
@@ -233,6 +236,7 @@ int rdhip_ctx_destroy(rdhip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->mws) (void)hipFree(c->mws);
     for (auto& sl : c->tslot) { if (sl.host) (void)hipHostFree(sl.host); if (sl.dev) (void)hipFree(sl.dev); if (sl.done) (void)hipEventDestroy(sl.done); }
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_progress) (void)hipFree(c->d_progress);
@@ -914,6 +918,69 @@ static rdhip_ctx::TableSlot* upload_table(rdhip_ctx* c, const std::vector<MultiR
     sl.used = bytes;
     return &sl;
 }
+// ---- rdhip_jacobian_multi for (model, rule, diff) combinations without a batch-table kernel: gather, ONE rdhip_jacobian, scatter --------------------------
+// Round 6 ships the one-launch multi kernels for ForwardAD only (every shipped instantiation is exercised); FiniteDifference, UserDefined,
+// the implicit rule and custom models ran one rdhip_jacobian call per batch -- 8.8 ms for 1 024 batches of 101 knots.  Knot points are independent, so the
+// batches' inputs are copied into ONE contiguous stack (a model-independent copy kernel over a table of the batches), the single-batch kernel runs over
+// it, and a second copy kernel hands the Jacobians out: three launches, the Jacobian stack moved twice more.
+struct BatchCopyRec { const void* z; const double* t; const double* dt; void* j; void* y; long long off; long long n; };
+// words: 4-byte units per knot point of the array handled (z: nz T / 4, t and dt: 2, J: n nz T / 4, y: n T / 4); 16-byte units where both sides allow it
+__device__ inline void copy_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long long nwords) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if ((((unsigned long long)dst | (unsigned long long)src) & 15ULL) == 0 && (nwords & 3) == 0) {
+        typedef unsigned V4 __attribute__((ext_vector_type(4)));
+        for (long long i = i0; i < nwords / 4; i += step) reinterpret_cast<V4*>(dst)[i] = reinterpret_cast<const V4*>(src)[i];
+    } else if ((((unsigned long long)dst | (unsigned long long)src) & 7ULL) == 0 && (nwords & 1) == 0) {
+        for (long long i = i0; i < nwords / 2; i += step) reinterpret_cast<unsigned long long*>(dst)[i] = reinterpret_cast<const unsigned long long*>(src)[i];
+    } else {
+        for (long long i = i0; i < nwords; i += step) dst[i] = src[i];
+    }
+}
+__global__ void __launch_bounds__(256) batch_gather_kernel(const BatchCopyRec* __restrict__ recs, int zw, unsigned* Zs, unsigned* Ts, unsigned* Ds) {
+    const BatchCopyRec r = recs[blockIdx.y];
+    copy_words(Zs + r.off * zw, static_cast<const unsigned*>(r.z), r.n * zw);
+    copy_words(Ts + r.off * 2, reinterpret_cast<const unsigned*>(r.t), r.n * 2);
+    copy_words(Ds + r.off * 2, reinterpret_cast<const unsigned*>(r.dt), r.n * 2);
+}
+__global__ void __launch_bounds__(256) batch_scatter_kernel(const BatchCopyRec* __restrict__ recs, int jw, int yw, const unsigned* Js, const unsigned* Ys) {
+    const BatchCopyRec r = recs[blockIdx.y];
+    copy_words(static_cast<unsigned*>(r.j), Js + r.off * jw, r.n * jw);
+    if (r.y && Ys) copy_words(static_cast<unsigned*>(r.y), Ys + r.off * yw, r.n * yw);
+}
+// RDHIP_ERR_UNSUPPORTED: not this way (the caller runs the batches one by one); otherwise the status of the three launches
+static int multi_staged(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, const std::vector<int>& live, const long long* N, const void* const* Z,
+                        const double* const* t, const double* const* dt, void* const* J, void* const* Y, const char* what) {
+    if (c->overlap || stream_is_capturing(c)) return RDHIP_ERR_UNSUPPORTED;      // (one staging area per context, reused in stream order; growing it allocates)
+    const ModelDesc& d = M->d;
+    const size_t ts = dtype == RDHIP_F64 ? 8 : 4, zb = (size_t)(d.n + d.m) * ts, jb = (size_t)d.n * (d.n + d.m) * ts, yb = (size_t)d.n * ts;
+    long long total = 0, nmax = 0; bool any_y = false;
+    std::vector<BatchCopyRec> recs; recs.reserve(live.size());
+    for (int b : live) { recs.push_back({Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, total, N[b]}); total += N[b]; nmax = N[b] > nmax ? N[b] : nmax; any_y = any_y || (Y && Y[b]); }
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_rec = 0, o_z = up(recs.size() * sizeof(BatchCopyRec)), o_t = o_z + up((size_t)total * zb), o_d = o_t + up((size_t)total * 8), o_j = o_d + up((size_t)total * 8),
+                 o_y = o_j + up((size_t)total * jb), need = o_y + (any_y ? up((size_t)total * yb) : 0);
+    if (c->mws_bytes < need) {
+        if (c->mws) (void)hipFree(c->mws);
+        c->mws = nullptr; c->mws_bytes = 0;
+        if (hipMalloc(&c->mws, need) != hipSuccess) { (void)hipGetLastError(); return RDHIP_ERR_UNSUPPORTED; }      // (no room for a second copy of the Jacobians: one by one)
+        c->mws_bytes = need;
+    }
+    char* w = static_cast<char*>(c->mws);
+    // (pageable source: the runtime stages it before the call returns, so the vector may go)
+    if (hipMemcpyAsync(w + o_rec, recs.data(), recs.size() * sizeof(BatchCopyRec), hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: batch table copy failed", what);
+    const unsigned gx = (unsigned)std::min<long long>(32, std::max<long long>(1, (nmax * (long long)(jb / 4) + 4095) / 4096));
+    hipLaunchKernelGGL(batch_gather_kernel, dim3(gx, (unsigned)recs.size()), dim3(256), 0, c->stream, reinterpret_cast<const BatchCopyRec*>(w + o_rec), (int)(zb / 4),
+                       reinterpret_cast<unsigned*>(w + o_z), reinterpret_cast<unsigned*>(w + o_t), reinterpret_cast<unsigned*>(w + o_d));
+    if (hipGetLastError() != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: gather launch failed", what);
+    const int rc = rdhip_jacobian(c, M, rule, diff, dtype, total, w + o_z, reinterpret_cast<const double*>(w + o_t), reinterpret_cast<const double*>(w + o_d), w + o_j,
+                                  any_y ? w + o_y : nullptr, RDHIP_DEVICE);
+    if (rc) return rc;
+    hipLaunchKernelGGL(batch_scatter_kernel, dim3(gx, (unsigned)recs.size()), dim3(256), 0, c->stream, reinterpret_cast<const BatchCopyRec*>(w + o_rec), (int)(jb / 4), (int)(yb / 4),
+                       reinterpret_cast<const unsigned*>(w + o_j), any_y ? reinterpret_cast<const unsigned*>(w + o_y) : nullptr);
+    if (hipGetLastError() != hipSuccess) return fail(c, RDHIP_ERR_HIP, "%s: scatter launch failed", what);
+    c->last_multi_launches += 2 + ((rule == RDHIP_IMPLICIT_MIDPOINT) ? 3 : 1);
+    return RDHIP_OK;
+}
 int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff, int dtype, int nbatch, const long long* N,
                          const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace) {
     const char* what = "rdhip_jacobian_multi";
@@ -1003,10 +1070,30 @@ int rdhip_jacobian_multi(rdhip_ctx* c, const rdhip_model* M, int rule, int diff,
     static const bool verbose = getenv("RDHIP_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "[rdhip] %s: no fused kernel for (model kind %d, rule %d, diff %d, %s pointers): %d batches run as separate rdhip_jacobian calls\n",
                          what, d.kind, rule, diff, memspace == RDHIP_DEVICE ? "device" : "host", (int)live.size());
-    for (int b : live) {                                          // same results, one call per batch
-        rc = rdhip_jacobian(c, M, rule, diff, dtype, N[b], Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, memspace);
+    // Same results, one call per RUN of batches: knot points are independent, so batches that follow each other in memory in every array (the slices of
+    // one stack -- what a caller holds who keeps its trajectories in one allocation) are one rdhip_jacobian call over their concatenation.  1 024 x 101
+    // satellite knots under FiniteDifference: 8.8 ms as 1 024 calls, one launch when the slices are adjacent (tools/bench_configs.py --sweep).
+    const size_t tsz = dtype == RDHIP_F64 ? 8 : 4;
+    const size_t zb = (size_t)(d.n + d.m) * tsz, jb = (size_t)d.n * (d.n + d.m) * tsz, yb = (size_t)d.n * tsz;
+    auto follows = [&](int a, int b) {          // batch b starts where batch a ends, in every array
+        const size_t na = (size_t)N[a];
+        return (const char*)Z[b] == (const char*)Z[a] + na * zb && t[b] == t[a] + na && dt[b] == dt[a] + na && (char*)J[b] == (char*)J[a] + na * jb &&
+               ((Y == nullptr) || (!Y[a] && !Y[b]) || (Y[a] && Y[b] && (char*)Y[b] == (char*)Y[a] + na * yb));
+    };
+    size_t nruns = live.empty() ? 0 : 1;
+    for (size_t i = 1; i < live.size(); ++i) nruns += follows(live[i - 1], live[i]) ? 0 : 1;
+    if (nruns >= 4 && memspace == RDHIP_DEVICE && nbatch <= 65535) {          // (a handful of calls is cheaper than two more passes over the Jacobians)
+        rc = multi_staged(c, M, rule, diff, dtype, live, N, Z, t, dt, J, Y, what);
+        if (rc != RDHIP_ERR_UNSUPPORTED) return rc;
+    }
+    for (size_t i = 0; i < live.size();) {
+        size_t e = i + 1; long long n = N[live[i]];
+        while (e < live.size() && follows(live[e - 1], live[e])) { n += N[live[e]]; ++e; }
+        const int b = live[i];
+        rc = rdhip_jacobian(c, M, rule, diff, dtype, n, Z[b], t[b], dt[b], J[b], Y ? Y[b] : nullptr, memspace);
         if (rc) return rc;
         c->last_multi_launches += (rule == RDHIP_IMPLICIT_MIDPOINT) ? 3 : 1;
+        i = e;
     }
     return RDHIP_OK;
 }
@@ -1240,7 +1327,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     LaunchArgs j{}; j.stream = c->stream; j.N = N; j.Z = r.Z; j.t = r.t; j.dt = r.dt; j.J = dJ;
     if (implicit) { j.Y = s.reserve((size_t)N * d.n * ts); if (s.rc) return s.rc; }      // the Newton solutions have to land somewhere
     c->last_rolljac_launches = 0;
-    LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1;
+    LaunchArgs f = r; f.J = dJ; f.progress = c->d_progress; f.progress_words = PROGRESS_WORDS; f.probe = 1; f.beside = c->fused_beside ? 1 : 0;
     // A TRAJECTORY-major stack of bandwidth size goes the two-launch way: its fused form gathers tiles of 4 trajectories x 16 knots (ragged when K is not a
     // multiple of 16, short runs of output) and was measured SLOWER than rollout + Jacobians in two launches from a few hundred thousand knot points
     // on (4 096 x 101 fp64: 252 vs 221 us; 16 384 x 64: 365 vs 365; the latency-sized 512 x 256 fp32: 138 vs 148, so small stacks stay fused); the
@@ -1415,7 +1502,7 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         if (p == main_model) continue;
         rdhip_ctx* ch = lazy ? c->side_child : c->child[slot];
         if (!chained) HIP_TRY(c, hipStreamWaitEvent(ch->stream, c->fork_ev, 0));
-        ch->allow_fused = (p == fused_model);
+        ch->allow_fused = (p == fused_model); ch->fused_beside = true;
         rc0 = rdhip_rollout_jacobian(ch, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         if (rc0) fail(c, rc0, "%s (model %d): %s", what, p, rdhip_last_error(ch));
         if (!lazy) HIP_TRY(c, hipEventRecord(c->join_ev[slot], ch->stream));
@@ -1424,11 +1511,11 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
     if (lazy) { c->side_pending = true; c->multi_pending = true; }      // (whatever happened above: the internal stream has work nothing may overtake)
     if (rc0 == RDHIP_OK) {
         const int p = main_model;
-        c->allow_fused = (fused_model == p);
+        c->allow_fused = (fused_model == p); c->fused_beside = nmodels > 1;
         c->in_overlapped_call = lazy;                        // (check_common must not join here: this call orders itself)
         rc0 = rdhip_rollout_jacobian(c, models[p], rule[p], diff, dtype, K[p], Mt[p], layout, Z[p], t[p], dt[p], X0 ? X0[p] : nullptr, J[p], memspace);
         c->in_overlapped_call = false;
-        c->allow_fused = true;
+        c->allow_fused = true; c->fused_beside = false;
     }
     if (lazy) { c->multi_sig = rc0 == RDHIP_OK ? sig : 0; c->multi_args.swap(argv_now); return rc0; }
     for (int p = 1; p < nmodels; ++p) if (c->join_ev[p - 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[p - 1], 0));      // join: later work on the context sees every model's results

@@ -205,6 +205,7 @@ struct LaunchArgs {
     unsigned long long pbase;       //   (call epoch << 32): words of earlier calls compare below
     int progress_words;             //   capacity of `progress`
     int probe;                      //   != 0: say whether the fused launch exists for these arguments (RDHIP_OK / RDHIP_ERR_UNSUPPORTED) without launching it
+    int beside;                     //   != 0: launches of other models of the same call run beside this one on other streams: keep to one workgroup per compute unit
     unsigned* sched;    // split-role Jacobian kernels: the launch's counter words of the dynamic tile schedule (kernels.hpp jac_split_loop), or NULL
     const MultiDesc* multi;   // jacobian: non-NULL = several batches in one launch (N, Z, t, dt, J, Y above are ignored); families that have no
                               // fused kernel for the (model, rule, diff) return RDHIP_ERR_UNSUPPORTED BEFORE launching anything and the caller

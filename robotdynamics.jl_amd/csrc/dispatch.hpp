@@ -405,7 +405,7 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
                 using FL2 = FusedLds<Fn, T, Cas, RC, Plan, NC>;
                 static_assert(2 * FL2::BYTES <= 160 * 1024, "two workgroups of the compact fused kernel per CU");
                 // (time-major stacks only: a trajectory-major stack this large runs as pipelined pieces anyway, fused_tj_max_knots)
-                if (a.time_major && tune_knobs().fused_two_per_cu && !(ratio_env > 0) && nj_env < 1 && split_of(K * G, cus - G) > 0) {
+                if (a.time_major && !a.beside && tune_knobs().fused_two_per_cu && !(ratio_env > 0) && nj_env < 1 && split_of(K * G, cus - G) > 0) {
                     const long long nj = 2 * cus - G;
                     auto kern = rollout_jac_fused_kernel<Fn, T, Cas, RC, Plan, NC, true>;
                     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;

@@ -1048,9 +1048,10 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
                     assert torch.equal(J1, Js[b])
                 else:
                     np.testing.assert_allclose(host(J1), host(Js[b]), rtol=0, atol=1e-13)
-    # FiniteDifference, the UserDefined chain rule and unaligned slabs: NO one-launch form since round 6 (their batch-table instantiations were half of the
-    # library's code and nothing tested them: csrc/dispatch.hpp launch_jacobian_multi) -- the call runs the batches one rdhip_jacobian launch each, says so,
-    # and is bit-identical to the per-trajectory calls; > 32 trajectories of a rigid body and of the cartpole
+    # FiniteDifference, the UserDefined chain rule and unaligned slabs: NO batch-table kernel since round 6 (their instantiations were half of the library's
+    # code and nothing tested them: csrc/dispatch.hpp launch_jacobian_multi) -- four batches and more are gathered into one stack, run as ONE rdhip_jacobian
+    # launch and scattered (three launches; fewer batches: one launch each); bit-identical to the per-trajectory calls; > 32 trajectories of a rigid body
+    # and of the cartpole
     for model, om, gen in ((RD.Satellite(), O.satellite(), lambda N: H.rand_rigid(rng, N, 6)), (RD.Cartpole(), O.cartpole(), lambda N: rng.random((N, 5)))):
         n, m = RD.state_dim(model), RD.control_dim(model)
         sizes = [70, 33, 0, 101] + [65] * 31
@@ -1060,7 +1061,7 @@ def test_jacobian_multi_fuses_independent_trajectories_into_one_launch():
         for diff, odiff, tol in ((RD.FiniteDifference(), O.FORWARD_AD, 1e-6), (RD.UserDefined(), O.USER, TOL)):
             Js = [RD.alloc_jacobians(dm, N, Zs[0].data).fill_(7.0) for N in sizes]
             Ys = [torch.full((N, n), 7.0, dtype=torch.float64, device="cuda") for N in sizes]
-            assert RD.jacobian_multi_(sig, diff, dm, Js, Ys, Zs) == sum(1 for N in sizes if N > 0)
+            assert RD.jacobian_multi_(sig, diff, dm, Js, Ys, Zs) == 3        # gather + ONE rdhip_jacobian over the 34 batches' concatenation + scatter (api.hip multi_staged)
             for b in (0, 1, 3, 4, 34):
                 Jo, Yo = om.jacobian(O.RK4, odiff, Zn[b], ts[b], dts[b])
                 np.testing.assert_allclose(host(Js[b]), Jo, rtol=0, atol=tol)

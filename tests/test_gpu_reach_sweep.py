@@ -290,6 +290,18 @@ def test_sweep_jacobian_multi(name, dname):
     for J in Js:
         assert_periodic(J, ref[0], *c.tol(O.FINITE_DIFF, ref[0]), f"{name}/{dname} multi FiniteDifference")
     assert refd is not None
+    # ... and from four batches on as gather + ONE rdhip_jacobian over the concatenation + scatter (api.hip multi_staged): three launches whatever the count
+    six = [BASE, 64, 130, 70, 71, 203]
+    launches, Js, Ys = _multi(c, fun, RD.FiniteDifference(), six)
+    assert launches == 3, launches
+    for J, Y in zip(Js, Ys):
+        assert_periodic(J, ref[0], *c.tol(O.FINITE_DIFF, ref[0]), f"{name}/{dname} multi FiniteDifference, six batches")
+        assert_periodic(Y, ref[1], *c.tol(O.FORWARD_AD, ref[1]), f"{name}/{dname} multi FiniteDifference, six batches, f(z)")
+    launches, Js, Ys = _multi(c, fun, RD.ForwardAD(), six, aligned=False)
+    assert launches == (1 if small else 3), launches
+    for J, Y in zip(Js, Ys):
+        assert_periodic(J, ref[0], *c.tol(O.FORWARD_AD, ref[0]), f"{name}/{dname} multi unaligned, six batches")
+        assert_periodic(Y, ref[1], *c.tol(O.FORWARD_AD, ref[1]), f"{name}/{dname} multi unaligned, six batches, f(z)")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------

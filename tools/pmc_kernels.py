@@ -119,11 +119,11 @@ U = st["data"][:K - 1, :, 13:].contiguous()
 for _ in range(REPS):
     RD.rollout_split_(sig, dsat, X, U, st["t"], st["dt"], time_major=True)
 torch.cuda.synchronize()
-report("rollout_split_32768x32", {"rollout_split_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "time-major")
+report("rollout_split_32768x32", {"rollout_split_lane_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "time-major")
 Xj = torch.empty((M, K, 13), dtype=torch.float64, device="cuda"); Xj[:, 0] = st["data"][0, :, :13]
 Uj = st["data"][:K - 1, :, 13:].transpose(0, 1).contiguous()
 tj, dj = st["t"].t().contiguous(), st["dt"].t().contiguous()
 for _ in range(REPS + 1):                                  # (one more launch than the time-major case: the script tells the two apart by their launch counts)
     RD.rollout_split_(sig, dsat, Xj, Uj, tj, dj)
 torch.cuda.synchronize()
-report("rollout_split_32768x32_trajectory_major", {"rollout_split_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "trajectory-major: a trajectory's 4-knot runs start and end inside 128-byte lines")
+report("rollout_split_32768x32_trajectory_major", {"rollout_split_lane_kernel": M * (K - 1) * (48 + 16 + 104) + M * 104}, "trajectory-major: a trajectory's 4-knot runs start and end inside 128-byte lines")

@@ -33,11 +33,16 @@ cases = [json.loads(l) for l in open(f"{out}/k_WRITE_SIZE.log") if l.startswith(
 lines = [f"calibration (1 GiB streaming fill / read under the same --pmc pass): WRITE_SIZE x {f_w:.3f}, FETCH_SIZE x {f_r:.3f}", "",
          "| case | kernel | launches | written MB | read MB | traffic MB | algorithmic MB | ratio |", "|---|---|---|---|---|---|---|---|"]
 rows = []
+used = {}
 for c in cases:
     for needle, alg in c["kernels"].items():
         w = [x for k, vs in kw.items() if needle in k for x in vs]
         r = [x for k, vs in kr.items() if needle in k for x in vs]
         if not w or not r: continue
+        if needle == "rollout_split_lane_kernel":      # one kernel, two cases in a row (time-major, then trajectory-major): the launches in dispatch order, `reps` for the first case, the rest for the second
+            n0 = used.get(needle, 0); n1 = n0 + c["reps"] if n0 == 0 else len(w)
+            w, r = w[n0:n1], r[n0:n1]; used[needle] = n1
+            if not w or not r: continue
         # (a kernel name may appear in several cases -- jac_ad_split_kernel --: cases run in order, take the launches by size class via the per-case count)
         wb = sorted(w)[len(w) // 2] * 1024 * f_w; rb = sorted(r)[len(r) // 2] * 1024 * f_r
         if needle == "jac_ad_split_kernel" or needle == "rollout_kernel" or needle == "jac_ad_small_kernel":
