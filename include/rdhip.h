@@ -285,15 +285,19 @@ int rdhip_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff,
  * Up to 32 non-empty batches travel in the kernel arguments; more are copied into a device table owned by the context (a binary search per tile,
  * none when all batches have the same length).  Fused -- ONE launch -- for RDHIP_FORWARD_AD (the reference's default diff method of a DiscretizedDynamics,
  * src/discretized_dynamics.jl:190) under every explicit rule, compiled-in models with device pointers whose J / Y start on 16-byte boundaries (custom
- * hipRTC models: every diff method, aligned or not -- their kernels are compiled on demand).  RDHIP_FINITE_DIFF, RDHIP_USER_DEFINED, unaligned outputs,
- * RDHIP_IMPLICIT_MIDPOINT (three passes per batch) and host arrays run the batches one rdhip_jacobian call at a time with the same results (round 6: the
- * batch-table instantiations of those bodies were half of the library's device code and nothing exercised them), and so does a capturing stream with
- * more than 32 batches in groups of 32 launches (no allocation inside a capture).  rdhip_ctx_last_multi_launches tells which happened; RDHIP_VERBOSE=1 logs the fallback.
+ * hipRTC models: every diff method, aligned or not -- their kernels are compiled on demand).  RDHIP_FINITE_DIFF, RDHIP_USER_DEFINED, unaligned outputs and
+ * RDHIP_IMPLICIT_MIDPOINT have no batch-table kernel (round 6: those instantiations were half of the library's device code and nothing exercised them).
+ * Such a call with device pointers and four or more runs of batches copies the batches' inputs into one stack owned by the context, runs ONE
+ * rdhip_jacobian over it and copies the outputs back: three launches (five for the implicit rule) and a second copy of the outputs in device memory
+ * (1 024 x 101 satellite knots under FiniteDifference: 166 us; not inside a stream capture, not in the launch-overlap mode).  Otherwise -- fewer runs,
+ * host arrays, no room for the stack -- one rdhip_jacobian call per RUN of batches, where batches that follow each other in memory in every array
+ * (the slices of one stack) form one run.  Same results either way.  A capturing stream with more than 32 ForwardAD batches issues groups of 32
+ * (no allocation inside a capture).  rdhip_ctx_last_multi_launches tells which happened; RDHIP_VERBOSE=1 logs the fallback.
  * Batches must not overlap. */
 int rdhip_jacobian_multi(rdhip_ctx* ctx, const rdhip_model* model, int rule, int diff, int dtype, int nbatch, const long long* N,
                          const void* const* Z, const double* const* t, const double* const* dt, void* const* J, void* const* Y, int memspace);
 /* kernel launches the last rdhip_jacobian_multi call on this context issued: 1 = fused into one launch (the per-trajectory loops of
- * src/functionbase.jl:242 callers collapsed), nbatch (3 x nbatch for the implicit rule) = the batch-by-batch fallback */
+ * src/functionbase.jl:242 callers collapsed), 3 (5 for the implicit rule) = gathered into one stack, otherwise one (three) per run of batches */
 int rdhip_ctx_last_multi_launches(rdhip_ctx* ctx, int* launches);
 
 /* dynamics_error(model, z2, z1) = discrete_dynamics(model, z1) - state(z2) (src/discrete_dynamics.jl:134-135; in-place :146-156) for

@@ -1619,7 +1619,7 @@ class PreparedJacobianMulti:
 
     @property
     def launches(self):
-        """kernel launches the last call issued (rdhip_ctx_last_multi_launches): 1 = fused, one per trajectory = the batch-by-batch fallback"""
+        """kernel launches the last call issued (rdhip_ctx_last_multi_launches): 1 = fused, 3 = gathered into one stack (no batch-table kernel for this diff method), otherwise one per run of batches"""
         ctx = getattr(self, "_last_ctx", None)
         if ctx is None:
             return 0
