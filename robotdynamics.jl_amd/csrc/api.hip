@@ -1333,7 +1333,7 @@ int rdhip_rollout_jacobian(rdhip_ctx* c, const rdhip_model* M, int rule, int dif
     // on (4 096 x 101 fp64: 252 vs 221 us; 16 384 x 64: 365 vs 365; the latency-sized 512 x 256 fp32: 138 vs 148, so small stacks stay fused); the
     // Jacobian launch over the contiguous stack then also gets the dynamic tile schedule.  Time-major stacks are faster fused at every size measured.
     const long long tj_max = tune_knobs().fused_tj_max_knots;
-    const bool tj_two_launches = layout != RDHIP_TIME_MAJOR && N >= tj_max;
+    const bool tj_two_launches = layout != RDHIP_TIME_MAJOR && N >= tj_max && dtype == RDHIP_F64;      // (fp32: the gathered tiles win at every size measured -- 4 096 x 256: 254 against 288 us, 2xx at two workgroups per CU)
     if (!implicit && c->allow_fused && !tj_two_launches && family_rolljac(d, rule, diff, dtype, f) == RDHIP_OK) {      // (probe: nothing is launched)
         // ONE launch: rollout workgroups + Jacobian workgroups that consume finished chunks through progress words (fused.hpp)
         f.probe = 0;
@@ -1419,17 +1419,17 @@ int rdhip_rollout_jacobian_multi(rdhip_ctx* c, int nmodels, const rdhip_model* c
         return RDHIP_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    // ONE launch for the pair the one-launch form exists for (mixed.hpp: a satellite-type rigid body + the cartpole under one rule, time-major stacks,
+    // ONE launch for the pair the one-launch form exists for (mixed.hpp: a satellite-type rigid body + the cartpole under one rule, either layout,
     // ForwardAD): both rollouts and both models' Jacobians in one grid on the context's stream -- no fork, no join, no second stream
-    if (nmodels == 2 && layout == RDHIP_TIME_MAJOR && diff == RDHIP_FORWARD_AD && tune_knobs().mixed && c->allow_fused) {
+    if (nmodels == 2 && diff == RDHIP_FORWARD_AD && tune_knobs().mixed && c->allow_fused) {
         for (int pa = 0; pa < 2; ++pa) {
             const int pb = 1 - pa;
             bool ok = true;
             for (int p = 0; p < 2; ++p) ok = ok && Z[p] && t[p] && dt[p] && J[p] && K[p] > 0 && Mt[p] > 0;
             if (!ok) break;
             LaunchArgs a{}, b{};
-            a.stream = c->stream; a.N = Mt[pa]; a.K = K[pa]; a.Z = Z[pa]; a.t = t[pa]; a.dt = dt[pa]; a.X0 = X0 ? X0[pa] : nullptr; a.J = J[pa]; a.time_major = 1;
-            b.stream = c->stream; b.N = Mt[pb]; b.K = K[pb]; b.Z = Z[pb]; b.t = t[pb]; b.dt = dt[pb]; b.X0 = X0 ? X0[pb] : nullptr; b.J = J[pb]; b.time_major = 1;
+            a.stream = c->stream; a.N = Mt[pa]; a.K = K[pa]; a.Z = Z[pa]; a.t = t[pa]; a.dt = dt[pa]; a.X0 = X0 ? X0[pa] : nullptr; a.J = J[pa]; a.time_major = layout == RDHIP_TIME_MAJOR ? 1 : 0;
+            b.stream = c->stream; b.N = Mt[pb]; b.K = K[pb]; b.Z = Z[pb]; b.t = t[pb]; b.dt = dt[pb]; b.X0 = X0 ? X0[pb] : nullptr; b.J = J[pb]; b.time_major = a.time_major;
             a.progress = c->d_progress; a.progress_words = PROGRESS_WORDS; a.probe = 1;
             if (fam_mixed_rolljac(models[pa]->d, rule[pa], models[pb]->d, rule[pb], diff, dtype, a, b) != RDHIP_OK) continue;
             if (dtype != RDHIP_F64 && dtype != RDHIP_F32) break;

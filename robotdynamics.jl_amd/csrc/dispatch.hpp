@@ -404,13 +404,20 @@ template <class Mdl, int RULE> int launch_rollout_jacobian_fused(const Mdl& m, i
                 constexpr int RC = R | CASCADE_COMPACT;
                 using FL2 = FusedLds<Fn, T, Cas, RC, Plan, NC>;
                 static_assert(2 * FL2::BYTES <= 160 * 1024, "two workgroups of the compact fused kernel per CU");
-                // (time-major stacks only: a trajectory-major stack this large runs as pipelined pieces anyway, fused_tj_max_knots)
-                if (a.time_major && !a.beside && tune_knobs().fused_two_per_cu && !(ratio_env > 0) && nj_env < 1 && split_of(K * G, cus - G) > 0) {
+                const long long ntl = a.time_major ? K * G : ((K + GATHER_RUN - 1) / GATHER_RUN) * ((M + GATHER_NRUN - 1) / GATHER_NRUN);
+                if (!a.beside && tune_knobs().fused_two_per_cu && !(ratio_env > 0) && nj_env < 1 && split_of(ntl, cus - G) > 0) {
                     const long long nj = 2 * cus - G;
-                    auto kern = rollout_jac_fused_kernel<Fn, T, Cas, RC, Plan, NC, true>;
-                    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
-                    RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), FL2::BYTES, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
-                                       a.progress, a.pbase, 0LL);
+                    if (a.time_major) {
+                        auto kern = rollout_jac_fused_kernel<Fn, T, Cas, RC, Plan, NC, true>;
+                        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+                        RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), FL2::BYTES, a.stream, Fn{m}, K, M, (int)G, 1LL, M, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                           a.progress, a.pbase, 0LL);
+                    } else {
+                        auto kern = rollout_jac_fused_kernel<Fn, T, Cas, RC, Plan, NC, false>;
+                        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FL2::BYTES) != hipSuccess) return RDHIP_ERR_HIP;
+                        RD_LAUNCH(kern, dim3((unsigned)(G + nj)), dim3(FUSED_THREADS), FL2::BYTES, a.stream, Fn{m}, K, M, (int)G, K, 1LL, (T*)a.Z, a.t, a.dt, (const T*)a.X0, (T*)a.J,
+                                           a.progress, a.pbase, 0LL);
+                    }
                     return hip_status(hipGetLastError());
                 }
             }

@@ -39,28 +39,30 @@ namespace rd {
 // 4.2 million 4-byte write-through pieces; whole knot blocks through LDS as write-through lines, 337 us: the compiler put a full vmcnt drain -- the
 // acknowledgement of the previous step's write-through stores -- in front of every step.)
 constexpr int MIXED_PREFETCH = 8;
-constexpr int MIXED_WPB = 4;      // rollout waves of B per workgroup of its own (one per SIMD)
+// rollout waves of B per workgroup of its own: one per SIMD for time-major stacks; ONE for a vector of trajectories, where every access of a wave touches 64
+// cache lines and four such waves on one CU queue up on its address path (config 5's share, trajectory-major: 188 us with four, against 155 for the streams)
+template <bool TM> constexpr int mixed_wpb() { return TM ? 4 : 1; }
 template <class Fn, class T>
-RD_DEV void mixed_small_rollout(const Fn& fn, long long j, long long K, long long M, T* __restrict__ Z, const double* __restrict__ tt,
-                                const double* __restrict__ dtt, const T* __restrict__ X0) {
+RD_DEV void mixed_small_rollout(const Fn& fn, long long j, long long K, long long sj, long long sk, T* __restrict__ Z, const double* __restrict__ tt,
+                                const double* __restrict__ dtt, const T* __restrict__ X0) {          // (sj, sk) = (1, M): time-major; (K, 1): trajectory-major
     constexpr int NX = Fn::NX, NU = Fn::NU, NZ = NX + NU, D = MIXED_PREFETCH;
     __builtin_amdgcn_s_setprio(3);
     T x[NX], u[NU], y[NX];
     {
-        const T* xs = X0 ? X0 + j * NX : Z + j * NZ;
+        const T* xs = X0 ? X0 + j * NX : Z + j * sj * NZ;
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xs[i];
     }
     if (K < 2) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) Z[j * NZ + i] = x[i];
+        for (int i = 0; i < NX; ++i) Z[j * sj * NZ + i] = x[i];
         __builtin_amdgcn_s_setprio(0);
         return;
     }
     const long long last = K - 1, nsteps = K - 1;
     T un[D][NU]; double hn[D], tn[D];
     auto fetch = [&](int d, long long knot) {
-        const long long idx = j + knot * M;
+        const long long idx = j * sj + knot * sk;
         hn[d] = dtt[idx]; tn[d] = tt[idx];
 #pragma unroll
         for (int i = 0; i < NU; ++i) un[d][i] = Z[idx * NZ + NX + i];
@@ -69,7 +71,7 @@ RD_DEV void mixed_small_rollout(const Fn& fn, long long j, long long K, long lon
     for (int d = 0; d < D; ++d) fetch(d, d < last ? d : last);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Z[j * NZ + i] = x[i];
+    for (int i = 0; i < NX; ++i) Z[j * sj * NZ + i] = x[i];
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](long long k, int d) {
         const double h = hn[d]; const T tk = (T)tn[d];
@@ -78,7 +80,7 @@ RD_DEV void mixed_small_rollout(const Fn& fn, long long j, long long K, long lon
         fetch(d, k + D < last ? k + D : last);
         __builtin_amdgcn_sched_barrier(0);
         fn.eval(x, u, tk, (T)h, y);
-        T* Zk = Z + (j + (k + 1) * M) * NZ;
+        T* Zk = Z + (j * sj + (k + 1) * sk) * NZ;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { x[i] = y[i]; Zk[i] = y[i]; }
     };
@@ -100,7 +102,7 @@ RD_DEV unsigned long long* mixed_flag_word(unsigned long long* progress, int GA)
 // NB + 1 waves (three state blocks + the IO wave); wave NB + 1 + i simulates B's group b + i GA.  First version: B's rollout on workgroups of its own
 // (16 for config 5) -- they were missing from the Jacobian workgroups for the whole first part of the walk (176 instead of 192: 232 instead of 225 us for A's
 // tiles, profiles/r06/c5_mixed_attempts.txt).  B's one-lane chain beside A's cascade waves costs A's rollout a few percent (one more wave on one SIMD).
-template <class FnA, class T, class Cas, int R, class Plan, int NC, class FnB>
+template <class FnA, class T, class Cas, int R, class Plan, int NC, class FnB, bool TM>
 RD_DEV void mixed_rollout_role(const FnA& fa, long long KA, long long MA, T* __restrict__ ZA, const double* __restrict__ tA, const double* __restrict__ dtA, const T* __restrict__ X0A,
                                const FnB& fb, long long KB, long long MB, int GA, T* __restrict__ ZB, const double* __restrict__ tB, const double* __restrict__ dtB, const T* __restrict__ X0B,
                                unsigned long long* __restrict__ progress, unsigned long long pbase) {
@@ -112,14 +114,14 @@ RD_DEV void mixed_rollout_role(const FnA& fa, long long KA, long long MA, T* __r
     const int nfull = (whole && KA >= 2) ? (int)((KA - 1) / L::S) : 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned long long* pword = progress + (size_t)blockIdx.x * FUSED_PROGRESS_STRIDE;
-    if (wave <= Cas::NB) CascadeWaves<FnA, T, Cas, R, 0, true>::run(wave, fa, KA, MA, 1LL, MA, ZA, tA, dtA, X0A, nfull, pword, pbase);
+    if (wave <= Cas::NB) CascadeWaves<FnA, T, Cas, R, 0, true>::run(wave, fa, KA, MA, TM ? 1LL : KA, TM ? MA : 1LL, ZA, tA, dtA, X0A, nfull, pword, pbase);
     else {
         const long long ngB = (MB + TILE - 1) / TILE;
         const long long g = (long long)blockIdx.x + (long long)(wave - Cas::NB - 1) * GA;
         if (g < ngB) {
             long long j = g * TILE + lane;
             j = j < MB ? j : MB - 1;                            // lanes past the batch redo the last trajectory: same values to the same addresses
-            mixed_small_rollout<FnB, T>(fb, j, KB, MB, ZB, tB, dtB, X0B);
+            mixed_small_rollout<FnB, T>(fb, j, KB, TM ? 1LL : KB, TM ? MB : 1LL, ZB, tB, dtB, X0B);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's state stores are written back (and acknowledged) before it counts itself finished
             if (lane == 0) {
                 unsigned long long* bflag = mixed_flag_word(progress, GA);
@@ -135,7 +137,7 @@ RD_DEV void mixed_rollout_role(const FnA& fa, long long KA, long long MA, T* __r
     if (threadIdx.x == 0) pub_progress(pword, pbase, KA);
 }
 
-template <class FnA, class T, class Cas, int R, class Plan, int NC, class FnB>
+template <class FnA, class T, class Cas, int R, class Plan, int NC, class FnB, bool TM = true>
 __global__ void __launch_bounds__(FUSED_THREADS, (fused_min_waves<T, R>()))
 rollout_jac_mixed_kernel(FnA fa, long long KA, long long MA, int GA, T* __restrict__ ZA, const double* __restrict__ tA, const double* __restrict__ dtA, const T* __restrict__ X0A,
                          T* __restrict__ JA, FnB fb, long long KB, long long MB, int GB, T* __restrict__ ZB, const double* __restrict__ tB, const double* __restrict__ dtB,
@@ -145,19 +147,20 @@ rollout_jac_mixed_kernel(FnA fa, long long KA, long long MA, int GA, T* __restri
     unsigned long long* bflag = mixed_flag_word(progress, GA);
     if ((int)blockIdx.x < GA) {
         // GB = 0: B's rollout rides on the idle waves of A's rollout workgroups (MB passed); GB > 0: B has workgroups of its own (MB = 0 here)
-        mixed_rollout_role<FnA, T, Cas, R, Plan, NC, FnB>(fa, KA, MA, ZA, tA, dtA, X0A, fb, KB, GB == 0 ? MB : 0, GA, ZB, tB, dtB, X0B, progress, pbase);
+        mixed_rollout_role<FnA, T, Cas, R, Plan, NC, FnB, TM>(fa, KA, MA, ZA, tA, dtA, X0A, fb, KB, GB == 0 ? MB : 0, GA, ZB, tB, dtB, X0B, progress, pbase);
         __syncthreads();
     } else if ((int)blockIdx.x < GA + GB) {
-        // B's rollout on workgroups of its own, MIXED_WPB waves each (one per SIMD): for SMALL batches, where A's rollout is the launch's critical path and
+        // B's rollout on workgroups of its own, mixed_wpb() waves each: for SMALL batches, where A's rollout is the launch's critical path and
         // a second chain on its SIMDs would stretch it (config 5's 8-way share, 8 + 8 groups: 135 us this way, 151 us on A's idle waves; the whole config
         // the other way round: 261 against 255 us, profiles/r06/c5_mixed_attempts.txt)
         const long long ngB = (MB + TILE - 1) / TILE;
-        const long long g = (long long)((int)blockIdx.x - GA) * MIXED_WPB + wave;
-        if (wave < MIXED_WPB && g < ngB) {
+        constexpr int WPB = mixed_wpb<TM>();
+        const long long g = (long long)((int)blockIdx.x - GA) * WPB + wave;
+        if (wave < WPB && g < ngB) {
             const int lane = threadIdx.x & 63;
             long long j = g * TILE + lane;
             j = j < MB ? j : MB - 1;
-            mixed_small_rollout<FnB, T>(fb, j, KB, MB, ZB, tB, dtB, X0B);
+            mixed_small_rollout<FnB, T>(fb, j, KB, TM ? 1LL : KB, TM ? MB : 1LL, ZB, tB, dtB, X0B);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (lane == 0) {
                 unsigned* cnt = reinterpret_cast<unsigned*>(bflag + 1);
@@ -170,8 +173,12 @@ rollout_jac_mixed_kernel(FnA fa, long long KA, long long MA, int GA, T* __restri
         __syncthreads();
     }
     // ---- A's Jacobian tiles: ONE call site of the tile loop, the walk covers both parts (fused.hpp) ----
-    {
+    if constexpr (TM) {
         const RolloutTilesTM<T> rt{KA, MA, GA, ZA, tA, dtA, JA, progress, pbase, FusedWalk::make(blockIdx.x, gridDim.x, (unsigned)(GA + GB), split, KA * GA)};
+        jac_split_loop<FnA, T, Plan, NC, AdUnrolledBody<FnA, T, Plan>>(fa, rt);
+    } else {                                                    // a vector of trajectories (the reference's layout): gathered tiles of 4 trajectories x 16 knots (fused.hpp)
+        const int Q = (int)((MA + GATHER_NRUN - 1) / GATHER_NRUN);
+        const RolloutTilesTJ<T> rt{KA, MA, Q, ZA, tA, dtA, JA, progress, pbase, FusedWalk::make(blockIdx.x, gridDim.x, (unsigned)(GA + GB), split, ((KA + GATHER_RUN - 1) / GATHER_RUN) * Q)};
         jac_split_loop<FnA, T, Plan, NC, AdUnrolledBody<FnA, T, Plan>>(fa, rt);
     }
     // ---- B's Jacobians: one 64-knot tile of the flat stack per wave and trip ----

@@ -389,8 +389,8 @@ def test_sweep_rollout_and_rollout_jacobian(name, dname):
             assert_periodic(got, Zr[:, :, :c.n], atol, rtol, f"{name}/{dname} rollout_split {rule.__name__} M={M} K={K} time_major={tm}")
         # an initial state of its own (x0) and the Jacobians along the rollout in the same call
         shapes = [(72, 9, False), (72, 9, True)]                      # (a multiple of 4: the fp32 time-major one-launch form wants 16-byte aligned rows of tiles)
-        if c.f32 and rule in (RD.RK3, RD.RK4) and name.startswith(("sat_", "quad_")):
-            shapes.append((4096, 5, True))                            # 64 rollout groups, bound by the Jacobian workgroups: the two-workgroups-per-CU form (fused.hpp)
+        if c.f32 and rule in (RD.RK3, RD.RK4) and name.startswith(("sat_", "quad_")) and ROTCODE[c.model.rotation] == 0:
+            shapes += [(4096, 5, True), (4096, 20, False)]            # 64 rollout groups, bound by the Jacobian workgroups: the two-workgroups-per-CU forms (fused.hpp)
         for M, K, tm in shapes:
             st, Zb, tb, dtb = _stack(c, M, K, tm, seed=11)
             x0 = tile_rows(Zb[:, 0, :c.n] * 0.5 + 0.25 * Zb[:, 1, :c.n], M)
@@ -472,19 +472,20 @@ def test_sweep_implicit_midpoint(name, dname):
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the mixed-model batch as ONE launch (csrc/mixed.hpp): satellite + cartpole under RK3 / RK4, fp32 / fp64, both placements of the cartpole's rollout
 # ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tm", [True, False], ids=["time_major", "trajectory_major"])
 @pytest.mark.parametrize("dname", ["f64", "f32"])
 @pytest.mark.parametrize("rule", [RD.RK3, RD.RK4])
-def test_sweep_mixed_model_call_in_one_launch(rule, dname):
+def test_sweep_mixed_model_call_in_one_launch(rule, dname, tm):
     ca, cb = case_of("sat_wd", dname), case_of("cartpole", dname)
     for idle in (0, 1):
         for MA, MB, K in ((132, 200, 9), (64, 64, 5)) + (((4096, 4096, 5),) if dname == "f32" and idle == 1 else ()):      # (the last: the two-per-CU form)
             RD.tune(f"mixed_idle={idle}")
             try:
-                sa, Za, ta, da = _stack(ca, MA, K, True, seed=23)
-                sb, Zb, tb, db = _stack(cb, MB, K, True, seed=29)
+                sa, Za, ta, da = _stack(ca, MA, K, tm, seed=23)
+                sb, Zb, tb, db = _stack(cb, MB, K, tm, seed=29)
                 funs = [RD.DiscretizedDynamics(ca.model, rule), RD.DiscretizedDynamics(cb.model, rule)]
                 Js = [RD.alloc_jacobians(funs[0], MA * K, sa["data"]).fill_(float("nan")), RD.alloc_jacobians(funs[1], MB * K, sb["data"]).fill_(float("nan"))]
-                call = RD.PreparedRolloutJacobianMulti(SIG, RD.ForwardAD(), funs, Js, [sa, sb], None, time_major=True)
+                call = RD.PreparedRolloutJacobianMulti(SIG, RD.ForwardAD(), funs, Js, [sa, sb], None, time_major=tm)
                 call()
                 assert call.launches == 1 and "rollout_jac_mixed_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
                 ca.note()
@@ -494,11 +495,13 @@ def test_sweep_mixed_model_call_in_one_launch(rule, dname):
                 nz = c.n + c.m
                 Zr = c.om.rollout(ORULE[rule], Zbase, tbase, dbase)
                 s = max(1.0, float(np.abs(Zr).max()))
-                assert_periodic(st["data"].transpose(0, 1), Zr, *((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0)), f"mixed {c.name}/{dname} states {rule.__name__} idle={idle} M={M}")
+                got = st["data"].transpose(0, 1) if tm else st["data"]
+                assert_periodic(got, Zr, *((2e-4 * s, 2e-4) if c.f32 else (1e-10 * s, 0.0)), f"mixed {c.name}/{dname} states {rule.__name__} idle={idle} M={M} tm={tm}")
                 Jo, _ = c.om.jacobian(ORULE[rule], O.FORWARD_AD, Zr.reshape(-1, nz), tbase.reshape(-1), dbase.reshape(-1))
                 Jo = Jo.reshape(Zbase.shape[0], K, c.n, nz)
                 sj = max(1.0, float(np.abs(Jo).max()))
-                assert_periodic(J.reshape(K, M, c.n, nz).transpose(0, 1), Jo, *((1e-3 * sj, 1e-3) if c.f32 else (1e-10 * sj, 0.0)), f"mixed {c.name}/{dname} Jacobians {rule.__name__} idle={idle} M={M}")
+                Jg = J.reshape(K, M, c.n, nz).transpose(0, 1) if tm else J.reshape(M, K, c.n, nz)
+                assert_periodic(Jg, Jo, *((1e-3 * sj, 1e-3) if c.f32 else (1e-10 * sj, 0.0)), f"mixed {c.name}/{dname} Jacobians {rule.__name__} idle={idle} M={M} tm={tm}")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------

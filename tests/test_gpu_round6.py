@@ -177,18 +177,19 @@ def test_rollout_split_host_arrays_and_errors():
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the two-workgroups-per-CU forms of the fp32 one-launch kernels (csrc/fused.hpp fused_min_waves, csrc/fam_mixed.hip): what BASELINE config 5 runs on
 # ------------------------------------------------------------------------------------------------------------------------------------------
-def _tm_stack(rng, M, K, mctl, ulo, uhi, rigid=True):
+def _tm_stack(rng, M, K, mctl, ulo, uhi, rigid=True, tm=True):
     Zn = H.rand_rigid(rng, M * K, mctl, ulo, uhi).reshape(M, K, 13 + mctl) if rigid else (rng.random((M, K, 5)) - np.array([0.4, 0.4, 0.4, 0.4, 0.0]))
     t = np.broadcast_to(np.arange(K) * 0.02, (M, K)).copy()
     dt = np.full((M, K), 0.02)
     dt[::7, K // 2] = 0.0                                             # a terminal knot inside some trajectories
-    st = {"data": torch.as_tensor(np.ascontiguousarray(Zn.transpose(1, 0, 2)).astype(np.float32)).cuda(), "t": torch.as_tensor(np.ascontiguousarray(t.T)).cuda(),
-          "dt": torch.as_tensor(np.ascontiguousarray(dt.T)).cuda()}
+    lay = (lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))) if tm else np.ascontiguousarray
+    st = {"data": torch.as_tensor(lay(Zn).astype(np.float32)).cuda(), "t": torch.as_tensor(lay(t)).cuda(), "dt": torch.as_tensor(lay(dt)).cuda()}
     return Zn.astype(np.float32).astype(np.float64), t, dt, st
 
 
+@pytest.mark.parametrize("tm", [True, False], ids=["time_major", "trajectory_major"])
 @pytest.mark.parametrize("case", ["satellite_rk4", "quadrotor_rk3", "satellite_body_rk4"])
-def test_two_per_cu_one_launch_form_ragged_groups_x0_and_the_one_per_cu_twin(case):
+def test_two_per_cu_one_launch_form_ragged_groups_x0_and_the_one_per_cu_twin(case, tm):
     """rollout! + jacobian! in ONE launch for a batch that is bound by its Jacobian workgroups (65 groups of 64 trajectories, the last one ragged): fp32,
     time-major, an initial state of its own -- the kernel under 128 registers, two workgroups per CU.  States and Jacobians against the
     oracle, and bit for bit against the one-workgroup-per-CU kernel (RDHIP_TUNE fused_two_per_cu=0: the same arithmetic in another register budget) and
@@ -203,7 +204,7 @@ def test_two_per_cu_one_launch_form_ragged_groups_x0_and_the_one_per_cu_twin(cas
     rng = np.random.default_rng(606)
     M, K, n = 4100, 21, 13
     nz = n + mctl
-    Zn, t, dt, st = _tm_stack(rng, M, K, mctl, ulo, uhi)
+    Zn, t, dt, st = _tm_stack(rng, M, K, mctl, ulo, uhi, tm=tm)
     x0 = Zn[:, 1, :n].copy(); x0[:, :3] *= 0.5
     x0 = x0.astype(np.float32)
     fun = RD.DiscretizedDynamics(model, rule)
@@ -214,7 +215,7 @@ def test_two_per_cu_one_launch_form_ragged_groups_x0_and_the_one_per_cu_twin(cas
         J = RD.alloc_jacobians(fun, M * K, s2["data"]); J.fill_(float("nan"))
         RD.tune(knob)
         try:
-            launches = RD.rollout_jacobian_(sig, AD, fun, J, s2, x0=torch.as_tensor(x0).cuda(), time_major=True)
+            launches = RD.rollout_jacobian_(sig, AD, fun, J, s2, x0=torch.as_tensor(x0).cuda(), time_major=tm)
             name = RD.last_kernel_name()
         finally:
             RD.tune("reset")
@@ -224,27 +225,30 @@ def test_two_per_cu_one_launch_form_ragged_groups_x0_and_the_one_per_cu_twin(cas
     assert torch.equal(outs["fused_two_per_cu=1"][0], outs["fused_two_per_cu=0"][0])
     assert torch.equal(outs["fused_two_per_cu=1"][1], outs["fused_two_per_cu=0"][1])
     s3 = {k: v.clone() for k, v in st.items()}
-    RD.rollout_(sig, fun, s3, torch.as_tensor(x0).cuda(), time_major=True)
+    RD.rollout_(sig, fun, s3, torch.as_tensor(x0).cuda(), time_major=tm)
     assert torch.equal(s3["data"], outs["fused_two_per_cu=1"][0])
     Zr = om.rollout(orule, Zn, t, dt, X0=x0.astype(np.float64))
-    got = host(outs["fused_two_per_cu=1"][0]).astype(np.float64).transpose(1, 0, 2)
+    got = host(outs["fused_two_per_cu=1"][0]).astype(np.float64)
+    got = got.transpose(1, 0, 2) if tm else got
     np.testing.assert_allclose(got[:, :, :n], Zr[:, :, :n], rtol=2e-4, atol=2e-4)
     np.testing.assert_array_equal(got[:, :, n:], Zn[:, :, n:])
     sl = slice(4032, 4100)                                            # the ragged last group and the one before it: Jacobians at the GPU's own fp32 states
     Zs = got[sl].reshape(-1, nz)
     Jo, _ = om.jacobian(orule, O.FORWARD_AD, Zs, t[sl].reshape(-1), dt[sl].reshape(-1))
-    Jg = host(outs["fused_two_per_cu=1"][1]).astype(np.float64).reshape(K, M, n, nz).transpose(1, 0, 2, 3)[sl].reshape(-1, n, nz)
+    Jg = host(outs["fused_two_per_cu=1"][1]).astype(np.float64)
+    Jg = (Jg.reshape(K, M, n, nz).transpose(1, 0, 2, 3) if tm else Jg.reshape(M, K, n, nz))[sl].reshape(-1, n, nz)
     np.testing.assert_allclose(Jg, Jo, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(Jo).max()))
 
 
-def test_two_per_cu_mixed_model_launch_ragged_groups():
+@pytest.mark.parametrize("tm", [True, False], ids=["time_major", "trajectory_major"])
+def test_two_per_cu_mixed_model_launch_ragged_groups(tm):
     """BASELINE config 5's call shape with ragged group counts: 4 100 satellite + 4 099 cartpole trajectories x 21 knots, fp32, ONE launch of the
     two-workgroups-per-CU mixed kernel; states of both models and the cartpole's Jacobians against the oracle, bit for bit against the one-per-CU twin."""
     rng = np.random.default_rng(607)
     MA, MB, K = 4100, 4099, 21
     sat, cart = RD.Satellite(2.0, np.diag([2.0, 3.0, 1.0])), RD.Cartpole()
-    Za, ta, da, sa = _tm_stack(rng, MA, K, 6, 0.0, 1.0)
-    Zb, tb, db, sb = _tm_stack(rng, MB, K, 1, 0.0, 1.0, rigid=False)
+    Za, ta, da, sa = _tm_stack(rng, MA, K, 6, 0.0, 1.0, tm=tm)
+    Zb, tb, db, sb = _tm_stack(rng, MB, K, 1, 0.0, 1.0, rigid=False, tm=tm)
     funs = [RD.DiscretizedDynamics(sat, RD.RK4), RD.DiscretizedDynamics(cart, RD.RK4)]
     outs = {}
     for knob in ("fused_two_per_cu=1", "fused_two_per_cu=0"):
@@ -252,7 +256,7 @@ def test_two_per_cu_mixed_model_launch_ragged_groups():
         Js = [RD.alloc_jacobians(funs[0], MA * K, s1["data"]).fill_(float("nan")), RD.alloc_jacobians(funs[1], MB * K, s2["data"]).fill_(float("nan"))]
         RD.tune(knob)
         try:
-            call = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Js, [s1, s2], None, time_major=True)
+            call = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Js, [s1, s2], None, time_major=tm)
             call()
             assert call.launches == 1 and "rollout_jac_mixed_kernel" in RD.last_kernel_name(), RD.last_kernel_name()
             name = RD.last_kernel_name()
@@ -265,10 +269,13 @@ def test_two_per_cu_mixed_model_launch_ragged_groups():
         assert torch.equal(a[i], b[i]), i
     Zra = O.satellite(2.0, np.diag([2.0, 3.0, 1.0])).rollout(O.RK4, Za, ta, da)
     Zrb = O.cartpole().rollout(O.RK4, Zb, tb, db)
-    np.testing.assert_allclose(host(a[0]).astype(np.float64).transpose(1, 0, 2)[:, :, :13], Zra[:, :, :13], rtol=2e-4, atol=2e-4)
-    gb = host(a[1]).astype(np.float64).transpose(1, 0, 2)
+    ga = host(a[0]).astype(np.float64)
+    np.testing.assert_allclose((ga.transpose(1, 0, 2) if tm else ga)[:, :, :13], Zra[:, :, :13], rtol=2e-4, atol=2e-4)
+    gb = host(a[1]).astype(np.float64)
+    gb = gb.transpose(1, 0, 2) if tm else gb
     np.testing.assert_allclose(gb[:, :, :4], Zrb[:, :, :4], rtol=2e-4, atol=2e-4)
     sl = slice(4032, 4099)
     Jo, _ = O.cartpole().jacobian(O.RK4, O.FORWARD_AD, gb[sl].reshape(-1, 5), tb[sl].reshape(-1), db[sl].reshape(-1))
-    Jg = host(a[3]).astype(np.float64).reshape(K, MB, 4, 5).transpose(1, 0, 2, 3)[sl].reshape(-1, 4, 5)
+    Jg = host(a[3]).astype(np.float64)
+    Jg = (Jg.reshape(K, MB, 4, 5).transpose(1, 0, 2, 3) if tm else Jg.reshape(MB, K, 4, 5))[sl].reshape(-1, 4, 5)
     np.testing.assert_allclose(Jg, Jo, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(Jo).max()))
