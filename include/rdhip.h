@@ -421,9 +421,11 @@ int rdhip_rollout_layout(rdhip_ctx* ctx, const rdhip_model* model, int rule, int
  * device has compute units -- a rollout that is a latency chain, not one that fills the chip -- (small models, custom models, the models of a
  * mixed-model call that did not get the overlapped launch), in four pieces of consecutive knots with the Jacobians of a finished piece on an
  * internal stream beside the rollout of the next (RDHIP_TUNE=rolljac_pipe_min_knots=N in the environment moves the limit, 0 = never; results are those of
- * the two plain launches).  rdhip_ctx_last_rollout_jacobian_launches says which (1 = overlapped in one launch, 2 = back to back, more = in pieces).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered from 4 trajectories x 16 knots) while they are
- * latency-sized; from 262 144 knot points on they run the two launches, which is faster there (4 096 x 101 fp64 knots: 204 vs 250 us;
- * RDHIP_TUNE=fused_tj_max_knots=N in the environment moves the limit).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
+ * the two plain launches).  rdhip_ctx_last_rollout_jacobian_launches says which (1 = overlapped in one launch, 2 = back to back, more = in pieces).  RDHIP_TRAJECTORY_MAJOR stacks take the overlapped launch as well (tiles gathered
+ * from 4 trajectories x 16 knots): fp32 stacks of any size (4 096 x 256 satellite knots: 231 us against 288 for the two launches; time-major: 199), fp64
+ * stacks while they are latency-sized -- from 262 144 knot points on those run the two launches, which is faster there (4 096 x 101 fp64 knots: 204 vs 250 us;
+ * RDHIP_TUNE=fused_tj_max_knots=N in the environment moves the limit).  An fp32 launch of either layout under RK3 / RK4 that is bound by its Jacobian
+ * workgroups runs two workgroups per compute unit (RDHIP_TUNE=fused_two_per_cu=0: never).  Implicit rules take RDHIP_TRAJECTORY_MAJOR data only.
  * The Jacobian workgroups of the overlapped launch hold their compute unit while they wait for the rollout workgroups of the SAME launch; the
  * library therefore keeps at most one such launch in flight per device and process (a second one, from any context, is ordered behind the first by
  * an event edge).  Outside its reach: launches replayed from captured graphs side by side, and other processes sharing the GPU -- do not run two of
@@ -432,6 +434,11 @@ int rdhip_rollout_jacobian(rdhip_ctx* ctx, const rdhip_model* model, int rule, i
                            void* Z, const double* t, const double* dt, const void* X0, void* J, int memspace);
 int rdhip_ctx_last_rollout_jacobian_launches(rdhip_ctx* ctx, int* launches);
 /* rdhip_rollout_jacobian for up to four MODELS in one call -- the mixed-model Monte-Carlo batch (even trajectories one model, odd ones another;
+ * BASELINE config 5).  ONE kernel launch on the context's stream, no internal stream, for the pair that configuration names -- a RigidBody{QuatRotation}
+ * satellite (world-frame velocities, diagonal inertia) and the Cartpole under the same rule (RK3 or RK4), RDHIP_FORWARD_AD, device pointers, either
+ * layout (trajectory-major fp64 stacks: below 262 144 knot points), both models' stacks of the same layout: both rollouts and every Jacobian in one grid
+ * (csrc/mixed.hpp; 4 096 + 4 096 trajectories x 256 knots in fp32: 229 us time-major, 280 us trajectory-major).  RDHIP_TUNE=mixed=0: never.  Every other
+ * combination, as described from here on:
  * `for p in models: rollout!(sig, dmodel[p], Z[p], x0[p]); jacobian! along it`, src/trajectories.jl:436-441 + src/functionbase.jl:242-257): model p has
  * its own stack (K[p] knots x M[p] trajectories, arrays Z[p], t[p], dt[p], X0[p] or NULL, J[p]; rule[p] its quadrature rule; X0 itself may be NULL).
  * With device pointers every model runs on its own internal stream between one fork and one join on the context's stream: the rollouts' latency
