@@ -271,6 +271,15 @@ def secondary_metrics(dev, reps):
             res["streams_form_round5"] = {"us_per_call": us5, "frac_of_hbm_peak": alg / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_launches_per_call": 9, "launches_counted_in": "profiles/r05/c5_whole_timeline.txt (1 on the context's stream, 8 on the internal one)", "how": "RDHIP_TUNE mixed=0"}
         finally:
             RD.tune("reset")
+        res["layout"] = "time-major (knot k of all trajectories contiguous)"
+        try:                                                      # the same call on the reference's own layout: a vector of trajectories (trajectory-major stacks); one launch as well
+            stj = [{"data": st["data"].transpose(0, 1).contiguous(), "t": st["t"].t().contiguous(), "dt": st["dt"].t().contiguous()} for st in stacks]
+            c5j = RD.PreparedRolloutJacobianMulti(RD.StaticReturn(), RD.ForwardAD(), funs, Jc, stj, None, time_major=False)
+            usj = _timed_us(lambda i: c5j(), 20, warm=2)
+            res["trajectory_major"] = {"us_per_call": usj, "frac_of_hbm_peak": alg / (usj * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel_launches_per_call": c5j.launches}
+            del stj, c5j
+        except Exception as e:
+            res["trajectory_major"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         pr = _pmc_rows("c5_whole_one_call_fp32") if Mc == 4096 else {}
         if "rollout_jac_mixed_kernel" in pr:
             tr = pr["rollout_jac_mixed_kernel"]["write_bytes"] + pr["rollout_jac_mixed_kernel"]["read_bytes"]
