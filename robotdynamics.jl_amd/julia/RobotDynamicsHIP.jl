@@ -1112,7 +1112,7 @@ function jacobian_multi!(::RD.FunctionSignature, diff::RD.DiffMethod, fun::RD.Ab
     check(c, rc)
     last_multi_launches(c)
 end
-"kernel launches the last `jacobian_multi!` on `ctx` issued: 1 = fused into one launch, one (three for ImplicitMidpoint) per trajectory = the fallback"
+"kernel launches the last `jacobian_multi!` on `ctx` issued: 1 = fused into one launch, 3 (5 for ImplicitMidpoint) = gathered into one stack (diff methods without a batch-table kernel), otherwise one (three) per run of adjacent trajectories"
 function last_multi_launches(c::Context)
     k = Ref{Cint}(0)
     check(c, ccall((:rdhip_ctx_last_multi_launches, librdhip), Cint, (Ptr{Cvoid}, Ref{Cint}), c.ptr, k))
