@@ -21,7 +21,16 @@ template <class T, bool B, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidB
 template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, false, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadPlan; static constexpr int NC = 4; };
 // body-frame velocities: the same column assignment with f(z) from wave 3 (round 4, tune/tune_plan.hip -DQUAD -DBODYF=true: 32.7 -> 31.9 us; every plan tried
 // spills 170-370 bytes per lane there -- a body-frame rotor column is 685 fp64 instructions on its own)
-using QuadBodyPlan = TablePlanS<17, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 2, 2, 2, /*w*/ 0, 1, 2, /*u*/ 3, 3, 0, 1>;
+// (round 6: in the body frame the v columns are no longer free -- r' = R(q) v, v' = .. - w x v -- so they are dealt out, and one rotor column moves to the
+// wave that had them; with the copy-wave prefetch and paced stores below: 32.0 -> 28.9 us at 65 536 knots, same box, tune/tune_plan.hip -DQUAD -DBODYF=true)
+using QuadBodyPlan = TablePlanS<17, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /*v*/ 3, 0, 1, /*w*/ 0, 1, 2, /*u*/ 3, 2, 0, 1>;
+// The fp64 body-frame quadrotor's compute role does not fit 256 registers.  What the spills cost was not their count but WHICH values went: the next tile's
+// prefetched inputs -- to spill a loaded value the wave first waits for it, i.e. for a memory round trip under the launch's saturated store stream, at the
+// top of every tile (s_waitcnt vmcnt(0) in front of six scratch stores: the waves were parked 57 % of their cycles).  Compute-only 23.3 us, stores-only
+// 22.8 us, together 32 us.  So the COPY waves prefetch for this model (kernels.hpp CopyPrefetchOf: scratch 172 -> 64 bytes per lane) and pace their stores
+// (3 sleep units per store: the compute waves' remaining scratch accesses share the CU's memory path with them).  Measured on the satellites too, where
+// both changes LOSE (world frame 26.9 -> 28.9 us, body frame 29.2 -> 30.2: their compute roles hold their prefetch, and the copy role spills instead).
+template <bool D, bool GZ> struct CopyPrefetchModel<RigidBody<double, WRENCH_QUADROTOR, true, D, GZ>, double> { static constexpr bool value = true; static constexpr int PACE = 3; };
 template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, true, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadBodyPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls

@@ -349,6 +349,14 @@ template <class Plan> struct FirstSplitOf<Plan, decltype((void)Plan::FIRST_SPLIT
 // the implicit-function-theorem kernel) then runs beside the previous tile's arithmetic instead of in front of this tile's
 template <class Body, class = void> struct HelperOf { static constexpr bool value = false; static constexpr size_t BYTES = 0; };
 template <class Body> struct HelperOf<Body, decltype((void)Body::HELPER)> { static constexpr bool value = Body::HELPER; static constexpr size_t BYTES = Body::HELPER_BYTES; };
+// Body::COPY_PREFETCH: the next tile's inputs are requested by the COPY waves (at the top of an iteration, behind the previous tile's stores) and written to
+// the LDS input tile by them between barriers A and B, instead of riding in the compute waves' registers across the whole tile.  For bodies whose compute
+// role is out of registers: there the compiler SPILLED the prefetched values -- and to spill a value it must have arrived, so the compute waves sat in
+// s_waitcnt vmcnt(0) for a load round trip under a saturated store stream at the top of every tile (body-frame quadrotor: parked 57 % of their cycles,
+// profiles/r06/valu_roofline.md).  Body::COPY_PACE: s_sleep units behind every tile store of a copy wave -- the compute waves' remaining scratch accesses
+// queue behind the copy waves' stores on the CU's one memory path, and a burst of 32 stores per lane holds them up longer than a paced one.
+template <class Body, class = void> struct CopyPrefetchOf { static constexpr bool value = false; static constexpr int PACE = 0; };
+template <class Body> struct CopyPrefetchOf<Body, decltype((void)Body::COPY_PREFETCH)> { static constexpr bool value = Body::COPY_PREFETCH; static constexpr int PACE = Body::COPY_PACE; };
 template <class Body, class = void> struct EpilogueOf { static constexpr bool value = false; };
 template <class Body> struct EpilogueOf<Body, decltype((void)Body::EPILOGUE)> { static constexpr bool value = Body::EPILOGUE; };
 template <class Body, class = void> struct EarlyOf { static constexpr bool value = false; };
@@ -554,8 +562,12 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
         }
     }
 };
+// models whose ForwardAD tile loop prefetches through the copy waves and paces their stores (CopyPrefetchOf above; specialised next to the model)
+template <class Mdl, class T> struct CopyPrefetchModel { static constexpr bool value = false; static constexpr int PACE = 0; };
 template <class Fn, class T, class Plan> struct AdUnrolledBody {
     static constexpr bool EARLY = true;                     // AdCols passes barrier E at column Plan::FIRST_SPLIT of a first tile
+    static constexpr bool COPY_PREFETCH = CopyPrefetchModel<decltype(Fn::m), T>::value;
+    static constexpr int COPY_PACE = CopyPrefetchModel<decltype(Fn::m), T>::PACE;
     template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr) {
         if constexpr (G < Plan::NG) {
             if (fr.g == G) AdCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr);
@@ -691,6 +703,9 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // a six-wave workgroup stay under the 168 registers of three waves per SIMD, i.e. TWO workgroups per compute unit (see UnrollPolicy / F32_NC)
     constexpr int NPASS = ((sizeof(T) == 4 || Tune::NPASS_ANY) && NCC == 2 && !GATHER) ? 2 : 1;      // (Tune::NPASS_ANY: fp64 tiles too, tune/tune_ng.hip)
     constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
+    constexpr bool CPF = (CopyPrefetchOf<Body>::value || Tune::COPY_PREFETCH_ALL) && !GATHER && NA == 0 && !HELPER && NPASS == 1 && !WaitsOf<BT>::value && NCC * TILE >= 2 * TILE;
+    constexpr int PACE = Tune::COPY_PACE > 0 ? Tune::COPY_PACE : (CPF ? CopyPrefetchOf<Body>::PACE : 0);
+    constexpr int ZPTC = (TIN * NZ + NCC * TILE - 1) / (NCC * TILE);      // input elements per copy thread
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ntiles = (t_end >= 0 && t_end < bt.ntiles()) ? t_end : bt.ntiles();
@@ -856,7 +871,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + gather_z(nx, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 tpre = tp[gather_knot(nx, threadIdx.x & (TILE - 1))];
-            } else {
+            } else if constexpr (!CPF) {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + ((e < nin1 * NZ) ? k1 * NZ + e : 0)); }
             {
@@ -910,9 +925,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 }
                 }
             }
+            if constexpr (!CPF) {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
+            }
             __syncthreads();                               // barrier B: LDS tile drained into the copy waves' registers
             if (wave == 0) RD_STAMP(it, 3);
             cur = nx;
@@ -941,7 +958,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
         const int ct = threadIdx.x - NG * TILE;            // 0 .. NCC*64-1
         const V4* jsrc = reinterpret_cast<const V4*>(jt);
         const V4* ysrc = reinterpret_cast<const V4*>(yt);
-        __builtin_amdgcn_s_setprio(3);                     // the copy waves' few instructions are latency-critical for the store stream
+        __builtin_amdgcn_s_setprio(Tune::COPY_PRIO);       // the copy waves' few instructions are latency-critical for the store stream
         if constexpr (RING_N > 0) {                        // one lane per iteration, all lookups in flight together, while the compute waves fetch the first inputs
             const long long ti = tile + (long long)ct * tstep;
             if (ct < RING_N && ti < tend) ring_put<T>(ring[ct], bt.at(ti));
@@ -1002,6 +1019,23 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
             const int nk = (int)((cur.N - k0) < TILE ? (cur.N - k0) : TILE);
             T* __restrict__ J = cur.J; T* __restrict__ Y = cur.Y;
             V4 jv[JPP], yv[YPLc];
+            T zin[CPF ? ZPTC : 1]; double tin = 0;             // CPF: the next tile's inputs, requested now (behind the previous tile's stores in this wave's queue)
+            if constexpr (CPF) {
+                const long long nt_ = RD_NEXT_TILE(it);
+                const bool more_ = nt_ < tend;
+                TileRef<T> nx_;
+                if (RING_N > 0 && !dyn && it + 1 < RING_N) nx_ = more_ ? ring_get<T>(ring[it + 1]) : cur;
+                else nx_ = at_uniform<T>(bt, more_ ? nt_ : tile);
+                const long long k1_ = nx_.k0;
+                const int nk1_ = more_ ? (int)((nx_.N - k1_) < TILE ? (nx_.N - k1_) : TILE) : 0;
+                const int nin1_ = more_ ? (int)((nx_.N + Fn::NEXT - k1_) < TIN ? (nx_.N + Fn::NEXT - k1_) : TIN) : 0;
+                const T* __restrict__ Zn_ = nx_.Z;
+#pragma unroll
+                for (int r = 0; r < ZPTC; ++r) { const int e = r * (NCC * TILE) + ct; zin[r] = Zn_[(e < nin1_ * NZ) ? k1_ * NZ + e : 0]; }
+                const double* tp_ = (ct < TILE) ? nx_.t : nx_.dt;
+                const int idx_ = ct & (TILE - 1);
+                tin = tp_[(ct < 2 * TILE && idx_ < nk1_) ? k1_ + idx_ : 0];
+            }
             bool skip_early = false;
             if constexpr (ES > 0) {
                 if (first) {
@@ -1039,6 +1073,11 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this part of the tile is in registers
                 if (ps == NPASS - 1) {
                     if (ct < TILE) RD_STAMP(it, 9);
+                    if constexpr (CPF) {                   // the compute waves are past barrier A: the input tile is free
+#pragma unroll
+                        for (int r = 0; r < ZPTC; ++r) { const int e = r * (NCC * TILE) + ct; if (e < TIN * NZ) zs[e] = zin[r]; }
+                        if (ct < 2 * TILE) ts[ct] = tin;
+                    }
                     __syncthreads();                       // barrier B
                     // where the NEXT tile lives, looked up now: with a batch table this is two dependent scalar-memory round trips, which must pass under
                     // this tile's store issue and not between the last store and barrier A of the next tile (where the compute waves are already waiting)
@@ -1052,7 +1091,10 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                     if (ps * JPP + r >= JPLc) continue;
                     const int u = (ps * JPP + r) * (NCC * TILE) + ct;
                     if (ES > 0 && skip_early && early_line(u)) continue;
-                    if (u * 16 + 16 <= jbytes) RD_TILE_STORE_BUF(jrs, (unsigned)ct * 16u, (unsigned)((ps * JPP + r) * (NCC * TILE) * 16), jv[r]);
+                    if (u * 16 + 16 <= jbytes) {
+                        RD_TILE_STORE_BUF(jrs, (unsigned)ct * 16u, (unsigned)((ps * JPP + r) * (NCC * TILE) * 16), jv[r]);
+                        if constexpr (PACE > 0) __builtin_amdgcn_s_sleep(PACE);
+                    }
                     else if (u * 16 < jbytes) {            // partial last unit of a ragged tile: element-wise
                         const T* pv = reinterpret_cast<const T*>(&jv[r]);
                         T* pd = reinterpret_cast<T*>(jdst + u);

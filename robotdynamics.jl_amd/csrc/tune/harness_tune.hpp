@@ -48,6 +48,15 @@ struct HarnessTune : DefaultTune {
 #if defined(RD_FUSED_F32_MINW)
     static constexpr int FUSED_F32_MINW = RD_FUSED_F32_MINW;
 #endif
+#if defined(RD_COPY_PREFETCH_ALL)
+    static constexpr bool COPY_PREFETCH_ALL = true;
+#endif
+#if defined(RD_COPY_PACE)
+    static constexpr int COPY_PACE = RD_COPY_PACE;
+#endif
+#if defined(RD_COPY_PRIO)
+    static constexpr int COPY_PRIO = RD_COPY_PRIO;
+#endif
 #if defined(RD_IFT_ABL)
     static constexpr int IFT_ABL = RD_IFT_ABL;
 #endif
