@@ -474,6 +474,8 @@ template <class Fn, class T, class Plan, class Cas, int G, int C> struct FdCasca
 };
 template <class Fn, class T, class Plan, class Cas> struct FdCascadeBody {
     static constexpr bool EARLY = true;
+    static constexpr bool COPY_PREFETCH = CopyPrefetchFd<decltype(Fn::m), T>::value;      // (kernels.hpp CopyPrefetchOf; the models: fam_rigid.hpp)
+    static constexpr int COPY_PACE = 0;
     static constexpr int NX = Fn::NX, NS = rule_stages<Fn::RULE_ID>();
     template <int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&f0)[NX], const T (&S)[NS][NX]) {
         if constexpr (G < Plan::NG) {

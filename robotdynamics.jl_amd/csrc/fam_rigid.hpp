@@ -31,6 +31,9 @@ using QuadBodyPlan = TablePlanS<17, 4, 3, 10, /*r*/ 2, 2, 2, /*q*/ 0, 1, 2, 3, /
 // (3 sleep units per store: the compute waves' remaining scratch accesses share the CU's memory path with them).  Measured on the satellites too, where
 // both changes LOSE (world frame 26.9 -> 28.9 us, body frame 29.2 -> 30.2: their compute roles hold their prefetch, and the copy role spills instead).
 template <bool D, bool GZ> struct CopyPrefetchModel<RigidBody<double, WRENCH_QUADROTOR, true, D, GZ>, double> { static constexpr bool value = true; static constexpr int PACE = 3; };
+// FiniteDifference, fp64 body-frame satellite (92 B of scratch, the same stall): 32.2 -> 29.6 us with the copy-wave prefetch (0.57 -> 0.62); the body-frame
+// quadrotor's FiniteDifference kernel spills 12 B and gains nothing, the world-frame kernels lose (28.4 -> 29.4 us): tune/tune_plan.hip -DFDK
+template <bool D, bool GZ> struct CopyPrefetchFd<RigidBody<double, WRENCH_SATELLITE, true, D, GZ>, double> { static constexpr bool value = true; };
 template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, true, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadBodyPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls

@@ -564,6 +564,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 };
 // models whose ForwardAD tile loop prefetches through the copy waves and paces their stores (CopyPrefetchOf above; specialised next to the model)
 template <class Mdl, class T> struct CopyPrefetchModel { static constexpr bool value = false; static constexpr int PACE = 0; };
+template <class Mdl, class T> struct CopyPrefetchFd { static constexpr bool value = false; };       // the same switch for the FiniteDifference body (cascade.hpp)
 template <class Fn, class T, class Plan> struct AdUnrolledBody {
     static constexpr bool EARLY = true;                     // AdCols passes barrier E at column Plan::FIRST_SPLIT of a first tile
     static constexpr bool COPY_PREFETCH = CopyPrefetchModel<decltype(Fn::m), T>::value;

@@ -65,8 +65,16 @@ using P4 = TablePlanS<19, 4, 2, 10, 0, 0, 0, 0, 1, 2, 3, 0, 1, 3, 0, 1, 2, 0, 1,
 using P5 = TablePlanS<19, 4, 3, 10, 1, 1, 1, 0, 1, 2, 3, 0, 1, 3, 0, 1, 2, 0, 0, 1, 3, 3, 2>;     // r on wave 1, v spread, uF 0,0,1
 #endif
 template <class Plan> void run(const char* name, const Fn& fn, long long N, const TT* Z, const double* t, const double* dt, TT** J, TT** Y, hipStream_t s, int reps) {
+#if !defined(FDK)
     constexpr size_t lds = SplitLds<Fn, TT, Plan, 4>::BYTES;
+#endif
+#if defined(FDK)        // the FiniteDifference kernel along the cascade instead (the column plan is the model's own FdPlanOf: one row of output, run<P0> only)
+    using FP = typename FdPlanOf<Mdl>::Plan;
+    constexpr size_t lds = SplitLds<Fn, TT, FP, 4>::BYTES;
+    auto k = jac_fd_cascade_kernel<Fn, TT, FP, Cascade<Mdl>, 4>;
+#else
     auto k = jac_ad_split_kernel<Fn, TT, Plan, 4>;
+#endif
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
