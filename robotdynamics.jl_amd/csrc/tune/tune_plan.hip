@@ -77,7 +77,8 @@ template <class Plan> void run(const char* name, const Fn& fn, long long N, cons
 #endif
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
+    static const int grid = getenv("TP_GRID") ? atoi(getenv("TP_GRID")) : 256;
+    auto launch = [&](int i) { hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, fn, N, Z, t, dt, J[i % 4], Y[i % 4], (unsigned*)nullptr); };
     for (int i = 0; i < 3000; ++i) launch(i);
     CK(hipStreamSynchronize(s));
     double best = 1e30, sum = 0;
