@@ -34,6 +34,10 @@ template <bool D, bool GZ> struct CopyPrefetchModel<RigidBody<double, WRENCH_QUA
 // FiniteDifference, fp64 body-frame satellite (92 B of scratch, the same stall): 32.2 -> 29.6 us with the copy-wave prefetch (0.57 -> 0.62); the body-frame
 // quadrotor's FiniteDifference kernel spills 12 B and gains nothing, the world-frame kernels lose (28.4 -> 29.4 us): tune/tune_plan.hip -DFDK
 template <bool D, bool GZ> struct CopyPrefetchFd<RigidBody<double, WRENCH_SATELLITE, true, D, GZ>, double> { static constexpr bool value = true; };
+// UserDefined (chain rule on the analytic stage Jacobians), fp64 body frame: 180 B of scratch in both.  Satellite 38.1 -> 36.4 us with the prefetch (pace loses),
+// quadrotor 39.1 -> 35.6 with the prefetch, 33.8 with pace 3 on top (tune/tune_plan.hip -DCHAINK)
+template <bool D, bool GZ> struct CopyPrefetchChain<RigidBody<double, WRENCH_SATELLITE, true, D, GZ>, double> { static constexpr bool value = true; static constexpr int PACE = 0; };
+template <bool D, bool GZ> struct CopyPrefetchChain<RigidBody<double, WRENCH_QUADROTOR, true, D, GZ>, double> { static constexpr bool value = true; static constexpr int PACE = 3; };
 template <class T, bool D, bool GZ, int RULE> struct UnrollPolicy<RigidBody<T, WRENCH_QUADROTOR, true, D, GZ>, RULE> { static constexpr bool value = true; using Plan = QuadBodyPlan; static constexpr int NC = 4; };
 
 // error-state columns of a rigid body: r 0-2, phi 3-5, v 6-8, w 9-11, then the controls

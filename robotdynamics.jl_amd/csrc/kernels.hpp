@@ -565,6 +565,7 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 // models whose ForwardAD tile loop prefetches through the copy waves and paces their stores (CopyPrefetchOf above; specialised next to the model)
 template <class Mdl, class T> struct CopyPrefetchModel { static constexpr bool value = false; static constexpr int PACE = 0; };
 template <class Mdl, class T> struct CopyPrefetchFd { static constexpr bool value = false; };       // the same switch for the FiniteDifference body (cascade.hpp)
+template <class Mdl, class T> struct CopyPrefetchChain { static constexpr bool value = false; static constexpr int PACE = 0; };       // ... and for the UserDefined chain-rule body
 template <class Fn, class T, class Plan> struct AdUnrolledBody {
     static constexpr bool EARLY = true;                     // AdCols passes barrier E at column Plan::FIRST_SPLIT of a first tile
     static constexpr bool COPY_PREFETCH = CopyPrefetchModel<decltype(Fn::m), T>::value;
@@ -704,7 +705,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     // a six-wave workgroup stay under the 168 registers of three waves per SIMD, i.e. TWO workgroups per compute unit (see UnrollPolicy / F32_NC)
     constexpr int NPASS = ((sizeof(T) == 4 || Tune::NPASS_ANY) && NCC == 2 && !GATHER) ? 2 : 1;      // (Tune::NPASS_ANY: fp64 tiles too, tune/tune_ng.hip)
     constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
-    constexpr bool CPF = (CopyPrefetchOf<Body>::value || Tune::COPY_PREFETCH_ALL) && !GATHER && NA == 0 && !HELPER && NPASS == 1 && !WaitsOf<BT>::value && NCC * TILE >= 2 * TILE;
+    constexpr bool CPF = ((CopyPrefetchOf<Body>::value && !Tune::COPY_PREFETCH_NONE) || Tune::COPY_PREFETCH_ALL) && !GATHER && NA == 0 && !HELPER && NPASS == 1 && !WaitsOf<BT>::value && NCC * TILE >= 2 * TILE;
     constexpr int PACE = Tune::COPY_PACE > 0 ? Tune::COPY_PACE : (CPF ? CopyPrefetchOf<Body>::PACE : 0);
     constexpr int ZPTC = (TIN * NZ + NCC * TILE - 1) / (NCC * TILE);      // input elements per copy thread
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
@@ -1692,6 +1693,8 @@ template <class Fn, class T, class Plan, int CH, int G, int C, bool VALUE_PENDIN
 };
 template <class Fn, class T, class Plan> struct ChainUnrolledBody {
     static constexpr bool EARLY = true;
+    static constexpr bool COPY_PREFETCH = CopyPrefetchChain<decltype(Fn::m), T>::value;       // (CopyPrefetchOf; the models: fam_rigid.hpp)
+    static constexpr int COPY_PACE = CopyPrefetchChain<decltype(Fn::m), T>::PACE;
     template <int CH, int G> static RD_DEV void waves(const Fn& fn, JacFrame<Fn, T>& fr, const T (&x2)[Fn::NX], const T (&x3)[Fn::NX], const T (&x4)[Fn::NX]) {
         if constexpr (G < Plan::NG) {
             if (fr.g == G) ChainCols<Fn, T, Plan, CH, G, Plan::chunk_begin(CH), (CH == Plan::value_chunk && G == Plan::value_wave)>::run(fn, fr, x2, x3, x4);

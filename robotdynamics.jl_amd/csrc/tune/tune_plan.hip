@@ -11,6 +11,9 @@ using namespace rd;
 #ifndef BODYF
 #define BODYF false
 #endif
+#ifndef DYNK                // true: the instantiation that carries the dynamic tile schedule (what the library launches for fp64, with or without counter words)
+#define DYNK false
+#endif
 #ifndef DIAG
 #define DIAG true
 #endif
@@ -71,9 +74,11 @@ template <class Plan> void run(const char* name, const Fn& fn, long long N, cons
 #if defined(FDK)        // the FiniteDifference kernel along the cascade instead (the column plan is the model's own FdPlanOf: one row of output, run<P0> only)
     using FP = typename FdPlanOf<Mdl>::Plan;
     constexpr size_t lds = SplitLds<Fn, TT, FP, 4>::BYTES;
-    auto k = jac_fd_cascade_kernel<Fn, TT, FP, Cascade<Mdl>, 4>;
+    auto k = jac_fd_cascade_kernel<Fn, TT, FP, Cascade<Mdl>, 4, DYNK>;
+#elif defined(CHAINK)   // the UserDefined chain-rule kernel (the model's ForwardAD column plan)
+    auto k = jac_chain_split_kernel<Fn, TT, Plan, 4, DYNK>;
 #else
-    auto k = jac_ad_split_kernel<Fn, TT, Plan, 4>;
+    auto k = jac_ad_split_kernel<Fn, TT, Plan, 4, DYNK>;
 #endif
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
