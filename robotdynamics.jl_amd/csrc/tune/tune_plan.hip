@@ -41,13 +41,13 @@ using P3 = TablePlan<20, 4, 3, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2
 using P4 = TablePlanS<20, 4, 0, 7, 2, 2, 2, 2, 0, 0, 0, 3, 3, 3, 3, 1, 1, 1, 0, 2, 2, 1, 3, 3>;
 using P5 = TablePlanS<20, 4, 2, 4, 0, 1, 2, 3, 0, 0, 2, 0, 1, 2, 3, 1, 1, 3, 0, 2, 2, 1, 3, 3>;    // one q1 column per wave first (early 4), value from wave 2
 #elif defined(QUAD) && BODYF
-// body frame: the v columns are no longer free (r' = R(q) v, v' = .. - w x v): spread them
-using P0 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;     // shipped (QuadBodyPlan)
-using P1 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 3, 0, 1>;     // v on 3, 0, 1
-using P2 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // v on 3, 0, 1; u1 on 2
-using P3 = TablePlanS<17, 4, 2, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // ... value from wave 2
-using P4 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 2, 0, 1, 0, 1, 2, 3, 3, 0, 1>;     // v on 2, 0, 1
-using P5 = TablePlanS<17, 4, 2, 10, 3, 3, 3, 0, 1, 2, 3, 2, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // r on 3, v on 2, 0, 1, u 3, 2, 0, 1, value from 2
+// body frame: the v columns are no longer free (r' = R(q) v, v' = .. - w x v): spread them.  Round 6, second batch: around the shipped plan (P0 here)
+using P0 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // shipped (QuadBodyPlan)
+using P1 = TablePlanS<17, 4, 3, 7,  2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // early part = r, q only
+using P2 = TablePlanS<17, 4, 3, 13, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // early part = r, q, v, w
+using P3 = TablePlanS<17, 4, 2, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 3, 2, 0, 1>;     // value from wave 2
+using P4 = TablePlanS<17, 4, 3, 10, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 2, 3, 0, 1>;     // rotors 2, 3, 0, 1
+using P5 = TablePlanS<17, 4, 0, 10, 3, 3, 3, 0, 1, 2, 3, 3, 0, 1, 0, 1, 2, 2, 2, 0, 1>;     // r on 3, rotors 2, 2, 0, 1, value from 0
 #elif defined(QUAD)
 using P0 = TablePlanS<17, 4, 2, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;     // shipped (QuadPlan)
 using P1 = TablePlanS<17, 4, 0, 10, 2, 2, 2, 0, 1, 2, 3, 2, 2, 2, 0, 1, 2, 3, 3, 0, 1>;
