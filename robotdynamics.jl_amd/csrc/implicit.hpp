@@ -794,12 +794,21 @@ template <class Fn, class T, class Plan> struct IftBody {
     // just as fast (the store stream is bound by the memory system, not by the waves that feed it).
     static constexpr size_t HELPER_BYTES = ((size_t)TILE * NX * sizeof(T) + 16 + 15) / 16 * 16;
     static constexpr bool HELPER = SplitLds<Fn, T, Plan, 4>::BYTES + 2 * HELPER_BYTES <= 160 * 1024;
-    template <class TR> static RD_DEV void helper_tile(const Fn& fn, const TR& r, unsigned char* dst) {
-        if (fn.solve != 2 || Tune::IFT_ABL == 2) return;
+    static constexpr bool HELPER_STAGES = true;            // (kernels.hpp HelperStagesOf: zrow / tv / hv below)
+    // zrow, tv, hv (HELPER_STAGES): this lane's knot point as it stands in memory, for the loop to put into the LDS input tile
+    template <class TR> static RD_DEV void helper_tile(const Fn& fn, const TR& r, unsigned char* dst, int = 0, T* zrow = nullptr, double* tv = nullptr, double* hv = nullptr) {
         constexpr int NZ = NX + NU;
         const int lane = threadIdx.x & 63;
         const int nk = (int)((r.N - r.k0) < TILE ? (r.N - r.k0) : TILE);
         const long long k = r.k0 + (lane < nk ? lane : nk - 1);
+        if (fn.solve != 2 || Tune::IFT_ABL == 2) {
+            if (zrow) {
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) zrow[i] = r.Z[k * NZ + i];
+                *tv = r.t[k]; *hv = r.dt[k];
+            }
+            return;
+        }
         const double hd = r.dt[k];
         const T h = (T)hd, tj = (T)r.t[k];
         const bool term = is_terminal_dt(hd);
@@ -807,7 +816,12 @@ template <class Fn, class T, class Plan> struct IftBody {
 #pragma unroll
         for (int i = 0; i < NX; ++i) x1[i] = r.Z[k * NZ + i];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = term ? T(0) : r.Z[k * NZ + NX + i];
+        for (int i = 0; i < NU; ++i) { const T uv = r.Z[k * NZ + NX + i]; if (zrow) zrow[NX + i] = uv; u[i] = term ? T(0) : uv; }
+        if (zrow) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) zrow[i] = x1[i];
+            *tv = r.t[k]; *hv = hd;
+        }
         bool unconv = false;
         bool bad = R::newton(fn.m, x1, u, tj, h, fn.iters, fn.tol, xn, xl, &unconv);
         bad = bad || unconv;

@@ -357,6 +357,11 @@ template <class Body> struct HelperOf<Body, decltype((void)Body::HELPER)> { stat
 // queue behind the copy waves' stores on the CU's one memory path, and a burst of 32 stores per lane holds them up longer than a paced one.
 template <class Body, class = void> struct CopyPrefetchOf { static constexpr bool value = false; static constexpr int PACE = 0; };
 template <class Body> struct CopyPrefetchOf<Body, decltype((void)Body::COPY_PREFETCH)> { static constexpr bool value = Body::COPY_PREFETCH; static constexpr int PACE = Body::COPY_PACE; };
+// Body::HELPER_STAGES (bodies with HELPER): the helper wave, which reads the next tile's knot points for its own chain anyway, also puts them into the LDS
+// input tile between barriers A and B (lane = knot point: its row of NX + NU values, t, dt) -- the compute waves request nothing.  Same reason as
+// CopyPrefetchOf: the implicit-function-theorem kernel's compute role spilled its seven prefetch registers and waited for them at the top of every tile.
+template <class Body, class = void> struct HelperStagesOf { static constexpr bool value = false; };
+template <class Body> struct HelperStagesOf<Body, decltype((void)Body::HELPER_STAGES)> { static constexpr bool value = Body::HELPER_STAGES; };
 template <class Body, class = void> struct EpilogueOf { static constexpr bool value = false; };
 template <class Body> struct EpilogueOf<Body, decltype((void)Body::EPILOGUE)> { static constexpr bool value = Body::EPILOGUE; };
 template <class Body, class = void> struct EarlyOf { static constexpr bool value = false; };
@@ -706,6 +711,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
     constexpr int NPASS = ((sizeof(T) == 4 || Tune::NPASS_ANY) && NCC == 2 && !GATHER) ? 2 : 1;      // (Tune::NPASS_ANY: fp64 tiles too, tune/tune_ng.hip)
     constexpr int JPP = (JPLc + NPASS - 1) / NPASS;          // units per copy lane and pass
     constexpr bool CPF = ((CopyPrefetchOf<Body>::value && !Tune::COPY_PREFETCH_NONE) || Tune::COPY_PREFETCH_ALL) && !GATHER && NA == 0 && !HELPER && NPASS == 1 && !WaitsOf<BT>::value && NCC * TILE >= 2 * TILE;
+    constexpr bool HSTAGE = HELPER && HelperStagesOf<Body>::value && !Tune::NO_HELPER_STAGE && !GATHER && NA == 0 && Fn::NEXT == 0 && !WaitsOf<BT>::value;
     constexpr int PACE = Tune::COPY_PACE > 0 ? Tune::COPY_PACE : (CPF ? CopyPrefetchOf<Body>::PACE : 0);
     constexpr int ZPTC = (TIN * NZ + NCC * TILE - 1) / (NCC * TILE);      // input elements per copy thread
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[HELPER ? 2 * HelperOf<Body>::BYTES : 16];
@@ -873,7 +879,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + gather_z(nx, e < TILE * NZ ? e : 0)); }
                 const double* tp = (threadIdx.x < TILE) ? nx.t : nx.dt;
                 tpre = tp[gather_knot(nx, threadIdx.x & (TILE - 1))];
-            } else if constexpr (!CPF) {
+            } else if constexpr (!CPF && !HSTAGE) {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; zpre[r] = tile_load<CoherentOf<BT>::value>(Z + ((e < nin1 * NZ) ? k1 * NZ + e : 0)); }
             {
@@ -927,7 +933,7 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 }
                 }
             }
-            if constexpr (!CPF) {
+            if constexpr (!CPF && !HSTAGE) {
 #pragma unroll
             for (int r = 0; r < ZPT; ++r) { const int e = r * NTC + threadIdx.x; if (e < TIN * NZ) zs[e] = zpre[r]; }
             if (threadIdx.x < 2 * TILE) ts[threadIdx.x] = tpre;
@@ -948,10 +954,23 @@ RD_DEV void jac_split_loop(const Fn& fn, const BT& bt, unsigned wg, unsigned nwg
                 if (!Tune::HELPER_CHAIN_FIRST && first) { __syncthreads(); first = false; } // barrier E first: the early part of the first tile must not wait for the next tile's chain
                 const long long nxt = RD_NEXT_TILE(it);
                 RD_STAMP(it, 11);
+                T hz[HSTAGE ? NZ : 1]; double ht = 0, hh = 0;      // HSTAGE: this lane's knot point of the next tile (lanes past a ragged tile's end repeat its last one)
+                if constexpr (HSTAGE) {
+                    if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES, 0, hz, &ht, &hh);
+                } else {
                 if (nxt < tend) Body::helper_tile(fn, at_uniform<T>(bt, nxt), hbuf + (size_t)((it + 1) & 1) * HelperOf<Body>::BYTES);
+                }
                 RD_STAMP(it, 12);
                 if (Tune::HELPER_CHAIN_FIRST && first) { __syncthreads(); first = false; }  // (tuning: the next tile's chain in front of barrier E)
                 __syncthreads();                               // barrier A
+                if constexpr (HSTAGE) {                        // the compute waves are done with the input tile
+                    if (nxt < tend) {
+                        const int hl = threadIdx.x & 63;
+#pragma unroll
+                        for (int i = 0; i < NZ; ++i) zs[hl * NZ + i] = hz[i];
+                        ts[hl] = ht; ts[TILE + hl] = hh;
+                    }
+                }
                 __syncthreads();                               // barrier B
             }
         }

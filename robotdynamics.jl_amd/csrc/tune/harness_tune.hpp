@@ -48,6 +48,9 @@ struct HarnessTune : DefaultTune {
 #if defined(RD_FUSED_F32_MINW)
     static constexpr int FUSED_F32_MINW = RD_FUSED_F32_MINW;
 #endif
+#if defined(RD_NO_HELPER_STAGE)
+    static constexpr bool NO_HELPER_STAGE = true;
+#endif
 #if defined(RD_COPY_PREFETCH_NONE)
     static constexpr bool COPY_PREFETCH_NONE = true;
 #endif

@@ -21,6 +21,7 @@ struct DefaultTune {
     static constexpr bool HELPER_CHAIN_FIRST = false;   // helper wave: the next tile's chain in front of barrier E (tune/tune_ift.hip)
     static constexpr int F32_MINB = 2;             // register budget of the fp32 ForwardAD tile kernels, in waves per SIMD (see kernels.hpp)
     static constexpr int FUSED_F32_MINW = 2;       // the same for the fp32 fused rollout -> Jacobians kernel (fused.hpp)
+    static constexpr bool NO_HELPER_STAGE = false;     // the helper wave does not stage the next tile's inputs (A/B, tune/tune_ift.hip)
     static constexpr bool COPY_PREFETCH_NONE = false;  // no body prefetches through its copy waves (A/B of the models that do, tune/tune_plan.hip)
     static constexpr bool COPY_PREFETCH_ALL = false;   // every split-role body prefetches through its copy waves (kernels.hpp CopyPrefetchOf)
     static constexpr int COPY_PACE = 0;            // s_sleep units behind every tile store of a copy wave (tune/tune_plan.hip: do paced stores let the compute waves' scratch accesses through?)
