@@ -98,7 +98,7 @@ template <class Plan> void run(const char* name, const Fn& fn, long long N, cons
 }
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 400;
-    const long long N = 65536 * (8 / sizeof(TT));
+    const long long N = getenv("TP_N") ? atoll(getenv("TP_N")) : 65536 * (8 / sizeof(TT));
     std::vector<TT> hz((size_t)N * NZc); std::vector<double> ht(N), hdt(N, 0.1);
     for (long long k = 0; k < N; ++k) { for (int i = 0; i < NZc; ++i) hz[k * NZc + i] = (TT)(0.5 + 0.8 * ((k * NZc + i) * 2654435761u % 1000) / 1000.0); ht[k] = 0.1 * k; }
     TT *Z, *J[4], *Y[4]; double *t, *dt;
