@@ -416,3 +416,24 @@ def test_header_is_plain_c_and_the_c_demo_links_and_runs():
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "n=13 m=6 p=13 errstate_dim=12" in out.stdout
+
+
+def test_every_documented_tuning_knob_is_accepted_and_nothing_else():
+    """include/rdhip.h lists the keys of RDHIP_TUNE / rdhip_tune(): every key of that list must parse (the parser and the header are kept in step by this
+    test), an unknown key is an error that names it, and "reset" restores the environment's settings.  Host-only: no launch is issued."""
+    import rdhip._lib as L
+    text = open(L.HEADER_PATH).read()
+    block = text[text.index("Keys (csrc/common.hpp TuneKnobs):"):text.index("Not tuning, and still their own environment variables")]
+    keys = sorted(set(re.findall(r"\b([a-z_]+[a-z0-9_]*)=", block)))
+    assert {"static_grid", "dyn_grid", "dynamic_tiles", "small", "small_max", "rollout", "rolljac", "fused_ratio", "fused_jac_workgroups", "fused_tj_max_knots",
+            "rolljac_pipe_min_knots", "multi_main", "fused_two_per_cu", "mixed", "mixed_idle", "ift"} <= set(keys), keys
+    src = open(os.path.join(ROOT, "robotdynamics.jl_amd", "csrc", "api.hip")).read()
+    parsed = set(re.findall(r'key == "([a-z_0-9]+)"', src))
+    assert parsed == set(keys), (sorted(parsed - set(keys)), sorted(set(keys) - parsed))        # header and parser name the same knobs
+    try:
+        for k in keys:
+            RD.tune(f"{k}=1")
+        with pytest.raises(Exception, match="no_such_knob"):
+            RD.tune("no_such_knob=1")
+    finally:
+        RD.tune("reset")
