@@ -34,6 +34,12 @@ __global__ void __launch_bounds__(FUSED_THREADS, (sizeof(TT) == 4 ? Tune::FUSED_
     const BT rt{{K, M, G, Z, tt, dtt, J, progress, pbase, FusedWalk::make(blockIdx.x, gridDim.x, 0u, 0, K * G)}};
     jac_split_loop<Fn, TT, SatPlan, 4, AdUnrolledBody<Fn, TT, SatPlan>>(fn, rt);
 }
+// the same over a TRAJECTORY-major stack: gathered tiles of 4 trajectories x 16 knots (RolloutTilesTJ)
+template <int MW> __global__ void __launch_bounds__(FUSED_THREADS, MW) cons_only_tj(Fn fn, long long K, long long M, TT* Z, const double* tt, const double* dtt, TT* J, unsigned long long* progress, unsigned long long pbase) {
+    const int Q = (int)((M + GATHER_NRUN - 1) / GATHER_NRUN);
+    const RolloutTilesTJ<TT> rt{K, M, Q, Z, tt, dtt, J, progress, pbase, FusedWalk::make(blockIdx.x, gridDim.x, 0u, 0, ((K + GATHER_RUN - 1) / GATHER_RUN) * Q)};
+    jac_split_loop<Fn, TT, SatPlan, 4, AdUnrolledBody<Fn, TT, SatPlan>>(fn, rt);
+}
 template <int MW> __global__ void __launch_bounds__(FUSED_THREADS, MW) cons_only_w(Fn fn, long long K, long long M, int G, TT* Z, const double* tt, const double* dtt, TT* J, unsigned long long* progress, unsigned long long pbase) {
     const RolloutTilesTM<TT> rt{K, M, G, Z, tt, dtt, J, progress, pbase, FusedWalk::make(blockIdx.x, gridDim.x, 0u, 0, K * G)};
     jac_split_loop<Fn, TT, SatPlan, 4, AdUnrolledBody<Fn, TT, SatPlan>>(fn, rt);
@@ -114,6 +120,18 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(s));
         const unsigned long long pb = epoch << 32;
         timeit("consumer role alone behind the rollout (256)", [&]() { hipLaunchKernelGGL(cons_only, dim3(256), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
+        {
+            auto ctj1 = cons_only_tj<2>; auto ctj4 = cons_only_tj<4>;
+            CK(hipFuncSetAttribute((const void*)ctj1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
+            CK(hipFuncSetAttribute((const void*)ctj4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
+            timeit("  trajectory-major gathered tiles, consumer alone (256)", [&]() { hipLaunchKernelGGL(ctj1, dim3(256), dim3(FT), FL::BYTES, s, fn, K, M, Z, t, dt, J, prog, pb); });
+            if (2 * FL::BYTES <= 160 * 1024) {
+                timeit("  trajectory-major, 128 registers, two per CU (512)", [&]() { hipLaunchKernelGGL(ctj4, dim3(512), dim3(FT), FL::BYTES, s, fn, K, M, Z, t, dt, J, prog, pb); });
+                auto ctm4 = cons_only_w<4>;
+                CK(hipFuncSetAttribute((const void*)ctm4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
+                timeit("  time-major, 128 registers, two per CU (512)", [&]() { hipLaunchKernelGGL(ctm4, dim3(512), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
+            }
+        }
         CK(hipFuncSetAttribute((const void*)cons_only_v<TilesNoCoh>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
         CK(hipFuncSetAttribute((const void*)cons_only_v<TilesNoPoll>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
         CK(hipFuncSetAttribute((const void*)shell_plain<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
@@ -158,7 +176,13 @@ int main(int argc, char** argv) {
         if (nj <= 0) continue;
         char name[96]; snprintf(name, sizeof name, "fused: %d rollout + %d Jacobian workgroups, split at %.2f", GW, nj, split_frac);
         const long long split = (long long)(split_frac * K) * G;
+#if defined(FUSED_TJ)    // the trajectory-major form of the same launch (gathered tiles; strides (K, 1))
+        auto kfj = rollout_jac_fused_kernel<Fn, TT, Cas, FR, SatPlan, FNC, false>;
+        CK(hipFuncSetAttribute((const void*)kfj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
+        timeit(name, [&]() { ++epoch; hipLaunchKernelGGL(kfj, dim3(GW + nj), dim3(FT), FL::BYTES, s, fn, K, M, G, K, 1LL, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, 0LL); });
+#else
         timeit(name, [&]() { ++epoch; hipLaunchKernelGGL(kf, dim3(GW + nj), dim3(FT), FL::BYTES, s, fn, K, M, G, 1LL, M, Z, t, dt, (const TT*)nullptr, J, prog, epoch << 32, split); });
+#endif
 #if defined(RD_FUSED_STAMP)
         std::vector<unsigned long long> hp(4096);
         CK(hipMemcpy(hp.data(), stamps, 4096 * 8, hipMemcpyDeviceToHost));
