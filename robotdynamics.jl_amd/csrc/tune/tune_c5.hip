@@ -163,6 +163,8 @@ int main(int argc, char** argv) {
             report("stamps: plain descriptor (512,1)", [&]() { hipLaunchKernelGGL(shell_plain<1>, dim3(192), dim3(FT), FL::BYTES, s, fn, N, Z, t, dt, J); });
             report("stamps: consumer, no poll", [&]() { hipLaunchKernelGGL(cons_only_v<TilesNoPoll>, dim3(192), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
             report("stamps: consumer", [&]() { hipLaunchKernelGGL(cons_only, dim3(192), dim3(FT), FL::BYTES, s, fn, K, M, G, Z, t, dt, J, prog, pb); });
+            { auto ctj = cons_only_tj<2>; CK(hipFuncSetAttribute((const void*)ctj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL::BYTES));
+              report("stamps: consumer, trajectory-major tiles", [&]() { hipLaunchKernelGGL(ctj, dim3(192), dim3(FT), FL::BYTES, s, fn, K, M, Z, t, dt, J, prog, pb); }); }
             st = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_split_stamp), &st, sizeof st));
         }
 #endif
